@@ -1,0 +1,352 @@
+"""CPU oracle for the Legommenders two-tower hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a from-scratch *functional restatement* (flat id tensors, fp32 torch-CPU
+arithmetic) of the reference's `Legommender.forward` path for NAML and NRMS.  It is the
+checker the HIP kernels are compared against and the `cpu_baseline` ("port") leg of
+bench.py.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import it;
+the product package `legommenders_amd` never does (tests/test_no_oracle_in_product.py).
+
+Pinning: every function below is checked against golden vectors produced by importing the
+REAL reference in the build container (tests/golden/make_golden.py -> tests/golden/*.npz;
+tests/test_oracle_golden.py).  The reference has no tests of its own,
+so those generated vectors are the pins.
+
+Reference citations are relative to /root/reference.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+EPS = float(torch.finfo(torch.float32).eps)   # model/common/attention.py:36
+UNSET = -1                                      # loader/env.py:10
+PAD, CLS, SEP = 0, 1, 2                         # model/inputer/concat_inputer.py:27-30
+
+
+def _t(x, dtype=None):
+    if isinstance(x, torch.Tensor):
+        return x if dtype is None else x.to(dtype)
+    t = torch.from_numpy(np.ascontiguousarray(x))
+    return t if dtype is None else t.to(dtype)
+
+
+# --------------------------------------------------------------------------- a6
+def additive_attention(x, mask, W1, b1, w2):
+    """AdditiveAttention.forward  (model/common/attention.py:23-38).
+
+    a = w2 . tanh(W1 x + b1);  e = exp(a) * mask  (no max-subtraction);
+    w = e / (sum(e) + eps);    out = sum_l w_l x_l.     x:[n,L,D] mask:[n,L] -> [n,D]
+    """
+    a = torch.tanh(F.linear(x, W1, b1))
+    a = F.linear(a, w2).squeeze(-1)
+    e = torch.exp(a) * mask.to(x.dtype)
+    w = e / (e.sum(-1, keepdim=True) + EPS)
+    return (x * w.unsqueeze(-1)).sum(1)
+
+
+# --------------------------------------------------------------------------- a3 / a4
+def glove_project(tok, table, lin_w, lin_b):
+    """SimpleInputer.get_embeddings for a pre-trained column wrapped in `Transformation`
+    (model/inputer/simple_inputer.py:55-63; loader/embedding_hub.py:95-96, eval / p=0).
+
+    pad id -1 is rewritten to 0, row 0 is looked up and projected (+bias), and the result is
+    zeroed at masked positions.  tok:[n,T] int64 with -1 pads -> ([n,T,D], mask[n,T]).
+    """
+    mask = (tok > UNSET).long()
+    seq = tok * mask
+    emb = F.linear(F.embedding(seq, table), lin_w, lin_b)
+    return emb * mask.unsqueeze(-1).to(emb.dtype), mask
+
+
+def table_lookup(tok, table):
+    """Same inputer path with a plain trainable nn.Embedding (loader/embedding_hub.py:325-335)."""
+    mask = (tok > UNSET).long()
+    emb = F.embedding(tok * mask, table)
+    return emb * mask.unsqueeze(-1).to(emb.dtype), mask
+
+
+# --------------------------------------------------------------------------- a5
+def cnn_operator(title_emb, title_mask, cat_emb, P, prefix="item_op."):
+    """CNNOperator.forward (model/operators/cnn_operator.py:48-67), eval / dropout 0.
+
+    title (len>1 column): Conv1d(k=3,'same') -> ReLU -> *mask;  category (len-1 column):
+    Linear;  concat along L in `item.inputs` order (title, category);  additive pool.
+    """
+    y = F.conv1d(title_emb.permute(0, 2, 1), P[prefix + "cnn.weight"], P[prefix + "cnn.bias"], padding="same")
+    y = torch.relu(y.permute(0, 2, 1)) * title_mask.unsqueeze(-1).to(title_emb.dtype)
+    c = F.linear(cat_emb, P[prefix + "linear.weight"], P[prefix + "linear.bias"])
+    out = torch.cat([y, c], dim=1)
+    mask = torch.cat([title_mask, torch.ones_like(title_mask[:, :1])], dim=1)
+    return additive_attention(out, mask,
+                              P[prefix + "additive_attention.encoder.0.weight"],
+                              P[prefix + "additive_attention.encoder.0.bias"],
+                              P[prefix + "additive_attention.encoder.2.weight"])
+
+
+# --------------------------------------------------------------------------- a8
+def mhsa(x, mask, in_w, in_b, out_w, out_b, heads):
+    """nn.MultiheadAttention(batch_first, key_padding_mask=(1-mask).bool(), need_weights=False)
+    as called by AttentionOperator.forward (model/operators/attention_operator.py:49-55),
+    restated explicitly: packed in-proj, per-head softmax(QK^T/sqrt(hd)) with masked keys = -inf,
+    .V, out-proj.  attention-dropout = 0 (eval).  x:[n,L,D] mask:[n,L] -> [n,L,D]
+    """
+    n, L, D = x.shape
+    hd = D // heads
+    qkv = F.linear(x, in_w, in_b)
+    q, k, v = qkv.split(D, dim=-1)
+    q = q.view(n, L, heads, hd).transpose(1, 2)
+    k = k.view(n, L, heads, hd).transpose(1, 2)
+    v = v.view(n, L, heads, hd).transpose(1, 2)
+    s = (q * (1.0 / math.sqrt(hd))) @ k.transpose(-1, -2)
+    s = s.masked_fill((mask == 0)[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    o = (p @ v).transpose(1, 2).reshape(n, L, D)
+    return F.linear(o, out_w, out_b)
+
+
+def attention_operator(x, mask, P, prefix, heads):
+    """AttentionOperator.forward (model/operators/attention_operator.py:46-59): MHSA -> Linear -> additive pool."""
+    o = mhsa(x, mask, P[prefix + "multi_head_attention.in_proj_weight"],
+             P[prefix + "multi_head_attention.in_proj_bias"],
+             P[prefix + "multi_head_attention.out_proj.weight"],
+             P[prefix + "multi_head_attention.out_proj.bias"], heads)
+    o = F.linear(o, P[prefix + "linear.weight"], P[prefix + "linear.bias"])
+    return additive_attention(o, mask,
+                              P[prefix + "additive_attention.encoder.0.weight"],
+                              P[prefix + "additive_attention.encoder.0.bias"],
+                              P[prefix + "additive_attention.encoder.2.weight"])
+
+
+# --------------------------------------------------------------------------- a3'
+def concat_layout(title_tok, title_len, cat, use_sep=True):
+    """ConcatInputer.sample_rebuilder (model/inputer/concat_inputer.py:58-87), vectorised over items.
+
+    Compact `[title..., SEP, category, SEP, PAD...]`; three full-length id rows (title column,
+    category column, special-token column) filled with -1 where the column is absent; the special
+    column holds PAD(0) after the live prefix; mask = 1 on the live prefix.
+    """
+    n, T = title_tok.shape
+    L = T + 1 + (2 if use_sep else 0)
+    t_ids = torch.full((n, L), UNSET, dtype=torch.long)
+    c_ids = torch.full((n, L), UNSET, dtype=torch.long)
+    s_ids = torch.full((n, L), UNSET, dtype=torch.long)
+    ar = torch.arange(L)[None, :]
+    tl = title_len[:, None]
+    t_ids[:, :T] = title_tok
+    t_ids = torch.where(ar < tl, t_ids, torch.full_like(t_ids, UNSET))
+    rows = torch.arange(n)
+    if use_sep:
+        s_ids[rows, title_len] = SEP
+        c_ids[rows, title_len + 1] = cat
+        s_ids[rows, title_len + 2] = SEP
+        live = title_len + 3
+    else:
+        c_ids[rows, title_len] = cat
+        live = title_len + 1
+    s_ids = torch.where(ar >= live[:, None], torch.full_like(s_ids, PAD), s_ids)
+    mask = (ar < live[:, None]).long()
+    return t_ids, c_ids, s_ids, mask
+
+
+def concat_embed(t_ids, c_ids, s_ids, P, glove):
+    """ConcatInputer.get_embeddings (model/inputer/concat_inputer.py:92-114): sum of the three
+    masked full-length look-ups (mask = id > -1, so the PAD(0) special ids past the prefix ARE
+    looked up and added -- the operator's attention mask removes them later)."""
+    if glove:
+        e_t, _ = glove_project(t_ids, P["embedding_vocab_table.glove.embedding.weight"],
+                               P["embedding_vocab_table.glove.linear.weight"],
+                               P["embedding_vocab_table.glove.linear.bias"])
+    else:
+        e_t, _ = table_lookup(t_ids, P["embedding_vocab_table.glove.weight"])
+    e_c, _ = table_lookup(c_ids, P["embedding_vocab_table.category.weight"])
+    e_s, _ = table_lookup(s_ids, P["embedding_vocab_table.__cat_inputer_special_ids.weight"])
+    return e_t + e_c + e_s
+
+
+# --------------------------------------------------------------------------- a9 / a10
+def dot_scores(user, items):
+    """prepare_for_predictor + DotPredictor.predict (model/operators/base_operator.py:65-69,
+    model/predictors/dot_predictor.py:7-10, model/legommender.py:268-283). user:[B,D] items:[B,C,D]"""
+    return (user.unsqueeze(1) * items).sum(-1)
+
+
+def ce_label0(scores):
+    """nn.CrossEntropyLoss with labels == 0 (model/legommender.py:114-118,254,263)."""
+    return F.cross_entropy(scores, torch.zeros(scores.shape[0], dtype=torch.long))
+
+
+# --------------------------------------------------------------------------- a1 / a2 / a7
+def _item_ids(cand, hist):
+    """History pads are item 0 and ARE encoded by the reference (loader/resampler.py:222-223)."""
+    B, C = cand.shape
+    S = hist.shape[1]
+    return torch.cat([cand.reshape(-1), hist.reshape(-1)]), B, C, S
+
+
+def naml_forward(P: Dict[str, torch.Tensor], title_tok, cat, cand, hist, hist_len):
+    """Legommender.forward for NAML/GloVe (model/legommender.py:219-263), eval-mode logits [B,C]."""
+    ids, B, C, S = _item_ids(cand, hist)
+    tok = title_tok[ids]
+    emb, mask = glove_project(tok, P["embedding_vocab_table.glove.embedding.weight"],
+                              P["embedding_vocab_table.glove.linear.weight"],
+                              P["embedding_vocab_table.glove.linear.bias"])
+    cat_emb = F.embedding(cat[ids], P["embedding_vocab_table.category.weight"]).unsqueeze(1)
+    items = cnn_operator(emb, mask, cat_emb, P)                       # [B*(C+S), D]
+    D = items.shape[-1]
+    cand_v = items[: B * C].view(B, C, D)
+    hist_v = items[B * C:].view(B, S, D)
+    hmask = (torch.arange(S)[None, :] < hist_len[:, None]).long()     # __clicks_mask__
+    user = additive_attention(hist_v, hmask,                           # AdaOperator (ada_operator.py:31-34)
+                              P["user_op.additive_attention.encoder.0.weight"],
+                              P["user_op.additive_attention.encoder.0.bias"],
+                              P["user_op.additive_attention.encoder.2.weight"])
+    return dot_scores(user, cand_v)
+
+
+def nrms_forward(P, title_tok, title_len, cat, cand, hist, hist_len, heads=8, glove=False):
+    """Legommender.forward for NRMS (item + user AttentionOperator), eval-mode logits [B,C]."""
+    ids, B, C, S = _item_ids(cand, hist)
+    t_ids, c_ids, s_ids, mask = concat_layout(title_tok[ids], title_len[ids], cat[ids], use_sep=True)
+    x = concat_embed(t_ids, c_ids, s_ids, P, glove)
+    items = attention_operator(x, mask, P, "item_op.", heads)
+    D = items.shape[-1]
+    cand_v = items[: B * C].view(B, C, D)
+    hist_v = items[B * C:].view(B, S, D)
+    hmask = (torch.arange(S)[None, :] < hist_len[:, None]).long()
+    user = attention_operator(hist_v, hmask, P, "user_op.", heads)
+    return dot_scores(user, cand_v)
+
+
+def loss_and_grads(kind, P_np, tables, cand, hist, hist_len, heads=8, glove=True, frozen=()):
+    """Logits, loss and d(loss)/d(param) for every trainable tensor (dropout 0).  numpy in/out."""
+    P = {}
+    for k, v in P_np.items():
+        t = _t(v).clone()
+        if k not in frozen and t.dtype == torch.float32 and not k.endswith("glove.embedding.weight"):
+            t.requires_grad_(True)
+        P[k] = t
+    tt, tl, ct = _t(tables["title_tok"]), _t(tables["title_len"]), _t(tables["cat"])
+    c, h, hl = _t(cand), _t(hist), _t(hist_len)
+    if kind == "naml":
+        logits = naml_forward(P, tt, ct, c, h, hl)
+    else:
+        logits = nrms_forward(P, tt, tl, ct, c, h, hl, heads=heads, glove=glove)
+    loss = ce_label0(logits)
+    names = [k for k, v in P.items() if v.requires_grad]
+    grads = torch.autograd.grad(loss, [P[k] for k in names], allow_unused=True)
+    g = {k: (gv.numpy() if gv is not None else np.zeros_like(P_np[k])) for k, gv in zip(names, grads)}
+    return logits.detach().numpy(), float(loss), g
+
+
+# --------------------------------------------------------------------------- a13
+def linear_schedule_factor(step, total, warmup=0):
+    """transformers.get_linear_schedule_with_warmup lambda (base_lego.py:211-223)."""
+    if step < warmup:
+        return float(step) / float(max(1, warmup))
+    return max(0.0, float(total - step) / float(max(1, total - warmup)))
+
+
+def adam_step(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.Adam defaults, no weight decay, no amsgrad (base_lego.py:201-204). step is 1-based.
+    fp32 arrays; returns (p, m, v)."""
+    p, g, m, v = (np.asarray(a, dtype=np.float32) for a in (p, g, m, v))
+    m = (b1 * m + (1 - b1) * g).astype(np.float32)
+    v = (b2 * v + (1 - b2) * g * g).astype(np.float32)
+    bc1 = 1.0 - b1 ** step
+    bc2 = 1.0 - b2 ** step
+    denom = (np.sqrt(v) / np.float32(math.sqrt(bc2)) + np.float32(eps)).astype(np.float32)
+    p = (p - np.float32(lr / bc1) * (m / denom)).astype(np.float32)
+    return p, m, v
+
+
+# --------------------------------------------------------------------------- a11
+def sample_negatives_semantics(cand_row, true_negs, item_size, K=4):
+    """Property checker for the negative sampler (loader/resampler.py:159-171): the first
+    min(K,len(true_negs)) negatives are distinct draws from the user's true-negative list, the
+    remainder are uniform item ids in [0,item_size-1] (collisions allowed).  Returns bool."""
+    negs = list(cand_row[1:])
+    if len(negs) != K:
+        return False
+    n_true = min(K, len(true_negs))
+    pool = list(true_negs)
+    for x in negs[:n_true]:
+        if x not in pool:
+            return False
+        pool.remove(x)
+    return all(0 <= x < item_size for x in negs[n_true:])
+
+
+# --------------------------------------------------------------------------- a14 (metrics)
+def _auc(labels, scores):
+    """sklearn.roc_auc_score restated: Mann-Whitney U with average ranks for ties."""
+    order = np.argsort(scores, kind="mergesort")
+    s = scores[order]
+    ranks = np.empty(len(s), dtype=np.float64)
+    i = 0
+    while i < len(s):
+        j = i
+        while j + 1 < len(s) and s[j + 1] == s[i]:
+            j += 1
+        ranks[i:j + 1] = 0.5 * (i + j) + 1.0
+        i = j + 1
+    r = np.empty_like(ranks)
+    r[order] = ranks
+    pos = labels == 1
+    n_pos, n_neg = pos.sum(), (~pos).sum()
+    return (r[pos].sum() - n_pos * (n_pos + 1) / 2.0) / (n_pos * n_neg)
+
+
+def _dcg(rel, scores, k):
+    """sklearn.metrics.ndcg_score(ignore_ties=False) DCG with tie averaging, truncated at k."""
+    disc = 1.0 / np.log2(np.arange(len(rel)) + 2.0)
+    disc[k:] = 0.0
+    _, inv, counts = np.unique(-scores, return_inverse=True, return_counts=True)
+    ranked = np.zeros(len(counts))
+    np.add.at(ranked, inv, rel)
+    ranked /= counts
+    groups = np.cumsum(counts) - 1
+    dsum = np.empty(len(counts))
+    cs = np.cumsum(disc)
+    dsum[0] = cs[groups[0]]
+    dsum[1:] = np.diff(cs[groups])
+    return float((ranked * dsum).sum())
+
+
+def _ndcg(labels, scores, k):
+    ideal = _dcg(labels.astype(np.float64), labels.astype(np.float64), k)
+    return _dcg(labels.astype(np.float64), scores.astype(np.float64), k) / ideal if ideal > 0 else 0.0
+
+
+def _mrr(labels, scores):
+    """The reference's non-standard MRR (utils/metrics.py:144-160): mean over ALL positives of
+    1/rank, divided by the number of positives."""
+    order = np.argsort(-scores, kind="stable")
+    y = labels[order]
+    rr = y / (np.arange(len(y)) + 1.0)
+    return float(rr.sum() / y.sum())
+
+
+def grouped_metrics(scores, labels, groups, names=("GAUC", "MRR", "NDCG@1", "NDCG@5", "NDCG@10")):
+    """MetricPool.calculate (utils/metrics.py:313-369): per-`group` metric, fp32 mean over groups."""
+    scores = np.asarray(scores, dtype=np.float64)
+    labels = np.asarray(labels)
+    groups = np.asarray(groups)
+    out = {}
+    uniq = np.unique(groups)
+    for name in names:
+        vals = []
+        for g in uniq:
+            sel = groups == g
+            l, s = labels[sel], scores[sel]
+            if name == "GAUC":
+                vals.append(_auc(l, s))
+            elif name == "MRR":
+                vals.append(_mrr(l, s))
+            elif name.startswith("NDCG@"):
+                vals.append(_ndcg(l, s, int(name.split("@")[1])))
+        out[name] = float(np.asarray(vals, dtype=np.float32).mean(dtype=np.float32))
+    return out
