@@ -1,0 +1,172 @@
+/* lego_hip.h -- C ABI of liblego_hip.so: the MI355X (gfx950) kernels for the Legommenders
+ * two-tower training hot path (NAML / NRMS `Legommender.forward` + backward + Adam).
+ *
+ * The reference (Jyonn/Legommenders) is pure Python/PyTorch and has no native layer; each
+ * entry point below names the reference call site (file:line, relative to the reference root)
+ * whose arithmetic it replaces.  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; tensors are dense,
+ *     row-major, fp32 / int32; `ld*` are row strides in elements (multiples of 4, 16-B aligned rows)
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue
+ *     work (no allocation, no synchronisation) so a caller may capture them into a hipGraph
+ *   - "dyn" arguments are device int32 scalars read by the kernels (ragged row counts produced
+ *     by lego_plan_batch), so the host never synchronises on a batch's raggedness
+ *   - return value 0 = ok; non-zero = error, message via lego_last_error() (thread-local)
+ *   - thread-safety: no global mutable state besides the thread-local error string
+ *
+ * Row spaces of one batch (built by lego_plan_batch / lego_plan_dense)
+ *   token rows  r in [0,R)      one per live title token; rows of one item instance are contiguous
+ *   Y rows      [0,R) token rows followed by [R,R+NI) one category row per item instance
+ *   rowinfo[r]  bit0 has-left-neighbour, bit1 has-right-neighbour, bit2 live, bits 8.. instance
+ *   counters[]  [0]=R  [1]=NI  [2]=R+NI  [3]=number of history instances (NI - B*C)
+ */
+#ifndef LEGO_HIP_H
+#define LEGO_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LEGO_ABI_VERSION 1
+#define LEGO_COUNTERS 8
+
+const char* lego_last_error(void);
+int lego_abi_version(void);
+
+typedef struct {
+    float p;             /* drop probability, 0 = off (eval) */
+    uint64_t seed;       /* per-run seed */
+    uint32_t site;       /* stream id: site index + 16 * step, so every step draws fresh masks */
+} lego_dropout;
+
+/* ---- a11 / a2: ragged batch plan.  Replaces Resampler.rebuild_clicks padding + the dense
+ * [B,C|S,T] stacking (loader/resampler.py:191-193,213-259) and Shaper.transform
+ * (utils/shaper.py:92-106): history pads are never materialised, pad tokens never become rows. */
+int lego_plan_batch(const int32_t* cand /*[B,C]*/, const int32_t* hist /*[B,S]*/, const int32_t* hist_len /*[B]*/,
+                    int B, int C, int S,
+                    const int32_t* title_tok /*[n_items,T], -1 pad*/, const int32_t* title_len /*[n_items]*/, int T,
+                    int32_t* counters /*[LEGO_COUNTERS]*/, int32_t* inst_item /*[B*(C+S)]*/,
+                    int32_t* seg_off /*[B*(C+S)+1]*/, int32_t* hist_off /*[B+1]*/,
+                    int32_t* rowinfo /*[B*(C+S)*T]*/, int32_t* row_tok /*[B*(C+S)*T]*/, void* stream);
+
+/* Dense plan for the operator-level API: n sequences of L positions, mask[n,L] (int32 0/1). */
+int lego_plan_dense(const int32_t* mask /*[n,L] or NULL = all live*/, int n, int L,
+                    int32_t* counters, int32_t* seg_off /*[n+1]*/, int32_t* rowinfo /*[n*L]*/, void* stream);
+
+/* ---- a4: embedding row gather.  nn.Embedding look-up of EmbeddingHub / Transformation
+ * (loader/embedding_hub.py:95-96,378-385); idx < 0 (pad) yields a zero row.  HBM-bound. */
+int lego_gather_rows(const float* table, int ld_table, int width, const int32_t* idx, int rows_cap,
+                     const int32_t* rows_dyn /*nullable*/, float* out, int ld_out,
+                     int accumulate /*1: out[r] += row where idx >= 0 (ConcatInputer's summed look-ups)*/, void* stream);
+/* backward of a TRAINABLE table (embed/null.yaml): grad_table[idx[r]] += g[r] (dense grad semantics) */
+int lego_scatter_add_rows(float* grad_table, int ld_table, int width, const int32_t* idx, int rows_cap,
+                          const int32_t* rows_dyn, const float* g, int ld_g, void* stream);
+
+/* ---- a4/a5/a6/a8: Linear layers.  out[M,N] = act(x[M,K] . W[N,K]^T + bias) * live * dropout.
+ * act: 0 none (nn.Linear: embedding_hub.py:95, cnn_operator.py:59, attention_operator.py:56),
+ *      2 tanh (AdditiveAttention.encoder[0..1], model/common/attention.py:17-21).
+ * x_row_off_dyn / out_row_off_dyn: optional device row offsets (category rows live at Y rows R..). */
+int lego_linear_fwd(const float* x, int ldx, const float* W, int ldw, const float* bias,
+                    float* out, int ldo, int M_cap, const int32_t* M_dyn, int N, int K, int act,
+                    const int32_t* rowinfo /*nullable: zero rows whose live bit is 0*/,
+                    const lego_dropout* drop /*nullable*/,
+                    const int32_t* x_row_off_dyn, const int32_t* out_row_off_dyn, void* stream);
+/* dx[M,K] (+)= g[M,N] . W[N,K];  optional fused ReLU-backward (dx = ref>0 ? dx*scale : 0),
+ * dropout/live re-masking and column sums of the result (bias gradient of the producer layer). */
+int lego_linear_bwd_data(const float* g, int ldg, const float* W, int ldw, float* dx, int lddx,
+                         int M_cap, const int32_t* M_dyn, int N, int K, int accumulate,
+                         const float* relu_ref, int ld_ref, float relu_scale,
+                         const int32_t* rowinfo, const lego_dropout* drop, float* colsum /*[K] nullable, += */,
+                         const int32_t* g_row_off_dyn, const int32_t* dx_row_off_dyn, void* stream);
+/* dW[N,K] += g[M,N]^T . x[M,K]   (split-K over the ragged row count, fp32 atomics) */
+int lego_linear_bwd_weight(const float* g, int ldg, const float* x, int ldx, float* dW, int lddw,
+                           int M_cap, const int32_t* M_dyn, int N, int K,
+                           const int32_t* g_row_off_dyn, const int32_t* x_row_off_dyn, void* stream);
+/* out[c] += sum_r x[r,c] over rows [off, off+M)  (bias gradients not fused elsewhere) */
+int lego_colsum(const float* x, int ldx, int M_cap, const int32_t* M_dyn, const int32_t* row_off_dyn,
+                int N, float* out, void* stream);
+
+/* ---- a5: CNNOperator title branch (model/operators/cnn_operator.py:54-57): Conv1d(k=3,'same')
+ * -> ReLU -> *mask -> Dropout as an implicit GEMM over token rows (taps = rows r-1,r,r+1 of the
+ * same item, from rowinfo).  Wt is the tap-major copy [3][Dout][Din] made by lego_conv3_pack. */
+int lego_conv3_pack(const float* w /*[Dout,Din,3]*/, float* wt /*[3,Dout,Din]*/, int Dout, int Din, void* stream);
+int lego_conv3_unpack_add(const float* dwt /*[3,Dout,Din]*/, float* dw /*[Dout,Din,3], +=*/, int Dout, int Din, void* stream);
+int lego_conv3_fwd(const float* h, int ldh, const float* wt, const float* bias, const int32_t* rowinfo,
+                   float* y, int ldy, int R_cap, const int32_t* R_dyn, int Dout, int Din,
+                   const lego_dropout* drop, void* stream);
+/* dh = live*dropout_in * sum_tap gy[r-(tap-1)] . Wt[tap];  colsum(dh) -> bias grad of the input projection */
+int lego_conv3_bwd_data(const float* gy, int ldg, const float* wt, const int32_t* rowinfo,
+                        float* dh, int lddh, int R_cap, const int32_t* R_dyn, int Dout, int Din,
+                        const lego_dropout* drop_in, float* colsum, void* stream);
+/* dwt[tap] += gy^T . h[r+tap-1] */
+int lego_conv3_bwd_weight(const float* gy, int ldg, const float* h, int ldh, const int32_t* rowinfo,
+                          float* dwt, int R_cap, const int32_t* R_dyn, int Dout, int Din, void* stream);
+
+/* ---- a6/a7: AdditiveAttention pooling (model/common/attention.py:31-38) over ragged segments.
+ * t = tanh(W1 x + b1) rows come from lego_linear_fwd(act=2).  Per segment i (rows seg_off[i]..
+ * seg_off[i+1]) plus optionally one extra row (extra_off_dyn + i: the category row):
+ *   a = t.w2; e = exp(a)*live (no max-subtraction); w = e/(sum e + 2^-23); out = sum w x. */
+int lego_additive_pool_fwd(const float* t, int ldt, const float* x, int ldx, const float* w2,
+                           const int32_t* seg_off, const int32_t* rowinfo /*nullable*/,
+                           const int32_t* extra_off_dyn /*nullable*/, int n_cap, const int32_t* n_dyn,
+                           int D, int A, float* out, int ldo, float* wrow /*[rows] saved weights*/, void* stream);
+/* given gout[n,D]: dx rows = w*gout (written, not accumulated); t is overwritten in place with
+ * dpre = da*w2*(1-t^2); gw2[A] += sum da*t ; gb1[A] += sum dpre. */
+int lego_additive_pool_bwd(float* t_dpre, int ldt, const float* x, int ldx, const float* w2,
+                           const int32_t* seg_off, const int32_t* extra_off_dyn, int n_cap, const int32_t* n_dyn,
+                           int D, int A, const float* gout, int ldgo, const float* wrow,
+                           float* dx, int lddx, float* gw2, float* gb1, void* stream);
+
+/* ---- a9/a10: DotPredictor + CrossEntropy(label 0) (model/predictors/dot_predictor.py:7-10,
+ * model/operators/base_operator.py:65-69, model/legommender.py:254,263,268-283). */
+int lego_dot_ce_fwd(const float* user /*[B,D]*/, int ldu, const float* items /*[B*C,D]*/, int ldi,
+                    int B, int C, int D, float* scores /*[B,C]*/, float* loss /*[1], +=mean*/, void* stream);
+int lego_dot_ce_bwd(const float* user, int ldu, const float* items, int ldi, const float* scores,
+                    int B, int C, int D, float gscale /*dloss * 1/B*/, float* guser, int ldgu,
+                    float* gitems, int ldgi, void* stream);
+
+/* ---- a8: nn.MultiheadAttention core of AttentionOperator (model/operators/attention_operator.py:49-55)
+ * over ragged segments: per (segment, head) softmax(q k^T / sqrt(hd)) v with all keys of the segment
+ * live (pads are not rows).  qkv rows are [q | k | v] (3*D) from lego_linear_fwd with in_proj. */
+int lego_mhsa_core_fwd(const float* qkv, int ldq, const int32_t* seg_off, int n_cap, const int32_t* n_dyn,
+                       int D, int heads, float* out, int ldo, float* probs /*[rows,heads,Lmax] saved*/,
+                       int Lmax, const lego_dropout* drop, int rows_cap, void* stream);
+int lego_mhsa_core_bwd(const float* qkv, int ldq, const int32_t* seg_off, int n_cap, const int32_t* n_dyn,
+                       int D, int heads, const float* gout, int ldgo, const float* probs, int Lmax,
+                       const lego_dropout* drop, int rows_cap, float* gqkv, int ldgq, void* stream);
+
+/* ---- a13: torch.optim.Adam (defaults, base_lego.py:201-204) over one flat fp32 buffer;
+ * grad is multiplied by grad_scale first (1/world after the RCCL all-reduce). step is 1-based. */
+int lego_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                   float eps, int step, float grad_scale, void* stream);
+
+/* ---- a11: negative sampling of Resampler.rebuild_candidates (loader/resampler.py:159-171) on
+ * device: cand[b,0] = positive; min(K,len) distinct draws from the user's true-negative list,
+ * the rest uniform item ids in [0,n_items). */
+int lego_sample_negatives(const int32_t* row_user /*[B]*/, const int32_t* row_item /*[B]*/,
+                          const int32_t* neg_list /*[n_users,neg_cap]*/, const int32_t* neg_len, int neg_cap,
+                          int B, int K, int n_items, uint64_t seed, uint32_t step, int32_t* cand /*[B,K+1]*/,
+                          void* stream);
+/* hist[b,:] / hist_len[b] = user tables rows of row_user[b]  (the DataSet row copy, data_set.py:61-85) */
+int lego_gather_history(const int32_t* row_user, const int32_t* user_hist /*[n_users,S]*/,
+                        const int32_t* user_hist_len, int B, int S, int32_t* hist, int32_t* hist_len, void* stream);
+
+/* ---- a3': ConcatInputer layout of NRMS (model/inputer/concat_inputer.py:58-114).  The item sequence
+ * [title..., SEP, category, SEP] is planned with lego_plan_batch over an encoded per-item sequence table
+ * (token id >= 0, SEP = -2, category = -(3+cat)); this splits the plan's row words into the three
+ * look-up index columns (-1 = column absent at that position) and a live-bit word for token rows. */
+int lego_nrms_decode_rows(const int32_t* row_tok, int R_cap, const int32_t* R_dyn, int32_t* idx_tok,
+                          int32_t* idx_special, int32_t* idx_cat, int32_t* tokinfo, void* stream);
+/* x[r,:] *= live(rowinfo[r]) * dropout-scale: backward of `Transformation`'s Dropout + the inputer mask
+ * (loader/embedding_hub.py:96, concat_inputer.py:111) when the producer is not a fused GEMM epilogue */
+int lego_mask_dropout_rows(float* x, int ld, int R_cap, const int32_t* R_dyn, int width, const int32_t* rowinfo,
+                           const lego_dropout* drop, void* stream);
+
+/* small utilities used by the host side */
+int lego_gather_i32(const int32_t* table, const int32_t* idx, int n_cap, const int32_t* n_dyn, int32_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,114 @@
+"""ctypes binding of liblego_hip.so (the C ABI declared in include/lego_hip.h).
+
+The product path has NO CPU fallback: if the shared object is missing or does not export a
+declared symbol, importing / calling raises.  `build()` compiles it in-tree with hipcc for gfx950.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "liblego_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "lego_hip.h")
+
+P = ctypes.c_void_p
+I = ctypes.c_int
+F = ctypes.c_float
+I64 = ctypes.c_int64
+U64 = ctypes.c_uint64
+U32 = ctypes.c_uint32
+
+
+class LegoDropout(ctypes.Structure):
+    _fields_ = [("p", ctypes.c_float), ("seed", ctypes.c_uint64), ("site", ctypes.c_uint32)]
+
+
+# name -> argtypes (all return int; 0 = ok).  Mirrors include/lego_hip.h one to one.
+SIGNATURES = {
+    "lego_plan_batch": [P, P, P, I, I, I, P, P, I, P, P, P, P, P, P, P],
+    "lego_plan_dense": [P, I, I, P, P, P, P],
+    "lego_gather_rows": [P, I, I, P, I, P, P, I, I, P],
+    "lego_nrms_decode_rows": [P, I, P, P, P, P, P, P],
+    "lego_mask_dropout_rows": [P, I, I, P, I, P, P, P],
+    "lego_scatter_add_rows": [P, I, I, P, I, P, P, I, P],
+    "lego_linear_fwd": [P, I, P, I, P, P, I, I, P, I, I, I, P, P, P, P, P],
+    "lego_linear_bwd_data": [P, I, P, I, P, I, I, P, I, I, I, P, I, F, P, P, P, P, P, P],
+    "lego_linear_bwd_weight": [P, I, P, I, P, I, I, P, I, I, P, P, P],
+    "lego_colsum": [P, I, I, P, P, I, P, P],
+    "lego_conv3_pack": [P, P, I, I, P],
+    "lego_conv3_unpack_add": [P, P, I, I, P],
+    "lego_conv3_fwd": [P, I, P, P, P, P, I, I, P, I, I, P, P],
+    "lego_conv3_bwd_data": [P, I, P, P, P, I, I, P, I, I, P, P, P],
+    "lego_conv3_bwd_weight": [P, I, P, I, P, P, I, P, I, I, P],
+    "lego_additive_pool_fwd": [P, I, P, I, P, P, P, P, I, P, I, I, P, I, P, P],
+    "lego_additive_pool_bwd": [P, I, P, I, P, P, P, I, P, I, I, P, I, P, P, I, P, P, P],
+    "lego_dot_ce_fwd": [P, I, P, I, I, I, I, P, P, P],
+    "lego_dot_ce_bwd": [P, I, P, I, P, I, I, I, F, P, I, P, I, P],
+    "lego_mhsa_core_fwd": [P, I, P, I, P, I, I, P, I, P, I, P, I, P],
+    "lego_mhsa_core_bwd": [P, I, P, I, P, I, I, P, I, P, I, P, I, P, I, P],
+    "lego_adam_step": [P, P, P, P, I64, F, F, F, F, I, F, P],
+    "lego_sample_negatives": [P, P, P, P, I, I, I, I, U64, U32, P, P],
+    "lego_gather_history": [P, P, P, I, I, P, P, P],
+    "lego_gather_i32": [P, P, I, P, P, P],
+}
+
+
+class LegoHipError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into legommenders_amd/csrc/liblego_hip.so (in-tree)."""
+    cmd = ["make", "-C", CSRC, "-j4"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout[-4000:])
+        print(res.stderr[-4000:])
+    if res.returncode != 0:
+        raise LegoHipError("building liblego_hip.so failed (hipcc --offload-arch=gfx950)")
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """The loaded library; raises (never falls back) if it is absent or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LegoHipError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C legommenders_amd/csrc`.")
+    handle = ctypes.CDLL(LIB_PATH)
+    handle.lego_last_error.restype = ctypes.c_char_p
+    handle.lego_last_error.argtypes = []
+    handle.lego_abi_version.restype = ctypes.c_int
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as exc:
+            raise LegoHipError(f"liblego_hip.so does not export {name}") from exc
+        fn.restype = ctypes.c_int
+        fn.argtypes = argtypes
+    _lib = handle
+    return handle
+
+
+def call(name: str, *args) -> None:
+    handle = lib()
+    rc = getattr(handle, name)(*args)
+    if rc != 0:
+        raise LegoHipError(f"{name}: {handle.lego_last_error().decode(errors='replace')}")
+
+
+def declared_symbols():
+    """Function names declared in include/lego_hip.h (used by the CPU-side ABI test)."""
+    import re
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lego_[a-z0-9_]+)\s*\(", text)))

@@ -1,0 +1,70 @@
+// Shared device helpers for the lego_hip kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lego {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// rowinfo word of the token-row space (built by the plan kernels, plan.hip)
+//   bit0 = row has a left neighbour inside its item, bit1 = right neighbour,
+//   bit2 = row is live (mask == 1), bits 8.. = item-instance index
+constexpr int RI_LEFT = 1, RI_RIGHT = 2, RI_LIVE = 4, RI_INST_SHIFT = 8;
+
+// ---------------------------------------------------------------- Philox4x32-10
+// Counter-based RNG for the three dropout sites; the mask is never stored, forward and
+// backward regenerate it from (seed, site, element counter).
+struct Philox4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                  uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return {c0, c1, c2, c3};
+}
+
+struct Dropout {
+    float p;            // drop probability; 0 disables
+    uint32_t seed_lo, seed_hi;
+    uint32_t site;      // dropout site id (distinct streams per site / step)
+};
+
+// keep-scales for the 4 elements (rows r0..r0+3, r0 % 4 == 0, column c) of a [*, ncols] matrix
+__device__ __forceinline__ void dropout_scale4(const Dropout& d, int r0, int c, int ncols, float (&s)[4]) {
+    if (d.p <= 0.f) { s[0] = s[1] = s[2] = s[3] = 1.f; return; }
+    const uint64_t ctr = (uint64_t)(r0 >> 2) * (uint64_t)ncols + (uint64_t)c;
+    const Philox4 r = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), d.site, 0u, d.seed_lo, d.seed_hi);
+    const uint32_t thr = (uint32_t)(d.p * 4294967296.0f);
+    const float inv = 1.f / (1.f - d.p);
+    s[0] = r.x >= thr ? inv : 0.f; s[1] = r.y >= thr ? inv : 0.f;
+    s[2] = r.z >= thr ? inv : 0.f; s[3] = r.w >= thr ? inv : 0.f;
+}
+
+__device__ __forceinline__ float dropout_scale1(const Dropout& d, int r, int c, int ncols) {
+    float s[4];
+    dropout_scale4(d, r & ~3, c, ncols, s);
+    return s[r & 3];
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace lego
+
+// ---------------------------------------------------------------- host-side error plumbing
+extern "C" const char* lego_last_error(void);
+namespace lego {
+int set_error(const char* fmt, ...);
+int check_launch(const char* what);
+}
+#define LEGO_REQUIRE(cond, ...) do { if (!(cond)) return ::lego::set_error(__VA_ARGS__); } while (0)

@@ -1,0 +1,296 @@
+// fp32 MFMA GEMM core for gfx950 (v_mfma_f32_32x32x2_f32: exact f32, k-ordered fma chain).
+//
+// One LDS-tiled main loop, specialised by operand loaders and an epilogue functor:
+//   * operands are either K-contiguous in memory ("KC": rows of the tile are matrix rows,
+//     LDS image [row][BK+4], fragments read with ds_read_b128) or M-contiguous ("MC": the
+//     reduction index is the memory row, LDS image [BK][rows], fragments read with ds_read_b32);
+//     NT = KC x KC, NN = KC x MC, TN = MC x MC -- no operand is ever transposed in memory.
+//   * loaders express the ragged gathers of the path: plain rows, rows through an index,
+//     conv taps (row r +/- 1 inside one item, predicate from the plan's rowinfo word).
+//   * 256 threads = 4 waves as WM x WN, each wave TM x TN MFMA 32x32 sub-tiles, BK = 32,
+//     register-staged double buffering: global loads for tile t+1 are issued before the
+//     MFMAs of tile t and written to the other LDS buffer after them (one barrier per tile).
+//   * the k order inside a BK step is permuted (lane half h takes k = 8q+4h+j for MFMA j)
+//     identically for A and B, so one ds_read_b128 feeds four MFMAs.
+#pragma once
+#include "common.hpp"
+
+namespace lego {
+
+constexpr int BK = 32;
+constexpr int KC_LD = BK + 4;   // +16 B pad: the 16 lanes of a ds_read_b128 group hit 16 distinct slots
+
+// ------------------------------------------------------------------ operand loaders
+// Every loader has: ext (rows of a KC operand / columns of an MC operand), K (reduction bound, set by
+// the kernel to the end of its k range) and prepare(tap), called once in the kernel prologue.
+// KC loaders: tile row -> matrix row, k contiguous.  row(r) is evaluated once per thread.
+struct KcRows {            // plain rows, optionally behind a device row offset
+    const float* p; int ld; int ext; int K; const int* row_off_dyn;
+    struct Row { const float* base; };
+    __device__ __forceinline__ void prepare(int) { if (row_off_dyn != nullptr) p += (size_t)(*row_off_dyn) * ld; }
+    __device__ __forceinline__ Row row(int r) const { return {r < ext ? p + (size_t)r * ld : nullptr}; }
+    __device__ __forceinline__ f32x4 get(const Row& R, int k) const {
+        if (R.base != nullptr && k < K) return *reinterpret_cast<const f32x4*>(R.base + k);
+        return f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+};
+
+struct KcConvA {           // logical K = 3*C: k -> (tap = k / C, c = k % C); source row r + dir*(tap-1)
+    const float* p; int ld; int ext; int K; const int* rowinfo; int C; int dir;
+    struct Row { const float* base; int flags; };
+    __device__ __forceinline__ void prepare(int) {}
+    __device__ __forceinline__ Row row(int r) const {
+        if (r >= ext) return {nullptr, 0};
+        return {p + (size_t)r * ld, rowinfo[r]};
+    }
+    __device__ __forceinline__ f32x4 get(const Row& R, int k) const {
+        if (R.base == nullptr || k >= K) return f32x4{0.f, 0.f, 0.f, 0.f};
+        const int tap = k / C;
+        const int c = k - tap * C;
+        const int s = dir * (tap - 1);
+        const bool ok = (s == 0) || (s < 0 ? (R.flags & RI_LEFT) != 0 : (R.flags & RI_RIGHT) != 0);
+        if (!ok) return f32x4{0.f, 0.f, 0.f, 0.f};
+        return *reinterpret_cast<const f32x4*>(R.base + (ptrdiff_t)s * ld + c);
+    }
+};
+
+struct KcTapW {            // B of the conv forward: B[o][tap*C + c] = wt[tap][o][c]  (tap-major packed weights)
+    const float* p; int ld /*= C*/; int ext /*= Dout*/; int K; int C; size_t tap_stride /*= Dout*C*/;
+    struct Row { const float* base; };
+    __device__ __forceinline__ void prepare(int) {}
+    __device__ __forceinline__ Row row(int r) const { return {r < ext ? p + (size_t)r * ld : nullptr}; }
+    __device__ __forceinline__ f32x4 get(const Row& R, int k) const {
+        if (R.base == nullptr || k >= K) return f32x4{0.f, 0.f, 0.f, 0.f};
+        const int tap = k / C;
+        return *reinterpret_cast<const f32x4*>(R.base + (size_t)tap * tap_stride + (k - tap * C));
+    }
+};
+
+// MC loaders: the reduction index is the memory row, tile columns are contiguous.
+struct McRows {
+    const float* p; int ld; int ext; int K; const int* row_off_dyn;
+    struct Row {};
+    __device__ __forceinline__ void prepare(int) { if (row_off_dyn != nullptr) p += (size_t)(*row_off_dyn) * ld; }
+    __device__ __forceinline__ f32x4 get(int kk, int c) const {
+        if (kk < K && c < ext) return *reinterpret_cast<const f32x4*>(p + (size_t)kk * ld + c);
+        return f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+};
+
+struct McShiftRows {       // row kk + (tap-1) of p, valid when the plan says row kk has that neighbour
+    const float* p; int ld; int ext; int K; const int* rowinfo; int s;
+    struct Row {};
+    __device__ __forceinline__ void prepare(int tap) { s = tap - 1; }
+    __device__ __forceinline__ f32x4 get(int kk, int c) const {
+        if (kk < K && c < ext) {
+            const int f = rowinfo[kk];
+            const bool ok = (s == 0) || (s < 0 ? (f & RI_LEFT) != 0 : (f & RI_RIGHT) != 0);
+            if (ok) return *reinterpret_cast<const f32x4*>(p + (ptrdiff_t)(kk + s) * ld + c);
+        }
+        return f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+};
+
+// ------------------------------------------------------------------ the kernel
+template <int BM, int BN, int WM, int WN>
+struct TileCfg {
+    static constexpr int kBM = BM, kBN = BN, kWM = WM, kWN = WN;
+    static constexpr int kTM = BM / (WM * 32), kTN = BN / (WN * 32);
+    static_assert(WM * WN == 4, "256-thread workgroups");
+    static_assert(kTM >= 1 && kTN >= 1, "wave tile");
+};
+
+template <bool MC, int ROWS>
+struct Stage {             // global -> registers -> LDS staging of one operand tile
+    static constexpr int kN = ROWS / 32;              // float4 per thread
+    static constexpr int kLdsFloats = MC ? BK * ROWS : ROWS * KC_LD;
+};
+
+struct GemmDims {
+    int M, N, K;            // static bounds
+    const int* m_dyn;       // optional device scalar overriding M (NT/NN) ...
+    const int* k_dyn;       // ... or K (TN: reduction over the dynamic row count)
+    int split_k;            // TN only: gridDim.z / taps
+};
+
+template <class Cfg, bool A_MC, bool B_MC, class ALoad, class BLoad, class Epi>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmDims dims, ALoad la, BLoad lb, Epi epi) {
+    constexpr int BM = Cfg::kBM, BN = Cfg::kBN, TM = Cfg::kTM, TN = Cfg::kTN;
+    using SA = Stage<A_MC, BM>;
+    using SB = Stage<B_MC, BN>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const As0 = smem;
+    float* const Bs0 = smem + 2 * SA::kLdsFloats;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / Cfg::kWN, wn = wave % Cfg::kWN;
+
+    int M = dims.M, K = dims.K;
+    if (dims.m_dyn != nullptr) M = min(M, *dims.m_dyn);
+    if (dims.k_dyn != nullptr) K = min(K, *dims.k_dyn);
+    const int N = dims.N;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    if (m0 >= M || n0 >= N) return;
+
+    // reduction range of this block (split-K along gridDim.z for the TN weight-gradient GEMMs)
+    int kbeg = 0, kend = K;
+    if (dims.split_k > 1) {
+        const int z = blockIdx.z % dims.split_k;
+        int chunk = (K + dims.split_k - 1) / dims.split_k;
+        chunk = (chunk + BK - 1) / BK * BK;
+        kbeg = z * chunk;
+        kend = min(K, kbeg + chunk);
+        if (kbeg >= kend) return;
+    }
+    const int tap = blockIdx.z / max(dims.split_k, 1);
+    epi.setup(M, N, tap);
+    if constexpr (!A_MC) la.ext = M;
+    la.K = kend;
+    lb.K = kend;
+    la.prepare(tap);
+    lb.prepare(tap);
+
+    // per-thread row state for KC operands (constant over the k loop)
+    typename ALoad::Row ra[SA::kN];
+    typename BLoad::Row rb[SB::kN];
+    if constexpr (!A_MC) {
+#pragma unroll
+        for (int j = 0; j < SA::kN; ++j) ra[j] = la.row(m0 + (tid >> 3) + 32 * j);
+    }
+    if constexpr (!B_MC) {
+#pragma unroll
+        for (int j = 0; j < SB::kN; ++j) rb[j] = lb.row(n0 + (tid >> 3) + 32 * j);
+    }
+
+    f32x4 sa[SA::kN], sb[SB::kN];
+    auto fetch = [&](int k0) {
+        if constexpr (A_MC) {
+            constexpr int PER = BM / 4, STEP = 256 / PER;
+#pragma unroll
+            for (int j = 0; j < SA::kN; ++j) sa[j] = la.get(k0 + tid / PER + STEP * j, m0 + (tid % PER) * 4);
+        } else {
+#pragma unroll
+            for (int j = 0; j < SA::kN; ++j) sa[j] = la.get(ra[j], k0 + (tid & 7) * 4);
+        }
+        if constexpr (B_MC) {
+            constexpr int PER = BN / 4, STEP = 256 / PER;
+#pragma unroll
+            for (int j = 0; j < SB::kN; ++j) sb[j] = lb.get(k0 + tid / PER + STEP * j, n0 + (tid % PER) * 4);
+        } else {
+#pragma unroll
+            for (int j = 0; j < SB::kN; ++j) sb[j] = lb.get(rb[j], k0 + (tid & 7) * 4);
+        }
+    };
+    auto commit = [&](float* A_, float* B_) {
+        if constexpr (A_MC) {
+            constexpr int PER = BM / 4, STEP = 256 / PER;
+#pragma unroll
+            for (int j = 0; j < SA::kN; ++j)
+                *reinterpret_cast<f32x4*>(A_ + (tid / PER + STEP * j) * BM + (tid % PER) * 4) = sa[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < SA::kN; ++j)
+                *reinterpret_cast<f32x4*>(A_ + ((tid >> 3) + 32 * j) * KC_LD + (tid & 7) * 4) = sa[j];
+        }
+        if constexpr (B_MC) {
+            constexpr int PER = BN / 4, STEP = 256 / PER;
+#pragma unroll
+            for (int j = 0; j < SB::kN; ++j)
+                *reinterpret_cast<f32x4*>(B_ + (tid / PER + STEP * j) * BN + (tid % PER) * 4) = sb[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < SB::kN; ++j)
+                *reinterpret_cast<f32x4*>(B_ + ((tid >> 3) + 32 * j) * KC_LD + (tid & 7) * 4) = sb[j];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+
+    fetch(kbeg);
+    commit(As0, Bs0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        const bool more = k0 + BK < kend;
+        if (more) fetch(k0 + BK);
+        const float* A_ = As0 + buf * SA::kLdsFloats;
+        const float* B_ = Bs0 + buf * SB::kLdsFloats;
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int row = (wm * TM + a) * 32 + li;
+                if constexpr (A_MC) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fa[a][j] = A_[(8 * q + 4 * lh + j) * BM + row];
+                } else {
+                    fa[a] = *reinterpret_cast<const f32x4*>(A_ + row * KC_LD + 8 * q + 4 * lh);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int col = (wn * TN + b) * 32 + li;
+                if constexpr (B_MC) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fb[b][j] = B_[(8 * q + 4 * lh + j) * BN + col];
+                } else {
+                    fb[b] = *reinterpret_cast<const f32x4*>(B_ + col * KC_LD + 8 * q + 4 * lh);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
+        }
+        if (more) commit(As0 + (buf ^ 1) * SA::kLdsFloats, Bs0 + (buf ^ 1) * SB::kLdsFloats);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // epilogue: lane holds column (li) x rows {(v&3) + 8*(v>>2) + 4*lh} of each 32x32 sub-tile
+    float csum[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) csum[b] = 0.f;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int c = n0 + (wn * TN + b) * 32 + li;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r0 = m0 + (wm * TM + a) * 32 + 8 * g + 4 * lh;
+                float v[4] = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+                if (c < N && r0 < M) {
+                    epi.apply4(r0, c, v);
+                    csum[b] += (v[0] + v[1]) + (v[2] + v[3]);
+                }
+            }
+        }
+    if (epi.colsum != nullptr) {
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int c = n0 + (wn * TN + b) * 32 + li;
+            const float s = csum[b] + __shfl_xor(csum[b], 32, 64);
+            if (lh == 0 && c < N) atomicAdd(epi.colsum + c, s);
+        }
+    }
+}
+
+template <class Cfg, bool A_MC, bool B_MC>
+constexpr size_t gemm_lds_bytes() {
+    return 2 * (Stage<A_MC, Cfg::kBM>::kLdsFloats + Stage<B_MC, Cfg::kBN>::kLdsFloats) * sizeof(float);
+}
+
+}  // namespace lego

@@ -1,0 +1,651 @@
+// HBM-bound kernels of the path: ragged batch plan, embedding row gather / scatter-add,
+// additive-attention pooling (wave-shuffle reductions, one wave per segment), dot + cross-entropy,
+// Adam, device-side negative sampling.  Everything here is integer/byte or streaming fp32 work:
+// coalesced 16-B accesses, no MFMA.
+#include "../../include/lego_hip.h"
+#include "common.hpp"
+
+namespace lego {
+
+constexpr float kEps = 1.1920928955078125e-07f;   // torch.finfo(float32).eps (model/common/attention.py:36)
+
+// ------------------------------------------------------------------ block scan (1024 threads)
+__device__ __forceinline__ int block_incl_scan_1024(int v, int* wsum) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    if (lane == 63) wsum[w] = v;
+    __syncthreads();
+    if (w == 0) {
+        int s = lane < 16 ? wsum[lane] : 0;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const int t = __shfl_up(s, o, 64);
+            if (lane >= o) s += t;
+        }
+        if (lane < 16) wsum[lane] = s;
+    }
+    __syncthreads();
+    if (w > 0) v += wsum[w - 1];
+    __syncthreads();
+    return v;
+}
+
+// One workgroup: scan the history lengths, enumerate the live item instances
+// (B*C candidates, then each user's hist_len clicked items), scan their title lengths.
+__global__ __launch_bounds__(1024) void plan_scan_kernel(
+    const int* __restrict__ cand, const int* __restrict__ hist, const int* __restrict__ hist_len,
+    int B, int C, int S, const int* __restrict__ title_len,
+    int* counters, int* inst_item, int* seg_off, int* hist_off) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < B; base += 1024) {
+        const int b = base + tid;
+        int len = 0;
+        if (b < B) len = min(max(hist_len[b], 0), S);
+        const int inc = block_incl_scan_1024(len, wsum);
+        const int carry = carry_s;
+        if (b < B) hist_off[b] = carry + inc - len;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + inc;
+        __syncthreads();
+    }
+    const int n_hist = carry_s;
+    if (tid == 0) hist_off[B] = n_hist;
+    __syncthreads();
+    const int BC = B * C;
+    const int NI = BC + n_hist;
+    const int NI_cap = B * (C + S);
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < NI_cap; base += 1024) {
+        const int i = base + tid;
+        int len = 0;
+        if (i < NI) {
+            int item;
+            if (i < BC) {
+                item = cand[i];
+            } else {
+                const int j = i - BC;
+                int lo = 0, hi = B - 1;          // largest b with hist_off[b] <= j
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (hist_off[mid] <= j) lo = mid; else hi = mid - 1;
+                }
+                item = hist[lo * S + (j - hist_off[lo])];
+            }
+            inst_item[i] = item;
+            len = title_len[item];
+        }
+        const int inc = block_incl_scan_1024(len, wsum);
+        const int carry = carry_s;
+        if (i < NI_cap) seg_off[i] = carry + inc - len;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + inc;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int R = carry_s;
+        seg_off[NI_cap] = R;
+        counters[0] = R; counters[1] = NI; counters[2] = R + NI; counters[3] = n_hist;
+        counters[4] = BC; counters[5] = 0; counters[6] = 0; counters[7] = 0;
+    }
+}
+
+__global__ void plan_rows_kernel(const int* __restrict__ counters, const int* __restrict__ inst_item,
+                                 const int* __restrict__ seg_off, const int* __restrict__ title_tok,
+                                 const int* __restrict__ title_len, int T, int NI_cap,
+                                 int* rowinfo, int* row_tok) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = gid >> 5, p0 = gid & 31;
+    if (i >= NI_cap || i >= counters[1]) return;
+    const int item = inst_item[i];
+    const int len = title_len[item];
+    const int r0 = seg_off[i];
+    for (int pos = p0; pos < len; pos += 32) {
+        rowinfo[r0 + pos] = (pos > 0 ? RI_LEFT : 0) | (pos < len - 1 ? RI_RIGHT : 0) | RI_LIVE | (i << RI_INST_SHIFT);
+        row_tok[r0 + pos] = title_tok[(size_t)item * T + pos];
+    }
+}
+
+__global__ void plan_dense_kernel(const int* __restrict__ mask, int n, int L, int* counters, int* seg_off, int* rowinfo) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r == 0) {
+        counters[0] = n * L; counters[1] = n; counters[2] = n * L + n; counters[3] = 0;
+        counters[4] = 0; counters[5] = 0; counters[6] = 0; counters[7] = 0;
+    }
+    if (r <= n) seg_off[r] = r * L;
+    if (r >= n * L) return;
+    const int i = r / L, pos = r - i * L;
+    const int live = mask == nullptr ? 1 : (mask[r] != 0);
+    rowinfo[r] = (pos > 0 ? RI_LEFT : 0) | (pos < L - 1 ? RI_RIGHT : 0) | (live ? RI_LIVE : 0) | (i << RI_INST_SHIFT);
+}
+
+// ------------------------------------------------------------------ gather / scatter
+// out[r, :] = table[idx[r], :]; the rows are swept as one flat float4 stream so both the
+// 1200-B (E0 = 300) source rows and the destination are read/written in whole 16-B pieces.
+__global__ void gather_rows_kernel(const float* __restrict__ table, int ld_table, int w4,
+                                   const int* __restrict__ idx, int rows_cap, const int* __restrict__ rows_dyn,
+                                   float* __restrict__ out, int ld_out, int accumulate) {
+    const int rows = rows_dyn != nullptr ? min(rows_cap, *rows_dyn) : rows_cap;
+    const long long total = (long long)rows * w4;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(e / w4);
+        const int c = (int)(e - (long long)r * w4) * 4;
+        const int i = idx[r];
+        f32x4* dst = reinterpret_cast<f32x4*>(out + (size_t)r * ld_out + c);
+        if (accumulate) {
+            if (i >= 0) *dst += *reinterpret_cast<const f32x4*>(table + (size_t)i * ld_table + c);
+        } else {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i >= 0) v = *reinterpret_cast<const f32x4*>(table + (size_t)i * ld_table + c);
+            *dst = v;
+        }
+    }
+}
+
+// NRMS sequence rows: the plan's row_tok word encodes token id (>= 0), SEP (-2) or category (-(3+cat))
+__global__ void nrms_decode_rows_kernel(const int* __restrict__ row_tok, int R_cap, const int* __restrict__ R_dyn,
+                                        int* idx_tok, int* idx_special, int* idx_cat, int* tokinfo) {
+    const int R = R_dyn != nullptr ? min(R_cap, *R_dyn) : R_cap;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int v = row_tok[r];
+    idx_tok[r] = v >= 0 ? v : -1;
+    idx_special[r] = v == -2 ? 2 : -1;                 // [SEP] = 2 (concat_inputer.py:27-30)
+    idx_cat[r] = v <= -3 ? -(v + 3) : -1;
+    tokinfo[r] = v >= 0 ? RI_LIVE : 0;
+}
+
+// x[r,:] *= live(rowinfo[r]) * dropout scale  (backward of a masked + dropped projection output)
+__global__ void mask_dropout_rows_kernel(float* __restrict__ x, int ld, int R_cap, const int* __restrict__ R_dyn, int width,
+                                         const int* __restrict__ rowinfo, Dropout drop) {
+    const int R = R_dyn != nullptr ? min(R_cap, *R_dyn) : R_cap;
+    const long long total = (long long)R * width;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(e / width);
+        const int c = (int)(e - (long long)r * width);
+        float v = x[(size_t)r * ld + c];
+        if (rowinfo != nullptr && !(rowinfo[r] & RI_LIVE)) v = 0.f;
+        else v *= dropout_scale1(drop, r, c, width);
+        x[(size_t)r * ld + c] = v;
+    }
+}
+
+__global__ void scatter_add_rows_kernel(float* grad_table, int ld_table, int width, const int* __restrict__ idx,
+                                        int rows_cap, const int* __restrict__ rows_dyn, const float* __restrict__ g, int ld_g) {
+    const int rows = rows_dyn != nullptr ? min(rows_cap, *rows_dyn) : rows_cap;
+    const long long total = (long long)rows * width;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(e / width);
+        const int c = (int)(e - (long long)r * width);
+        const int i = idx[r];
+        if (i >= 0) atomicAdd(grad_table + (size_t)i * ld_table + c, g[(size_t)r * ld_g + c]);
+    }
+}
+
+__global__ void gather_i32_kernel(const int* __restrict__ table, const int* __restrict__ idx, int n_cap,
+                                  const int* __restrict__ n_dyn, int* out) {
+    const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = table[idx[i]];
+}
+
+// out[c] += sum over rows; block = 64 columns x 4 row lanes, 256 rows per block
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ldx, int M_cap,
+                                                     const int* __restrict__ M_dyn, const int* __restrict__ off_dyn,
+                                                     int N, float* out) {
+    __shared__ float part[4][64];
+    const int M = M_dyn != nullptr ? min(M_cap, *M_dyn) : M_cap;
+    const int off = off_dyn != nullptr ? *off_dyn : 0;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ry = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * 256;
+    if (r0 >= M) return;
+    float s = 0.f;
+    if (c < N)
+        for (int r = r0 + ry; r < min(M, r0 + 256); r += 4) s += x[(size_t)(r + off) * ldx + c];
+    part[ry][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (ry == 0 && c < N) atomicAdd(out + c, (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
+}
+
+__global__ void conv3_pack_kernel(const float* __restrict__ w, float* __restrict__ wt, int Dout, int Din) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;      // over [tap][o][c]
+    const int per = Dout * Din;
+    if (e >= 3 * per) return;
+    const int tap = e / per, oc = e - tap * per;
+    wt[e] = w[(size_t)oc * 3 + tap];
+}
+__global__ void conv3_unpack_add_kernel(const float* __restrict__ dwt, float* __restrict__ dw, int Dout, int Din) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;      // over [o][c][tap]
+    const int per = Dout * Din;
+    if (e >= 3 * per) return;
+    const int oc = e / 3, tap = e - oc * 3;
+    dw[e] += dwt[(size_t)tap * per + oc];
+}
+
+// ------------------------------------------------------------------ additive attention pooling
+constexpr int kMaxChunks = 4;       // columns handled per lane: 4 floats x kMaxChunks  (D, A <= 1024)
+constexpr int kMaxSegRows = 256;    // rows per segment incl. the extra row
+
+__device__ __forceinline__ float dot_row(const float* __restrict__ a, const float* __restrict__ b, int n, int lane) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxChunks; ++j) {
+        const int c = 4 * lane + 256 * j;
+        if (c < n) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(a + c);
+            const f32x4 y = *reinterpret_cast<const f32x4*>(b + c);
+            s += (x[0] * y[0] + x[1] * y[1]) + (x[2] * y[2] + x[3] * y[3]);
+        }
+    }
+    return wave_sum(s);
+}
+
+__global__ __launch_bounds__(256) void additive_pool_fwd_kernel(
+    const float* __restrict__ t, int ldt, const float* __restrict__ x, int ldx, const float* __restrict__ w2,
+    const int* __restrict__ seg_off, const int* __restrict__ rowinfo, const int* __restrict__ extra_off_dyn,
+    int n_cap, const int* __restrict__ n_dyn, int D, int A, float* __restrict__ out, int ldo, float* __restrict__ wrow) {
+    const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int beg = seg_off[i], end = seg_off[i + 1];
+    const int extra = extra_off_dyn != nullptr ? *extra_off_dyn + i : -1;
+    const int cnt = (end - beg) + (extra >= 0 ? 1 : 0);
+    f32x4 acc[kMaxChunks];
+#pragma unroll
+    for (int j = 0; j < kMaxChunks; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float stash[kMaxSegRows / 64] = {0.f, 0.f, 0.f, 0.f};
+    float s = 0.f;
+    for (int l = 0; l < cnt; ++l) {
+        const int row = (l < end - beg) ? beg + l : extra;
+        const float a = dot_row(t + (size_t)row * ldt, w2, A, lane);
+        const bool live = (l < end - beg && rowinfo != nullptr) ? (rowinfo[row] & RI_LIVE) != 0 : true;
+        const float e = live ? expf(a) : 0.f;
+        s += e;
+#pragma unroll
+        for (int j = 0; j < kMaxChunks; ++j) {
+            const int c = 4 * lane + 256 * j;
+            if (c < D) acc[j] += e * *reinterpret_cast<const f32x4*>(x + (size_t)row * ldx + c);
+        }
+        if ((l & 63) == lane) {
+            const int k = l >> 6;
+            if (k == 0) stash[0] = e; else if (k == 1) stash[1] = e; else if (k == 2) stash[2] = e; else stash[3] = e;
+        }
+    }
+    const float inv = 1.f / (s + kEps);
+#pragma unroll
+    for (int j = 0; j < kMaxChunks; ++j) {
+        const int c = 4 * lane + 256 * j;
+        if (c < D) *reinterpret_cast<f32x4*>(out + (size_t)i * ldo + c) = acc[j] * inv;
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxSegRows / 64; ++k) {
+        const int l = lane + 64 * k;
+        if (l < cnt) wrow[(l < end - beg) ? beg + l : extra] = stash[k] * inv;
+    }
+}
+
+__global__ __launch_bounds__(256) void additive_pool_bwd_kernel(
+    float* __restrict__ t, int ldt, const float* __restrict__ x, int ldx, const float* __restrict__ w2,
+    const int* __restrict__ seg_off, const int* __restrict__ extra_off_dyn, int n_cap, const int* __restrict__ n_dyn,
+    int D, int A, const float* __restrict__ gout, int ldgo, const float* __restrict__ wrow,
+    float* __restrict__ dx, int lddx, float* gw2, float* gb1) {
+    __shared__ float red[2][4][kMaxChunks * 256];
+    const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 aw2[kMaxChunks], ab1[kMaxChunks], w2v[kMaxChunks];
+#pragma unroll
+    for (int j = 0; j < kMaxChunks; ++j) {
+        aw2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ab1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int c = 4 * lane + 256 * j;
+        w2v[j] = c < A ? *reinterpret_cast<const f32x4*>(w2 + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
+        const int beg = seg_off[i], end = seg_off[i + 1];
+        const int extra = extra_off_dyn != nullptr ? *extra_off_dyn + i : -1;
+        const int cnt = (end - beg) + (extra >= 0 ? 1 : 0);
+        const float* go = gout + (size_t)i * ldgo;
+        float stash[kMaxSegRows / 64] = {0.f, 0.f, 0.f, 0.f};
+        float sdw = 0.f;
+        for (int l = 0; l < cnt; ++l) {
+            const int row = (l < end - beg) ? beg + l : extra;
+            const float dw = dot_row(go, x + (size_t)row * ldx, D, lane);
+            sdw += wrow[row] * dw;
+            if ((l & 63) == lane) {
+                const int k = l >> 6;
+                if (k == 0) stash[0] = dw; else if (k == 1) stash[1] = dw; else if (k == 2) stash[2] = dw; else stash[3] = dw;
+            }
+        }
+        for (int l = 0; l < cnt; ++l) {
+            const int row = (l < end - beg) ? beg + l : extra;
+            const int k = l >> 6;
+            const float mine = k == 0 ? stash[0] : k == 1 ? stash[1] : k == 2 ? stash[2] : stash[3];
+            const float dw = __shfl(mine, l & 63, 64);
+            const float w = wrow[row];
+            const float da = w * (dw - sdw);
+#pragma unroll
+            for (int j = 0; j < kMaxChunks; ++j) {
+                const int c = 4 * lane + 256 * j;
+                if (c < D) *reinterpret_cast<f32x4*>(dx + (size_t)row * lddx + c) = w * *reinterpret_cast<const f32x4*>(go + c);
+                if (c < A) {
+                    f32x4* tp = reinterpret_cast<f32x4*>(t + (size_t)row * ldt + c);
+                    const f32x4 tv = *tp;
+                    const f32x4 dpre = da * w2v[j] * (1.f - tv * tv);
+                    aw2[j] += da * tv;
+                    ab1[j] += dpre;
+                    *tp = dpre;
+                }
+            }
+        }
+    }
+    // block reduction of the two parameter-gradient partials, then one atomic per column per block
+#pragma unroll
+    for (int j = 0; j < kMaxChunks; ++j) {
+        const int c = 4 * lane + 256 * j;
+        *reinterpret_cast<f32x4*>(&red[0][wave][c]) = aw2[j];
+        *reinterpret_cast<f32x4*>(&red[1][wave][c]) = ab1[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < A; c += 256) {
+        atomicAdd(gw2 + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
+        atomicAdd(gb1 + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
+    }
+}
+
+// ------------------------------------------------------------------ dot predictor + cross entropy(label 0)
+constexpr int kMaxCand = 64;
+
+__global__ __launch_bounds__(256) void dot_ce_fwd_kernel(const float* __restrict__ user, int ldu,
+                                                         const float* __restrict__ items, int ldi, int B, int C, int D,
+                                                         float* __restrict__ scores, float* loss) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    float mine = -INFINITY;
+    for (int c = 0; c < C; ++c) {
+        const float s = dot_row(user + (size_t)b * ldu, items + (size_t)(b * C + c) * ldi, D, lane);
+        if (lane == c) mine = s;
+    }
+    if (lane < C) scores[b * C + lane] = mine;
+    if (loss != nullptr) {
+        float mx = mine;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        const float ex = lane < C ? expf(mine - mx) : 0.f;
+        const float se = wave_sum(ex);
+        const float s0 = __shfl(mine, 0, 64);
+        if (lane == 0) atomicAdd(loss, (logf(se) + mx - s0) / (float)B);
+    }
+}
+
+__global__ __launch_bounds__(256) void dot_ce_bwd_kernel(const float* __restrict__ user, int ldu,
+                                                         const float* __restrict__ items, int ldi,
+                                                         const float* __restrict__ scores, int B, int C, int D, float gscale,
+                                                         float* __restrict__ guser, int ldgu, float* __restrict__ gitems, int ldgi) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float mine = lane < C ? scores[b * C + lane] : -INFINITY;
+    float mx = mine;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    const float ex = lane < C ? expf(mine - mx) : 0.f;
+    const float se = wave_sum(ex);
+    const float g_mine = (ex / se - (lane == 0 ? 1.f : 0.f)) * gscale;
+    f32x4 gu[kMaxChunks];
+#pragma unroll
+    for (int j = 0; j < kMaxChunks; ++j) gu[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C; ++c) {
+        const float g = __shfl(g_mine, c, 64);
+#pragma unroll
+        for (int j = 0; j < kMaxChunks; ++j) {
+            const int d = 4 * lane + 256 * j;
+            if (d < D) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(user + (size_t)b * ldu + d);
+                const f32x4 it = *reinterpret_cast<const f32x4*>(items + (size_t)(b * C + c) * ldi + d);
+                gu[j] += g * it;
+                *reinterpret_cast<f32x4*>(gitems + (size_t)(b * C + c) * ldgi + d) = g * u;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kMaxChunks; ++j) {
+        const int d = 4 * lane + 256 * j;
+        if (d < D) *reinterpret_cast<f32x4*>(guser + (size_t)b * ldgu + d) = gu[j];
+    }
+}
+
+// ------------------------------------------------------------------ Adam
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long long n, float step_size, float beta1, float beta2, float eps, float inv_sqrt_bc2, float gscale) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gr = g[i] * gscale;
+        const float mi = beta1 * m[i] + (1.f - beta1) * gr;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gr * gr;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        p[i] -= step_size * (mi / denom);
+    }
+}
+
+// ------------------------------------------------------------------ negative sampling / history fetch
+__global__ void sample_negatives_kernel(const int* __restrict__ row_user, const int* __restrict__ row_item,
+                                        const int* __restrict__ neg_list, const int* __restrict__ neg_len, int neg_cap,
+                                        int B, int K, int n_items, uint32_t seed_lo, uint32_t seed_hi, uint32_t step, int* cand) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int u = row_user[b];
+    const int L = min(max(neg_len[u], 0), neg_cap);
+    const int n_true = min(K, L);
+    int* out = cand + (size_t)b * (K + 1);
+    out[0] = row_item[b];
+    uint32_t ctr = 0;
+    Philox4 r = philox4x32_10((uint32_t)b, step, ctr++, 0x6e656773u, seed_lo, seed_hi);
+    int have = 0;
+    uint32_t pool[4] = {r.x, r.y, r.z, r.w};
+    auto next = [&]() -> uint32_t {
+        if (have == 4) {
+            r = philox4x32_10((uint32_t)b, step, ctr++, 0x6e656773u, seed_lo, seed_hi);
+            pool[0] = r.x; pool[1] = r.y; pool[2] = r.z; pool[3] = r.w; have = 0;
+        }
+        return pool[have++];
+    };
+    int chosen[kMaxCand];
+    for (int k = 0; k < n_true; ++k) {            // distinct POSITIONS of the true-negative list (random.sample)
+        int pos;
+        bool dup;
+        do {
+            pos = (int)(((unsigned long long)next() * (unsigned long long)L) >> 32);
+            dup = false;
+            for (int q = 0; q < k; ++q) dup |= (chosen[q] == pos);
+        } while (dup);
+        chosen[k] = pos;
+        out[1 + k] = neg_list[(size_t)u * neg_cap + pos];
+    }
+    for (int k = n_true; k < K; ++k)              // random.randint(0, item_size - 1) fill
+        out[1 + k] = (int)(((unsigned long long)next() * (unsigned long long)n_items) >> 32);
+}
+
+__global__ void gather_history_kernel(const int* __restrict__ row_user, const int* __restrict__ user_hist,
+                                      const int* __restrict__ user_hist_len, int B, int S, int* hist, int* hist_len) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= B * S) return;
+    const int b = gid / S, s = gid - b * S;
+    const int u = row_user[b];
+    hist[gid] = user_hist[(size_t)u * S + s];
+    if (s == 0) hist_len[b] = user_hist_len[u];
+}
+
+}  // namespace lego
+
+using namespace lego;
+#define ST ((hipStream_t)stream)
+
+extern "C" int lego_plan_batch(const int32_t* cand, const int32_t* hist, const int32_t* hist_len, int B, int C, int S,
+                               const int32_t* title_tok, const int32_t* title_len, int T,
+                               int32_t* counters, int32_t* inst_item, int32_t* seg_off, int32_t* hist_off,
+                               int32_t* rowinfo, int32_t* row_tok, void* stream) {
+    LEGO_REQUIRE(B > 0 && C > 0 && S >= 0 && T > 0, "lego_plan_batch: bad sizes B=%d C=%d S=%d T=%d", B, C, S, T);
+    LEGO_REQUIRE((long long)B * (C + S) < (1 << 23), "lego_plan_batch: too many item instances");
+    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, ST, cand, hist, hist_len, B, C, S, title_len,
+                       counters, inst_item, seg_off, hist_off);
+    const int NI_cap = B * (C + S);
+    hipLaunchKernelGGL(plan_rows_kernel, dim3((NI_cap * 32 + 255) / 256), dim3(256), 0, ST, counters, inst_item, seg_off,
+                       title_tok, title_len, T, NI_cap, rowinfo, row_tok);
+    return check_launch("lego_plan_batch");
+}
+
+extern "C" int lego_plan_dense(const int32_t* mask, int n, int L, int32_t* counters, int32_t* seg_off, int32_t* rowinfo,
+                               void* stream) {
+    LEGO_REQUIRE(n > 0 && L > 0, "lego_plan_dense: bad sizes n=%d L=%d", n, L);
+    LEGO_REQUIRE(L + 1 <= kMaxSegRows, "lego_plan_dense: L=%d exceeds the %d-row segment limit", L, kMaxSegRows - 1);
+    hipLaunchKernelGGL(plan_dense_kernel, dim3((n * L + n + 256) / 256), dim3(256), 0, ST, mask, n, L, counters, seg_off, rowinfo);
+    return check_launch("lego_plan_dense");
+}
+
+extern "C" int lego_gather_rows(const float* table, int ld_table, int width, const int32_t* idx, int rows_cap,
+                                const int32_t* rows_dyn, float* out, int ld_out, int accumulate, void* stream) {
+    LEGO_REQUIRE((width & 3) == 0 && (ld_table & 3) == 0 && (ld_out & 3) == 0, "lego_gather_rows: width/ld must be multiples of 4");
+    if (rows_cap <= 0) return 0;
+    const long long total = (long long)rows_cap * (width / 4);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, ST, table, ld_table, width / 4, idx, rows_cap, rows_dyn, out, ld_out, accumulate);
+    return check_launch("lego_gather_rows");
+}
+
+extern "C" int lego_nrms_decode_rows(const int32_t* row_tok, int R_cap, const int32_t* R_dyn, int32_t* idx_tok,
+                                     int32_t* idx_special, int32_t* idx_cat, int32_t* tokinfo, void* stream) {
+    if (R_cap <= 0) return 0;
+    hipLaunchKernelGGL(nrms_decode_rows_kernel, dim3((R_cap + 255) / 256), dim3(256), 0, ST, row_tok, R_cap, R_dyn, idx_tok,
+                       idx_special, idx_cat, tokinfo);
+    return check_launch("lego_nrms_decode_rows");
+}
+
+extern "C" int lego_mask_dropout_rows(float* x, int ld, int R_cap, const int32_t* R_dyn, int width, const int32_t* rowinfo,
+                                      const lego_dropout* drop, void* stream) {
+    if (R_cap <= 0) return 0;
+    Dropout d{0.f, 0u, 0u, 0u};
+    if (drop != nullptr && drop->p > 0.f) d = Dropout{drop->p, (uint32_t)drop->seed, (uint32_t)(drop->seed >> 32), drop->site};
+    const long long total = (long long)R_cap * width;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(mask_dropout_rows_kernel, dim3(blocks), dim3(256), 0, ST, x, ld, R_cap, R_dyn, width, rowinfo, d);
+    return check_launch("lego_mask_dropout_rows");
+}
+
+extern "C" int lego_scatter_add_rows(float* grad_table, int ld_table, int width, const int32_t* idx, int rows_cap,
+                                     const int32_t* rows_dyn, const float* g, int ld_g, void* stream) {
+    if (rows_cap <= 0) return 0;
+    const long long total = (long long)rows_cap * width;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(blocks), dim3(256), 0, ST, grad_table, ld_table, width, idx, rows_cap, rows_dyn, g, ld_g);
+    return check_launch("lego_scatter_add_rows");
+}
+
+extern "C" int lego_gather_i32(const int32_t* table, const int32_t* idx, int n_cap, const int32_t* n_dyn, int32_t* out, void* stream) {
+    if (n_cap <= 0) return 0;
+    hipLaunchKernelGGL(gather_i32_kernel, dim3((n_cap + 255) / 256), dim3(256), 0, ST, table, idx, n_cap, n_dyn, out);
+    return check_launch("lego_gather_i32");
+}
+
+extern "C" int lego_colsum(const float* x, int ldx, int M_cap, const int32_t* M_dyn, const int32_t* row_off_dyn,
+                           int N, float* out, void* stream) {
+    if (M_cap <= 0) return 0;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, (M_cap + 255) / 256), dim3(256), 0, ST, x, ldx, M_cap, M_dyn, row_off_dyn, N, out);
+    return check_launch("lego_colsum");
+}
+
+extern "C" int lego_conv3_pack(const float* w, float* wt, int Dout, int Din, void* stream) {
+    const int n = 3 * Dout * Din;
+    hipLaunchKernelGGL(conv3_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, ST, w, wt, Dout, Din);
+    return check_launch("lego_conv3_pack");
+}
+extern "C" int lego_conv3_unpack_add(const float* dwt, float* dw, int Dout, int Din, void* stream) {
+    const int n = 3 * Dout * Din;
+    hipLaunchKernelGGL(conv3_unpack_add_kernel, dim3((n + 255) / 256), dim3(256), 0, ST, dwt, dw, Dout, Din);
+    return check_launch("lego_conv3_unpack_add");
+}
+
+extern "C" int lego_additive_pool_fwd(const float* t, int ldt, const float* x, int ldx, const float* w2,
+                                      const int32_t* seg_off, const int32_t* rowinfo, const int32_t* extra_off_dyn,
+                                      int n_cap, const int32_t* n_dyn, int D, int A, float* out, int ldo, float* wrow,
+                                      void* stream) {
+    LEGO_REQUIRE((D & 3) == 0 && (A & 3) == 0 && D <= 256 * kMaxChunks && A <= 256 * kMaxChunks,
+                 "lego_additive_pool_fwd: D=%d A=%d must be multiples of 4 and <= %d", D, A, 256 * kMaxChunks);
+    LEGO_REQUIRE((ldt & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0, "lego_additive_pool_fwd: strides must be multiples of 4");
+    if (n_cap <= 0) return 0;
+    hipLaunchKernelGGL(additive_pool_fwd_kernel, dim3((n_cap + 3) / 4), dim3(256), 0, ST, t, ldt, x, ldx, w2, seg_off, rowinfo,
+                       extra_off_dyn, n_cap, n_dyn, D, A, out, ldo, wrow);
+    return check_launch("lego_additive_pool_fwd");
+}
+
+extern "C" int lego_additive_pool_bwd(float* t_dpre, int ldt, const float* x, int ldx, const float* w2,
+                                      const int32_t* seg_off, const int32_t* extra_off_dyn, int n_cap, const int32_t* n_dyn,
+                                      int D, int A, const float* gout, int ldgo, const float* wrow,
+                                      float* dx, int lddx, float* gw2, float* gb1, void* stream) {
+    LEGO_REQUIRE((D & 3) == 0 && (A & 3) == 0 && D <= 256 * kMaxChunks && A <= 256 * kMaxChunks,
+                 "lego_additive_pool_bwd: D=%d A=%d must be multiples of 4 and <= %d", D, A, 256 * kMaxChunks);
+    if (n_cap <= 0) return 0;
+    int blocks = (n_cap + 3) / 4;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(additive_pool_bwd_kernel, dim3(blocks), dim3(256), 0, ST, t_dpre, ldt, x, ldx, w2, seg_off, extra_off_dyn,
+                       n_cap, n_dyn, D, A, gout, ldgo, wrow, dx, lddx, gw2, gb1);
+    return check_launch("lego_additive_pool_bwd");
+}
+
+extern "C" int lego_dot_ce_fwd(const float* user, int ldu, const float* items, int ldi, int B, int C, int D,
+                               float* scores, float* loss, void* stream) {
+    LEGO_REQUIRE(C <= kMaxCand && (D & 3) == 0 && D <= 256 * kMaxChunks, "lego_dot_ce_fwd: C=%d D=%d unsupported", C, D);
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(dot_ce_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, user, ldu, items, ldi, B, C, D, scores, loss);
+    return check_launch("lego_dot_ce_fwd");
+}
+extern "C" int lego_dot_ce_bwd(const float* user, int ldu, const float* items, int ldi, const float* scores,
+                               int B, int C, int D, float gscale, float* guser, int ldgu, float* gitems, int ldgi, void* stream) {
+    LEGO_REQUIRE(C <= kMaxCand && (D & 3) == 0 && D <= 256 * kMaxChunks, "lego_dot_ce_bwd: C=%d D=%d unsupported", C, D);
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(dot_ce_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, user, ldu, items, ldi, scores, B, C, D, gscale,
+                       guser, ldgu, gitems, ldgi);
+    return check_launch("lego_dot_ce_bwd");
+}
+
+extern "C" int lego_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                              float eps, int step, float grad_scale, void* stream) {
+    LEGO_REQUIRE(step >= 1, "lego_adam_step: step is 1-based (got %d)", step);
+    if (n <= 0) return 0;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, ST, p, g, m, v, (long long)n, step_size, beta1, beta2, eps,
+                       inv_sqrt_bc2, grad_scale);
+    return check_launch("lego_adam_step");
+}
+
+extern "C" int lego_sample_negatives(const int32_t* row_user, const int32_t* row_item, const int32_t* neg_list,
+                                     const int32_t* neg_len, int neg_cap, int B, int K, int n_items, uint64_t seed,
+                                     uint32_t step, int32_t* cand, void* stream) {
+    LEGO_REQUIRE(K < kMaxCand && n_items > 0, "lego_sample_negatives: K=%d n_items=%d unsupported", K, n_items);
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(sample_negatives_kernel, dim3((B + 127) / 128), dim3(128), 0, ST, row_user, row_item, neg_list, neg_len,
+                       neg_cap, B, K, n_items, (uint32_t)seed, (uint32_t)(seed >> 32), step, cand);
+    return check_launch("lego_sample_negatives");
+}
+
+extern "C" int lego_gather_history(const int32_t* row_user, const int32_t* user_hist, const int32_t* user_hist_len,
+                                   int B, int S, int32_t* hist, int32_t* hist_len, void* stream) {
+    if (B <= 0 || S <= 0) return 0;
+    hipLaunchKernelGGL(gather_history_kernel, dim3((B * S + 255) / 256), dim3(256), 0, ST, row_user, user_hist, user_hist_len,
+                       B, S, hist, hist_len);
+    return check_launch("lego_gather_history");
+}

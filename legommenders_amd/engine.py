@@ -1,0 +1,421 @@
+"""Host-side orchestration of the HIP hot path: one training / scoring step of the two-tower
+recommender (`Legommender.forward` + backward, reference model/legommender.py:219-263) as a
+sequence of liblego_hip.so calls over a pre-allocated HBM workspace.
+
+Data layout (everything resident in HBM, nothing crosses PCIe inside a step):
+  * item tables   title_tok i32[n_items,T] (-1 pad), title_len i32[n_items], cat i32[n_items]
+  * per batch     cand i32[B,C], hist i32[B,S], hist_len i32[B]
+  * ragged plan   built on device by lego_plan_batch: only LIVE item instances (B*C candidates +
+                  sum(hist_len) clicked items) and only LIVE title tokens become rows; row counts
+                  stay on the device (`counters`) and are read by the kernels, never by the host.
+  * row spaces    token rows [0,R): X (gathered GloVe rows), H (projected), Y (conv output);
+                  Y rows [R,R+NI): one category row per instance; T = tanh hidden of the additive
+                  attention over all Y rows; item vectors [NI,D]; history instances of one user are
+                  contiguous, so the user encoder pools straight over item-vector rows.
+No torch op touches the data path; torch only owns the memory and the stream.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from ._lib import LegoDropout, call
+
+SITE_PROJ, SITE_CONV, SITE_ITEM_ATT, SITE_USER_ATT = 0, 1, 2, 3
+
+
+def _ptr(t: Optional[torch.Tensor], off: int = 0):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr() + off * t.element_size())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise _lib.LegoHipError(f"{name} must live on the GPU (the HIP path has no CPU fallback)")
+    if t.dtype != dtype or not t.is_contiguous():
+        raise _lib.LegoHipError(f"{name}: expected contiguous {dtype}, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t
+
+
+class ItemTables:
+    """Device-resident item table (the reference's Resampler.item_cache, loader/resampler.py:113-126,
+    kept as flat int32 arrays instead of a python list of per-item tensor dicts)."""
+
+    def __init__(self, title_tok, title_len, cat, device):
+        self.title_tok = torch.as_tensor(title_tok).to(device=device, dtype=torch.int32).contiguous()
+        self.title_len = torch.as_tensor(title_len).to(device=device, dtype=torch.int32).contiguous()
+        self.cat = torch.as_tensor(cat).to(device=device, dtype=torch.int32).contiguous()
+        self.n_items, self.T = self.title_tok.shape
+
+
+class _Base:
+    def __init__(self, params: Dict[str, torch.Tensor], tables: ItemTables, B: int, C: int, S: int,
+                 seed: int = 2023):
+        self.P = params
+        self.tb = tables
+        self.B, self.C, self.S, self.T = B, C, S, tables.T
+        self.dev = tables.title_tok.device
+        self.seed = seed
+        self.step = 0
+        self.NIc = B * (C + S)
+        self.BC = B * C
+        i32 = dict(dtype=torch.int32, device=self.dev)
+        self.counters = torch.zeros(8, **i32)
+        self.inst_item = torch.zeros(self.NIc, **i32)
+        self.seg_off = torch.zeros(self.NIc + 1, **i32)
+        self.hist_off = torch.zeros(B + 1, **i32)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        self.scores = torch.zeros(B, C, dtype=torch.float32, device=self.dev)
+
+    def _f(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float32, device=self.dev)
+
+    def cnt(self, k):
+        """device pointer to counters[k] (0 = token rows R, 1 = instances NI, 2 = R+NI, 3 = history instances)"""
+        return _ptr(self.counters, k)
+
+    def drop(self, p: float, site: int, training: bool):
+        if not training or p <= 0.0:
+            return None
+        return ctypes.byref(LegoDropout(p, self.seed, site + 16 * self.step))
+
+    def grads_like(self):
+        return {k: torch.zeros_like(v) for k, v in self.P.items() if v.dtype == torch.float32 and k not in self.frozen}
+
+
+class NamlEngine(_Base):
+    """NAML: frozen-GloVe gather -> Linear(E0->D) -> Conv1d(k3)+ReLU -> additive pool (items),
+    additive pool over the click history (users), dot product + CE.  Parameter names are the
+    reference's state_dict keys."""
+
+    frozen = ("embedding_vocab_table.glove.embedding.weight",)
+
+    def __init__(self, params, tables, B, C=5, S=50, seed=2023, p_proj=0.1, p_conv=0.1):
+        super().__init__(params, tables, B, C, S, seed)
+        P = params
+        self.E0 = P["embedding_vocab_table.glove.embedding.weight"].shape[1]
+        self.D = P["embedding_vocab_table.glove.linear.weight"].shape[0]
+        self.A = P["item_op.additive_attention.encoder.0.weight"].shape[0]
+        self.Au = P["user_op.additive_attention.encoder.0.weight"].shape[0]
+        self.p_proj, self.p_conv = p_proj, p_conv
+        D, A, E0 = self.D, self.A, self.E0
+        for k, v in P.items():
+            _check(v, torch.float32, k)
+        if D % 32:
+            raise _lib.LegoHipError(f"hidden size {D} must be a multiple of 32 for the conv implicit GEMM")
+        self.Rc = self.NIc * self.T
+        self.Ryc = self.Rc + self.NIc
+        i32 = dict(dtype=torch.int32, device=self.dev)
+        self.rowinfo = torch.zeros(self.Rc, **i32)
+        self.row_tok = torch.zeros(self.Rc, **i32)
+        self.inst_cat = torch.zeros(self.NIc, **i32)
+        self.X = self._f(self.Rc, E0)
+        self.H = self._f(self.Rc, D)
+        self.Y = self._f(self.Ryc, D)
+        self.Tt = self._f(self.Ryc, A)
+        self.wrow = self._f(self.Ryc)
+        self.cat_emb = self._f(self.NIc, D)
+        self.items = self._f(self.NIc, D)
+        self.Tu = self._f(B * S, self.Au)
+        self.wu = self._f(B * S)
+        self.user = self._f(B, D)
+        self.wt = self._f(3, D, D)
+        # backward workspace
+        self.d_user = self._f(B, D)
+        self.d_items = self._f(self.NIc, D)
+        self.dY = self._f(self.Ryc, D)
+        self.dH = self._f(self.Rc, D)
+        self.d_cat_emb = self._f(self.NIc, D)
+        self.dwt = self._f(3, D, D)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, cand, hist, hist_len, training=False, with_loss=True):
+        P, B, C, S, D, A, E0 = self.P, self.B, self.C, self.S, self.D, self.A, self.E0
+        st = _stream()
+        _check(cand, torch.int32, "cand"); _check(hist, torch.int32, "hist"); _check(hist_len, torch.int32, "hist_len")
+        self._training = training
+        call("lego_plan_batch", _ptr(cand), _ptr(hist), _ptr(hist_len), B, C, S,
+             _ptr(self.tb.title_tok), _ptr(self.tb.title_len), self.T,
+             _ptr(self.counters), _ptr(self.inst_item), _ptr(self.seg_off), _ptr(self.hist_off),
+             _ptr(self.rowinfo), _ptr(self.row_tok), st)
+        # k1: frozen GloVe row gather, then Transformation = Dropout(Linear(.)) (embedding_hub.py:95-96)
+        call("lego_gather_rows", _ptr(P["embedding_vocab_table.glove.embedding.weight"]), E0, E0,
+             _ptr(self.row_tok), self.Rc, self.cnt(0), _ptr(self.X), E0, 0, st)
+        call("lego_linear_fwd", _ptr(self.X), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
+             _ptr(P["embedding_vocab_table.glove.linear.bias"]), _ptr(self.H), D, self.Rc, self.cnt(0), D, E0, 0,
+             _ptr(self.rowinfo), self.drop(self.p_proj, SITE_PROJ, training), None, None, st)
+        # k3: conv + relu + mask + dropout (cnn_operator.py:54-57)
+        call("lego_conv3_pack", _ptr(P["item_op.cnn.weight"]), _ptr(self.wt), D, D, st)
+        call("lego_conv3_fwd", _ptr(self.H), D, _ptr(self.wt), _ptr(P["item_op.cnn.bias"]), _ptr(self.rowinfo),
+             _ptr(self.Y), D, self.Rc, self.cnt(0), D, D, self.drop(self.p_conv, SITE_CONV, training), st)
+        # k2/k4: category embedding + Linear on the length-1 column (cnn_operator.py:58-60) -> Y rows R..R+NI
+        call("lego_gather_i32", _ptr(self.tb.cat), _ptr(self.inst_item), self.NIc, self.cnt(1), _ptr(self.inst_cat), st)
+        call("lego_gather_rows", _ptr(P["embedding_vocab_table.category.weight"]), D, D, _ptr(self.inst_cat),
+             self.NIc, self.cnt(1), _ptr(self.cat_emb), D, 0, st)
+        call("lego_linear_fwd", _ptr(self.cat_emb), D, _ptr(P["item_op.linear.weight"]), D,
+             _ptr(P["item_op.linear.bias"]), _ptr(self.Y), D, self.NIc, self.cnt(1), D, D, 0,
+             None, None, None, self.cnt(0), st)
+        # k5: additive attention pool over [title tokens..., category] (attention.py:31-38)
+        self._additive_fwd("item_op.", self.Y, self.Ryc, self.cnt(2), self.Tt, A, self.seg_off, None, self.cnt(0),
+                           self.NIc, self.cnt(1), self.items, self.wrow, st)
+        # k7: AdaOperator = additive pool over the clicked items of each user (ada_operator.py:31-34)
+        hist_items = _ptr(self.items, self.BC * D)
+        self._additive_fwd("user_op.", hist_items, B * S, self.cnt(3), self.Tu, self.Au, self.hist_off, None, None,
+                           B, None, self.user, self.wu, st, x_is_ptr=True)
+        # k11/k12: dot predictor + CE(label 0)
+        self.loss.zero_()
+        call("lego_dot_ce_fwd", _ptr(self.user), D, _ptr(self.items), D, B, C, D, _ptr(self.scores),
+             _ptr(self.loss) if with_loss else None, st)
+        self.step += 1 if training else 0
+        return self.scores, self.loss
+
+    def _additive_fwd(self, prefix, x, rows_cap, rows_dyn, t, A, seg_off, rowinfo, extra, n_cap, n_dyn, out, wrow, st,
+                      x_is_ptr=False):
+        P, D = self.P, self.D
+        xp = x if x_is_ptr else _ptr(x)
+        call("lego_linear_fwd", xp, D, _ptr(P[prefix + "additive_attention.encoder.0.weight"]), D,
+             _ptr(P[prefix + "additive_attention.encoder.0.bias"]), _ptr(t), A, rows_cap, rows_dyn, A, D, 2,
+             None, None, None, None, st)
+        call("lego_additive_pool_fwd", _ptr(t), A, xp, D, _ptr(P[prefix + "additive_attention.encoder.2.weight"]),
+             _ptr(seg_off), _ptr(rowinfo), extra, n_cap, n_dyn, D, A, _ptr(out), D, _ptr(wrow), st)
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, G: Dict[str, torch.Tensor], gloss: float = 1.0):
+        """Accumulates d(loss)/d(param) into G (reference key names); call after forward(training...)."""
+        P, B, C, S, D, A, E0 = self.P, self.B, self.C, self.S, self.D, self.A, self.E0
+        st = _stream()
+        training = self._training
+        step_save = self.step
+        if training:
+            self.step -= 1          # regenerate the masks of the forward pass of this step
+        call("lego_dot_ce_bwd", _ptr(self.user), D, _ptr(self.items), D, _ptr(self.scores), B, C, D,
+             float(gloss) / B, _ptr(self.d_user), D, _ptr(self.d_items), D, st)
+        hist_items = _ptr(self.items, self.BC * D)
+        d_hist_items = _ptr(self.d_items, self.BC * D)
+        self._additive_bwd("user_op.", G, hist_items, d_hist_items, B * S, self.cnt(3), self.Tu, self.Au, self.hist_off,
+                           None, B, None, self.d_user, self.wu, st)
+        # user-side dx += dpre . W1
+        call("lego_linear_bwd_data", _ptr(self.Tu), self.Au, _ptr(P["user_op.additive_attention.encoder.0.weight"]), D,
+             d_hist_items, D, B * S, self.cnt(3), self.Au, D, 1, None, 0, 1.0, None, None, None, None, None, st)
+        # item-side pool backward: dY direct part, dpre in place of T
+        self._additive_bwd("item_op.", G, _ptr(self.Y), _ptr(self.dY), self.Ryc, self.cnt(2), self.Tt, A, self.seg_off,
+                           self.cnt(0), self.NIc, self.cnt(1), self.d_items, self.wrow, st)
+        keep = 1.0 / (1.0 - self.p_conv) if (training and self.p_conv > 0) else 1.0
+        w1 = _ptr(P["item_op.additive_attention.encoder.0.weight"])
+        # token rows: dY = relu'(.)*keep * (dY + dpre.W1); column sums -> conv bias grad
+        call("lego_linear_bwd_data", _ptr(self.Tt), A, w1, D, _ptr(self.dY), D, self.Rc, self.cnt(0), A, D, 1,
+             _ptr(self.Y), D, keep, None, None, _ptr(G["item_op.cnn.bias"]), None, None, st)
+        # category rows: dY += dpre.W1; column sums -> item linear bias grad
+        call("lego_linear_bwd_data", _ptr(self.Tt), A, w1, D, _ptr(self.dY), D, self.NIc, self.cnt(1), A, D, 1,
+             None, 0, 1.0, None, None, _ptr(G["item_op.linear.bias"]), self.cnt(0), self.cnt(0), st)
+        # conv weight / data gradients
+        self.dwt.zero_()
+        call("lego_conv3_bwd_weight", _ptr(self.dY), D, _ptr(self.H), D, _ptr(self.rowinfo), _ptr(self.dwt),
+             self.Rc, self.cnt(0), D, D, st)
+        call("lego_conv3_unpack_add", _ptr(self.dwt), _ptr(G["item_op.cnn.weight"]), D, D, st)
+        call("lego_conv3_bwd_data", _ptr(self.dY), D, _ptr(self.wt), _ptr(self.rowinfo), _ptr(self.dH), D,
+             self.Rc, self.cnt(0), D, D, self.drop(self.p_proj, SITE_PROJ, training),
+             _ptr(G["embedding_vocab_table.glove.linear.bias"]), st)
+        call("lego_linear_bwd_weight", _ptr(self.dH), D, _ptr(self.X), E0,
+             _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Rc, self.cnt(0), D, E0, None, None, st)
+        # category branch: Linear weight grad, embedding grad (trainable 18 x D table)
+        call("lego_linear_bwd_weight", _ptr(self.dY), D, _ptr(self.cat_emb), D, _ptr(G["item_op.linear.weight"]), D,
+             self.NIc, self.cnt(1), D, D, self.cnt(0), None, st)
+        call("lego_linear_bwd_data", _ptr(self.dY), D, _ptr(P["item_op.linear.weight"]), D, _ptr(self.d_cat_emb), D,
+             self.NIc, self.cnt(1), D, D, 0, None, 0, 1.0, None, None, None, self.cnt(0), None, st)
+        call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.category.weight"]), D, D, _ptr(self.inst_cat),
+             self.NIc, self.cnt(1), _ptr(self.d_cat_emb), D, st)
+        self.step = step_save
+
+    def _additive_bwd(self, prefix, G, x_ptr, dx_ptr, rows_cap, rows_dyn, t, A, seg_off, extra, n_cap, n_dyn, gout, wrow, st):
+        P, D = self.P, self.D
+        call("lego_additive_pool_bwd", _ptr(t), A, x_ptr, D, _ptr(P[prefix + "additive_attention.encoder.2.weight"]),
+             _ptr(seg_off), extra, n_cap, n_dyn, D, A, _ptr(gout), D, _ptr(wrow), dx_ptr, D,
+             _ptr(G[prefix + "additive_attention.encoder.2.weight"]), _ptr(G[prefix + "additive_attention.encoder.0.bias"]), st)
+        # dW1 += dpre^T . x   (x is still the forward activation)
+        call("lego_linear_bwd_weight", _ptr(t), A, x_ptr, D, _ptr(G[prefix + "additive_attention.encoder.0.weight"]), D,
+             rows_cap, rows_dyn, A, D, None, None, st)
+
+
+class NrmsEngine(_Base):
+    """NRMS: ConcatInputer sequence [title..., SEP, category, SEP] -> AttentionOperator (MHSA -> Linear ->
+    additive pool) for items, AttentionOperator over the clicked item vectors for users, dot + CE
+    (reference model/operators/attention_operator.py:46-59, model/inputer/concat_inputer.py:58-114).
+    `glove=True`: frozen GloVe + Linear(E0->D) token embedding; `glove=False`: trainable [V,D] table
+    (config/embed/null.yaml, dense-gradient semantics)."""
+
+    def __init__(self, params, tables, B, C=5, S=50, heads=8, glove=False, seed=2023, p_proj=0.1, p_att=0.1):
+        super().__init__(params, tables, B, C, S, seed)
+        P = params
+        self.glove, self.heads = glove, heads
+        self.frozen = ("embedding_vocab_table.glove.embedding.weight",) if glove else ()
+        self.D = P["item_op.linear.weight"].shape[1]
+        self.A = P["item_op.additive_attention.encoder.0.weight"].shape[0]
+        self.E0 = P["embedding_vocab_table.glove.embedding.weight"].shape[1] if glove else self.D
+        self.p_proj, self.p_att = (p_proj if glove else 0.0), p_att
+        for k, v in P.items():
+            _check(v, torch.float32, k)
+        D, A = self.D, self.A
+        # encoded per-item sequence table: token id >= 0, SEP = -2, category = -(3 + cat), pad = -1
+        T = tables.T
+        self.L = T + 3
+        n = tables.n_items
+        seq = torch.full((n, self.L), -1, dtype=torch.int32, device=self.dev)
+        seq[:, :T] = tables.title_tok
+        ar = torch.arange(self.L, device=self.dev)[None, :]
+        tl = tables.title_len[:, None].to(torch.int64)
+        seq = torch.where(ar < tl, seq, torch.full_like(seq, -1))
+        rows = torch.arange(n, device=self.dev)
+        tli = tables.title_len.to(torch.int64)
+        seq[rows, tli] = -2
+        seq[rows, tli + 1] = (-(3 + tables.cat)).to(torch.int32)
+        seq[rows, tli + 2] = -2
+        self.seq_tok = seq.contiguous()
+        self.seq_len = (tables.title_len + 3).contiguous()
+        self.Rc = self.NIc * self.L
+        i32 = dict(dtype=torch.int32, device=self.dev)
+        self.rowinfo = torch.zeros(self.Rc, **i32)
+        self.row_tok = torch.zeros(self.Rc, **i32)
+        self.idx_tok = torch.zeros(self.Rc, **i32)
+        self.idx_spec = torch.zeros(self.Rc, **i32)
+        self.idx_cat = torch.zeros(self.Rc, **i32)
+        self.tokinfo = torch.zeros(self.Rc, **i32)
+        self.X = self._f(self.Rc, self.E0) if glove else None
+        self.E = self._f(self.Rc, D)
+        self.dE = self._f(self.Rc, D)
+        self.items = self._f(self.NIc, D)
+        self.d_items = self._f(self.NIc, D)
+        self.user = self._f(B, D)
+        self.d_user = self._f(B, D)
+        self.item_ws = self._att_ws(self.Rc, self.L)
+        self.user_ws = self._att_ws(B * S, S)
+
+    def _att_ws(self, rows, Lmax):
+        D, A, H = self.D, self.A, self.heads
+        return dict(rows=rows, Lmax=Lmax, qkv=self._f(rows, 3 * D), o=self._f(rows, D), att=self._f(rows, D),
+                    lin=self._f(rows, D), t=self._f(rows, A), wrow=self._f(rows), probs=self._f(rows, H, Lmax),
+                    d_lin=self._f(rows, D), d_att=self._f(rows, D), d_o=self._f(rows, D), d_qkv=self._f(rows, 3 * D))
+
+    # AttentionOperator.forward over ragged segments
+    def _att_fwd(self, pre, ws, x_ptr, rows_dyn, seg_off, n_cap, n_dyn, out, site, training, st):
+        P, D, A = self.P, self.D, self.A
+        rows = ws["rows"]
+        call("lego_linear_fwd", x_ptr, D, _ptr(P[pre + "multi_head_attention.in_proj_weight"]), D,
+             _ptr(P[pre + "multi_head_attention.in_proj_bias"]), _ptr(ws["qkv"]), 3 * D, rows, rows_dyn, 3 * D, D, 0,
+             None, None, None, None, st)
+        call("lego_mhsa_core_fwd", _ptr(ws["qkv"]), 3 * D, _ptr(seg_off), n_cap, n_dyn, D, self.heads, _ptr(ws["o"]), D,
+             _ptr(ws["probs"]), ws["Lmax"], self.drop(self.p_att, site, training), rows, st)
+        call("lego_linear_fwd", _ptr(ws["o"]), D, _ptr(P[pre + "multi_head_attention.out_proj.weight"]), D,
+             _ptr(P[pre + "multi_head_attention.out_proj.bias"]), _ptr(ws["att"]), D, rows, rows_dyn, D, D, 0,
+             None, None, None, None, st)
+        call("lego_linear_fwd", _ptr(ws["att"]), D, _ptr(P[pre + "linear.weight"]), D, _ptr(P[pre + "linear.bias"]),
+             _ptr(ws["lin"]), D, rows, rows_dyn, D, D, 0, None, None, None, None, st)
+        call("lego_linear_fwd", _ptr(ws["lin"]), D, _ptr(P[pre + "additive_attention.encoder.0.weight"]), D,
+             _ptr(P[pre + "additive_attention.encoder.0.bias"]), _ptr(ws["t"]), A, rows, rows_dyn, A, D, 2,
+             None, None, None, None, st)
+        call("lego_additive_pool_fwd", _ptr(ws["t"]), A, _ptr(ws["lin"]), D,
+             _ptr(P[pre + "additive_attention.encoder.2.weight"]), _ptr(seg_off), None, None, n_cap, n_dyn, D, A,
+             _ptr(out), D, _ptr(ws["wrow"]), st)
+
+    def _att_bwd(self, pre, ws, G, x_ptr, dx_ptr, rows_dyn, seg_off, n_cap, n_dyn, gout, site, training, st):
+        P, D, A = self.P, self.D, self.A
+        rows = ws["rows"]
+        call("lego_additive_pool_bwd", _ptr(ws["t"]), A, _ptr(ws["lin"]), D,
+             _ptr(P[pre + "additive_attention.encoder.2.weight"]), _ptr(seg_off), None, n_cap, n_dyn, D, A,
+             _ptr(gout), D, _ptr(ws["wrow"]), _ptr(ws["d_lin"]), D,
+             _ptr(G[pre + "additive_attention.encoder.2.weight"]), _ptr(G[pre + "additive_attention.encoder.0.bias"]), st)
+        call("lego_linear_bwd_weight", _ptr(ws["t"]), A, _ptr(ws["lin"]), D,
+             _ptr(G[pre + "additive_attention.encoder.0.weight"]), D, rows, rows_dyn, A, D, None, None, st)
+        # d_lin += dpre . W1 ; its column sums are the gradient of linear.bias
+        call("lego_linear_bwd_data", _ptr(ws["t"]), A, _ptr(P[pre + "additive_attention.encoder.0.weight"]), D,
+             _ptr(ws["d_lin"]), D, rows, rows_dyn, A, D, 1, None, 0, 1.0, None, None, _ptr(G[pre + "linear.bias"]), None, None, st)
+        call("lego_linear_bwd_weight", _ptr(ws["d_lin"]), D, _ptr(ws["att"]), D, _ptr(G[pre + "linear.weight"]), D,
+             rows, rows_dyn, D, D, None, None, st)
+        call("lego_linear_bwd_data", _ptr(ws["d_lin"]), D, _ptr(P[pre + "linear.weight"]), D, _ptr(ws["d_att"]), D,
+             rows, rows_dyn, D, D, 0, None, 0, 1.0, None, None, _ptr(G[pre + "multi_head_attention.out_proj.bias"]), None, None, st)
+        call("lego_linear_bwd_weight", _ptr(ws["d_att"]), D, _ptr(ws["o"]), D,
+             _ptr(G[pre + "multi_head_attention.out_proj.weight"]), D, rows, rows_dyn, D, D, None, None, st)
+        call("lego_linear_bwd_data", _ptr(ws["d_att"]), D, _ptr(P[pre + "multi_head_attention.out_proj.weight"]), D,
+             _ptr(ws["d_o"]), D, rows, rows_dyn, D, D, 0, None, 0, 1.0, None, None, None, None, None, st)
+        call("lego_mhsa_core_bwd", _ptr(ws["qkv"]), 3 * D, _ptr(seg_off), n_cap, n_dyn, D, self.heads, _ptr(ws["d_o"]), D,
+             _ptr(ws["probs"]), ws["Lmax"], self.drop(self.p_att, site, training), rows, _ptr(ws["d_qkv"]), 3 * D, st)
+        call("lego_colsum", _ptr(ws["d_qkv"]), 3 * D, rows, rows_dyn, None, 3 * D,
+             _ptr(G[pre + "multi_head_attention.in_proj_bias"]), st)
+        call("lego_linear_bwd_weight", _ptr(ws["d_qkv"]), 3 * D, x_ptr, D,
+             _ptr(G[pre + "multi_head_attention.in_proj_weight"]), D, rows, rows_dyn, 3 * D, D, None, None, st)
+        call("lego_linear_bwd_data", _ptr(ws["d_qkv"]), 3 * D, _ptr(P[pre + "multi_head_attention.in_proj_weight"]), D,
+             dx_ptr, D, rows, rows_dyn, 3 * D, D, 0, None, 0, 1.0, None, None, None, None, None, st)
+
+    def forward(self, cand, hist, hist_len, training=False, with_loss=True):
+        P, B, C, S, D = self.P, self.B, self.C, self.S, self.D
+        st = _stream()
+        _check(cand, torch.int32, "cand"); _check(hist, torch.int32, "hist"); _check(hist_len, torch.int32, "hist_len")
+        self._training = training
+        call("lego_plan_batch", _ptr(cand), _ptr(hist), _ptr(hist_len), B, C, S,
+             _ptr(self.seq_tok), _ptr(self.seq_len), self.L,
+             _ptr(self.counters), _ptr(self.inst_item), _ptr(self.seg_off), _ptr(self.hist_off),
+             _ptr(self.rowinfo), _ptr(self.row_tok), st)
+        call("lego_nrms_decode_rows", _ptr(self.row_tok), self.Rc, self.cnt(0), _ptr(self.idx_tok), _ptr(self.idx_spec),
+             _ptr(self.idx_cat), _ptr(self.tokinfo), st)
+        if self.glove:
+            E0 = self.E0
+            call("lego_gather_rows", _ptr(P["embedding_vocab_table.glove.embedding.weight"]), E0, E0, _ptr(self.idx_tok),
+                 self.Rc, self.cnt(0), _ptr(self.X), E0, 0, st)
+            call("lego_linear_fwd", _ptr(self.X), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
+                 _ptr(P["embedding_vocab_table.glove.linear.bias"]), _ptr(self.E), D, self.Rc, self.cnt(0), D, E0, 0,
+                 _ptr(self.tokinfo), self.drop(self.p_proj, SITE_PROJ, training), None, None, st)
+        else:
+            call("lego_gather_rows", _ptr(P["embedding_vocab_table.glove.weight"]), D, D, _ptr(self.idx_tok),
+                 self.Rc, self.cnt(0), _ptr(self.E), D, 0, st)
+        call("lego_gather_rows", _ptr(P["embedding_vocab_table.__cat_inputer_special_ids.weight"]), D, D,
+             _ptr(self.idx_spec), self.Rc, self.cnt(0), _ptr(self.E), D, 1, st)
+        call("lego_gather_rows", _ptr(P["embedding_vocab_table.category.weight"]), D, D, _ptr(self.idx_cat),
+             self.Rc, self.cnt(0), _ptr(self.E), D, 1, st)
+        self._att_fwd("item_op.", self.item_ws, _ptr(self.E), self.cnt(0), self.seg_off, self.NIc, self.cnt(1),
+                      self.items, SITE_ITEM_ATT, training, st)
+        self._att_fwd("user_op.", self.user_ws, _ptr(self.items, self.BC * D), self.cnt(3), self.hist_off, B, None,
+                      self.user, SITE_USER_ATT, training, st)
+        self.loss.zero_()
+        call("lego_dot_ce_fwd", _ptr(self.user), D, _ptr(self.items), D, B, C, D, _ptr(self.scores),
+             _ptr(self.loss) if with_loss else None, st)
+        self.step += 1 if training else 0
+        return self.scores, self.loss
+
+    def backward(self, G, gloss: float = 1.0):
+        P, B, C, S, D = self.P, self.B, self.C, self.S, self.D
+        st = _stream()
+        training = self._training
+        step_save = self.step
+        if training:
+            self.step -= 1
+        call("lego_dot_ce_bwd", _ptr(self.user), D, _ptr(self.items), D, _ptr(self.scores), B, C, D,
+             float(gloss) / B, _ptr(self.d_user), D, _ptr(self.d_items), D, st)
+        self._att_bwd("user_op.", self.user_ws, G, _ptr(self.items, self.BC * D), _ptr(self.d_items, self.BC * D),
+                      self.cnt(3), self.hist_off, B, None, self.d_user, SITE_USER_ATT, training, st)
+        self._att_bwd("item_op.", self.item_ws, G, _ptr(self.E), _ptr(self.dE), self.cnt(0), self.seg_off, self.NIc,
+                      self.cnt(1), self.d_items, SITE_ITEM_ATT, training, st)
+        # embedding tables: the three summed look-ups of ConcatInputer.get_embeddings
+        call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.__cat_inputer_special_ids.weight"]), D, D,
+             _ptr(self.idx_spec), self.Rc, self.cnt(0), _ptr(self.dE), D, st)
+        call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.category.weight"]), D, D, _ptr(self.idx_cat),
+             self.Rc, self.cnt(0), _ptr(self.dE), D, st)
+        if self.glove:
+            E0 = self.E0
+            call("lego_mask_dropout_rows", _ptr(self.dE), D, self.Rc, self.cnt(0), D, _ptr(self.tokinfo),
+                 self.drop(self.p_proj, SITE_PROJ, training), st)
+            call("lego_colsum", _ptr(self.dE), D, self.Rc, self.cnt(0), None, D,
+                 _ptr(G["embedding_vocab_table.glove.linear.bias"]), st)
+            call("lego_linear_bwd_weight", _ptr(self.dE), D, _ptr(self.X), E0,
+                 _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Rc, self.cnt(0), D, E0, None, None, st)
+        else:
+            call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.glove.weight"]), D, D, _ptr(self.idx_tok),
+                 self.Rc, self.cnt(0), _ptr(self.dE), D, st)
+        self.step = step_save

@@ -16,3 +16,11 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _fresh_hip_library():
+    """(Re)build liblego_hip.so before any test: a stale .so behind a changed header is the one
+    failure mode ctypes cannot detect.  `make` is a no-op when everything is up to date."""
+    from legommenders_amd import _lib
+    _lib.build()

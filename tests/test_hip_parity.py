@@ -1,0 +1,237 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden vectors generated from the
+reference and against the CPU oracle on the same seeded inputs.  fp32 everywhere; the north-star
+tolerance is 1e-3 on logits -- these tests hold the kernels to ~1e-4 relative."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.golden_util import GOLDEN, MODEL_FIXTURES, load_model_fixture  # noqa: E402
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _close(got, ref, rtol=2e-4, atol=None, what=""):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    scale = max(1e-12, float(np.abs(ref).max()))
+    tol = rtol * scale if atol is None else atol + rtol * scale
+    err = float(np.abs(got - ref).max())
+    assert err <= tol, f"{what}: max|diff|={err:.3e} > {tol:.3e} (scale {scale:.3e})"
+
+
+def _grads_close(grads, G, name):
+    """Gradient check that is robust to the two places where fp32 results legitimately differ from the
+    reference's: (a) a ReLU pre-activation within rounding of 0 may flip (one rank-1 update of size
+    |dY||H| appears in cnn.weight / cnn.bias), so the max-norm bound is loose but the Frobenius bound is
+    tight; (b) gradients that are pure cancellation noise (|g| ~ 1e-11 when the additive-attention
+    weights are uniform) are compared against the global gradient scale, not their own."""
+    gscale = max(float(np.abs(g).max()) for g in G.values())
+    for k, g in G.items():
+        got = grads[k].detach().cpu().numpy().astype(np.float64)
+        ref = g.astype(np.float64)
+        d = got - ref
+        scale = float(np.abs(ref).max())
+        assert float(np.abs(d).max()) <= 2e-3 * scale + 2e-7 * gscale, \
+            f"{name} grad {k}: max|diff|={np.abs(d).max():.3e} scale={scale:.3e}"
+        assert float(np.linalg.norm(d)) <= 3e-4 * float(np.linalg.norm(ref)) + 2e-7 * gscale * np.sqrt(d.size), \
+            f"{name} grad {k}: |diff|_F={np.linalg.norm(d):.3e} |ref|_F={np.linalg.norm(ref):.3e}"
+
+
+# --------------------------------------------------------------------------- op level
+def test_linear_family_matches_torch():
+    from legommenders_amd import kernels as K
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    for (M, N, Kd) in [(1, 64, 300), (130, 256, 300), (257, 64, 64), (1000, 256, 256), (77, 300, 64)]:
+        x = torch.randn(M, Kd, generator=g)
+        W = torch.randn(N, Kd, generator=g) * 0.1
+        b = torch.randn(N, generator=g)
+        y = K.linear_fwd(x.to(dev), W.to(dev), b.to(dev), act=0)
+        _close(y.cpu(), x @ W.T + b, what=f"linear_fwd {M}x{N}x{Kd}")
+        if N % 4 == 0:
+            yt = K.linear_fwd(x.to(dev), W.to(dev), b.to(dev), act=2)
+            _close(yt.cpu(), torch.tanh(x @ W.T + b), what="linear_fwd tanh")
+            gy = torch.randn(M, N, generator=g)
+            dx = K.linear_bwd_data(gy.to(dev), W.to(dev))
+            _close(dx.cpu(), gy @ W, what=f"linear_bwd_data {M}x{N}x{Kd}")
+            dW = torch.zeros(N, Kd, device=dev)
+            K.linear_bwd_weight(gy.to(dev), x.to(dev), dW)
+            _close(dW.cpu(), gy.T @ x, what=f"linear_bwd_weight {M}x{N}x{Kd}")
+
+
+def test_conv3_matches_torch_conv1d():
+    from legommenders_amd import kernels as K
+    dev = _dev()
+    g = torch.Generator().manual_seed(6)
+    for (n, L, D) in [(3, 30, 64), (17, 30, 256), (5, 1, 64), (4, 7, 32)]:
+        lens = torch.randint(1, L + 1, (n,), generator=g)
+        lens[0] = L
+        mask = (torch.arange(L)[None] < lens[:, None]).int()
+        h = torch.randn(n, L, D, generator=g) * mask[..., None]
+        w = torch.randn(D, D, 3, generator=g) * 0.05
+        b = torch.randn(D, generator=g) * 0.1
+        ref = torch.relu(torch.nn.functional.conv1d(h.permute(0, 2, 1), w, b, padding="same").permute(0, 2, 1)) * mask[..., None]
+        plan = K.plan_dense(mask.to(dev))
+        wt = K.conv3_pack(w.to(dev))
+        y = K.conv3_fwd(h.reshape(n * L, D).to(dev), wt, b.to(dev), plan)
+        _close(y.cpu().view(n, L, D), ref, what=f"conv3_fwd n={n} L={L} D={D}")
+        # backward of y.sum-like functional: compare against autograd
+        hh = h.clone().requires_grad_(True)
+        ww = w.clone().requires_grad_(True)
+        bb = b.clone().requires_grad_(True)
+        out = torch.relu(torch.nn.functional.conv1d(hh.permute(0, 2, 1), ww, bb, padding="same").permute(0, 2, 1)) * mask[..., None]
+        gy = torch.randn(n, L, D, generator=g)
+        out.backward(gy)
+        gpre = (gy * mask[..., None] * (ref > 0)).reshape(n * L, D).contiguous()
+        dh = K.conv3_bwd_data(gpre.to(dev), wt, plan, D)
+        _close(dh.cpu().view(n, L, D) * mask[..., None], hh.grad * mask[..., None], what="conv3_bwd_data")
+        dwt = torch.zeros(3, D, D, device=dev)
+        K.conv3_bwd_weight(gpre.to(dev), h.reshape(n * L, D).to(dev), plan, dwt)
+        dw = torch.zeros(D, D, 3, device=dev)
+        K.conv3_unpack_add(dwt, dw)
+        _close(dw.cpu(), ww.grad, what="conv3_bwd_weight")
+
+
+def test_additive_pool_golden():
+    from legommenders_amd import kernels as K
+    dev = _dev()
+    z = np.load(os.path.join(GOLDEN, "ops.npz"))
+    x = torch.tensor(z["add.x"]).to(dev)
+    mask = torch.tensor(z["add.mask"]).int().to(dev)
+    W1, b1, w2 = (torch.tensor(z[k]).to(dev) for k in ("add.W1", "add.b1", "add.w2"))
+    y, ctx = K.additive_attention_fwd(x, mask, W1, b1, w2)
+    _close(y.cpu(), z["add.y"], what="additive fwd")
+    assert float(y[0].abs().max()) == 0.0        # all-masked row -> exact zeros
+    gx, gW1, gb1, gw2 = K.additive_attention_bwd(ctx, torch.tensor(z["add.gy"]).to(dev))
+    _close(gx.cpu(), z["add.gx"], what="additive gx")
+    _close(gW1.cpu(), z["add.gW1"], what="additive gW1")
+    _close(gb1.cpu(), z["add.gb1"], what="additive gb1")
+    _close(gw2.cpu(), z["add.gw2"], what="additive gw2")
+
+
+def test_dot_ce_golden():
+    from legommenders_amd import kernels as K
+    dev = _dev()
+    z = np.load(os.path.join(GOLDEN, "ops.npz"))
+    u = torch.tensor(z["dot.u"]).to(dev)
+    it = torch.tensor(z["dot.i"]).to(dev)
+    scores, loss = K.dot_ce_fwd(u, it)
+    _close(scores.cpu(), z["dot.s"], what="dot scores")
+    assert abs(float(loss) - float(z["dot.loss"])) < 1e-5
+    gu, gi = K.dot_ce_bwd(u, it, scores)
+    _close(gu.cpu(), z["dot.gu"], what="dot gu")
+    _close(gi.cpu(), z["dot.gi"], what="dot gi")
+
+
+def test_adam_trajectory_golden():
+    from legommenders_amd import kernels as K
+    from oracle import lego_oracle as O
+    dev = _dev()
+    z = np.load(os.path.join(GOLDEN, "ops.npz"))
+    p = torch.tensor(z["adam.traj"][0]).to(dev)
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    for step in range(3):
+        lr = float(z["adam.lr"]) * O.linear_schedule_factor(step, int(z["adam.total"]))
+        K.adam_step(p, torch.tensor(z["adam.g"][step]).to(dev), m, v, lr, step + 1)
+        np.testing.assert_allclose(p.cpu().numpy(), z["adam.traj"][step + 1], rtol=2e-6, atol=1e-7)
+
+
+def test_mhsa_golden():
+    from legommenders_amd import kernels as K
+    dev = _dev()
+    z = np.load(os.path.join(GOLDEN, "ops.npz"))
+    x = torch.tensor(z["mha.x"]).to(dev)
+    mask = torch.tensor(z["mha.mask"]).int().to(dev)
+    ps = [torch.tensor(z[k]).to(dev) for k in ("mha.in_w", "mha.in_b", "mha.out_w", "mha.out_b")]
+    heads = int(z["mha.heads"])
+    y, ctx = K.mhsa_fwd(x, mask, *ps, heads)
+    live = z["mha.mask"].astype(bool)
+    _close(y.cpu().numpy()[live], z["mha.y"][live], what="mhsa fwd")
+    gx, gin_w, gin_b, gout_w, gout_b = K.mhsa_bwd(ctx, torch.tensor(z["mha.gy"]).to(dev))
+    _close(gx.cpu(), z["mha.gx"], what="mhsa gx")
+    _close(gin_w.cpu(), z["mha.gin_w"], what="mhsa gin_w")
+    _close(gin_b.cpu(), z["mha.gin_b"], what="mhsa gin_b")
+    _close(gout_w.cpu(), z["mha.gout_w"], what="mhsa gout_w")
+    _close(gout_b.cpu(), z["mha.gout_b"], what="mhsa gout_b")
+
+
+# --------------------------------------------------------------------------- full model
+def _engine(name):
+    from legommenders_amd import engine as E
+    ItemTables, NamlEngine = E.ItemTables, E.NamlEngine
+    dev = _dev()
+    meta, P, G, tables, batch, logits, loss = load_model_fixture(name)
+    Pd = {k: torch.tensor(v).to(dev).contiguous() for k, v in P.items()}
+    tb = ItemTables(tables["title_tok"], tables["title_len"], tables["cat"], dev)
+    B, C = batch["cand"].shape
+    S = batch["hist"].shape[1]
+    if meta["kind"] == "naml":
+        eng = NamlEngine(Pd, tb, B, C, S)
+    else:
+        eng = E.NrmsEngine(Pd, tb, B, C, S, heads=meta["heads"], glove=(meta["embed"] == "glove"))
+    ids = [torch.tensor(batch[k]).int().to(dev).contiguous() for k in ("cand", "hist", "hist_len")]
+    return eng, ids, G, logits, loss
+
+
+@pytest.mark.parametrize("name", MODEL_FIXTURES)
+def test_engine_logits_loss_grads_vs_golden(name):
+    eng, ids, G, logits, loss = _engine(name)
+    scores, l = eng.forward(*ids, training=False)
+    _close(scores.cpu(), logits, rtol=1e-4, atol=2e-5, what=f"{name} logits")
+    assert float(np.abs(scores.cpu().numpy() - logits).max()) < 1e-3      # the north-star bar
+    assert abs(float(l) - loss) < 2e-5
+    grads = eng.grads_like()
+    eng.backward(grads)
+    torch.cuda.synchronize()
+    _grads_close(grads, G, name)
+
+
+def test_engine_matches_oracle_on_fresh_inputs():
+    """Same seeded inputs through the oracle and the HIP engine (not a stored fixture)."""
+    from oracle import lego_oracle as O
+    from legommenders_amd.engine import ItemTables, NamlEngine
+    dev = _dev()
+    meta, P, G, tables, batch, _, _ = load_model_fixture("naml_glove_d64")
+    rs = np.random.RandomState(99)
+    n_items = tables["title_tok"].shape[0]
+    B, C, S = 16, 5, 50
+    cand = rs.randint(0, n_items, size=(B, C))
+    hist_len = rs.randint(0, S + 1, size=B)
+    hist_len[0] = 0                                   # empty history -> zero user vector
+    hist = rs.randint(0, n_items, size=(B, S)) * (np.arange(S)[None] < hist_len[:, None])
+    ref_logits, ref_loss, ref_g = O.loss_and_grads("naml", P, tables, cand, hist, hist_len)
+    Pd = {k: torch.tensor(v).to(dev).contiguous() for k, v in P.items()}
+    eng = NamlEngine(Pd, ItemTables(tables["title_tok"], tables["title_len"], tables["cat"], dev), B, C, S)
+    ids = [torch.tensor(a).int().to(dev).contiguous() for a in (cand, hist, hist_len)]
+    scores, l = eng.forward(*ids, training=False)
+    _close(scores.cpu(), ref_logits, rtol=1e-4, atol=2e-5, what="logits")
+    grads = eng.grads_like()
+    eng.backward(grads)
+    _grads_close(grads, ref_g, "fresh")
+
+
+def test_dropout_is_unbiased_and_regenerated():
+    """Training-mode dropout (Philox): keep-rate ~ 1-p, scale 1/(1-p), identical mask in fwd and bwd."""
+    from legommenders_amd import kernels as K
+    dev = _dev()
+    M, N, Kd = 4096, 256, 64
+    x = torch.ones(M, Kd, device=dev)
+    W = torch.full((N, Kd), 1.0 / Kd, device=dev)
+    y = K.linear_fwd(x, W, None, act=0, drop=(0.1, 1234, 7))
+    keep = (y > 0).float().mean().item()
+    assert abs(keep - 0.9) < 0.01
+    vals = y[y > 0]
+    assert torch.allclose(vals, torch.full_like(vals, 1.0 / 0.9), rtol=1e-5)
+    y2 = K.linear_fwd(x, W, None, act=0, drop=(0.1, 1234, 7))
+    assert torch.equal(y, y2)
+    y3 = K.linear_fwd(x, W, None, act=0, drop=(0.1, 1234, 8))
+    assert not torch.equal(y, y3)
