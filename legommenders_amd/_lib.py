@@ -75,6 +75,16 @@ def build(verbose: bool = False) -> str:
 _lib = None
 
 
+def _single_hip_runtime():
+    """PyTorch-ROCm ships its own libamdhip64.so.7; liblego_hip.so must bind to THAT copy (same
+    soname), otherwise two HIP runtimes live in one process and torch's streams / device state are
+    invisible to our launches.  Loading torch's copy first makes the dynamic loader reuse it."""
+    import torch
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+
+
 def lib() -> ctypes.CDLL:
     """The loaded library; raises (never falls back) if it is absent or incomplete."""
     global _lib
@@ -84,6 +94,7 @@ def lib() -> ctypes.CDLL:
         raise LegoHipError(
             f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
             "Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C legommenders_amd/csrc`.")
+    _single_hip_runtime()
     handle = ctypes.CDLL(LIB_PATH)
     handle.lego_last_error.restype = ctypes.c_char_p
     handle.lego_last_error.argtypes = []

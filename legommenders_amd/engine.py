@@ -78,6 +78,20 @@ class _Base:
     def _f(self, *shape):
         return torch.zeros(*shape, dtype=torch.float32, device=self.dev)
 
+    timers = None   # set to a dict to time tagged kernels with HIP events on the launch stream (bench.py)
+
+    def k(self, tag, name, *args):
+        """call() with optional per-kernel HIP-event timing (events on torch's current stream, which is
+        the stream every kernel of the step is launched on)."""
+        t = self.timers
+        if t is None:
+            return call(name, *args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call(name, *args)
+        e1.record()
+        t.setdefault(tag, []).append((e0, e1))
+
     def cnt(self, k):
         """device pointer to counters[k] (0 = token rows R, 1 = instances NI, 2 = R+NI, 3 = history instances)"""
         return _ptr(self.counters, k)
@@ -147,14 +161,14 @@ class NamlEngine(_Base):
              _ptr(self.counters), _ptr(self.inst_item), _ptr(self.seg_off), _ptr(self.hist_off),
              _ptr(self.rowinfo), _ptr(self.row_tok), st)
         # k1: frozen GloVe row gather, then Transformation = Dropout(Linear(.)) (embedding_hub.py:95-96)
-        call("lego_gather_rows", _ptr(P["embedding_vocab_table.glove.embedding.weight"]), E0, E0,
+        self.k("gather_rows", "lego_gather_rows", _ptr(P["embedding_vocab_table.glove.embedding.weight"]), E0, E0,
              _ptr(self.row_tok), self.Rc, self.cnt(0), _ptr(self.X), E0, 0, st)
-        call("lego_linear_fwd", _ptr(self.X), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
+        self.k("proj_fwd", "lego_linear_fwd", _ptr(self.X), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
              _ptr(P["embedding_vocab_table.glove.linear.bias"]), _ptr(self.H), D, self.Rc, self.cnt(0), D, E0, 0,
              _ptr(self.rowinfo), self.drop(self.p_proj, SITE_PROJ, training), None, None, st)
         # k3: conv + relu + mask + dropout (cnn_operator.py:54-57)
         call("lego_conv3_pack", _ptr(P["item_op.cnn.weight"]), _ptr(self.wt), D, D, st)
-        call("lego_conv3_fwd", _ptr(self.H), D, _ptr(self.wt), _ptr(P["item_op.cnn.bias"]), _ptr(self.rowinfo),
+        self.k("conv3_fwd", "lego_conv3_fwd", _ptr(self.H), D, _ptr(self.wt), _ptr(P["item_op.cnn.bias"]), _ptr(self.rowinfo),
              _ptr(self.Y), D, self.Rc, self.cnt(0), D, D, self.drop(self.p_conv, SITE_CONV, training), st)
         # k2/k4: category embedding + Linear on the length-1 column (cnn_operator.py:58-60) -> Y rows R..R+NI
         call("lego_gather_i32", _ptr(self.tb.cat), _ptr(self.inst_item), self.NIc, self.cnt(1), _ptr(self.inst_cat), st)
@@ -181,7 +195,7 @@ class NamlEngine(_Base):
                       x_is_ptr=False):
         P, D = self.P, self.D
         xp = x if x_is_ptr else _ptr(x)
-        call("lego_linear_fwd", xp, D, _ptr(P[prefix + "additive_attention.encoder.0.weight"]), D,
+        self.k("additive_fwd_" + prefix[:4], "lego_linear_fwd", xp, D, _ptr(P[prefix + "additive_attention.encoder.0.weight"]), D,
              _ptr(P[prefix + "additive_attention.encoder.0.bias"]), _ptr(t), A, rows_cap, rows_dyn, A, D, 2,
              None, None, None, None, st)
         call("lego_additive_pool_fwd", _ptr(t), A, xp, D, _ptr(P[prefix + "additive_attention.encoder.2.weight"]),
@@ -211,20 +225,20 @@ class NamlEngine(_Base):
         keep = 1.0 / (1.0 - self.p_conv) if (training and self.p_conv > 0) else 1.0
         w1 = _ptr(P["item_op.additive_attention.encoder.0.weight"])
         # token rows: dY = relu'(.)*keep * (dY + dpre.W1); column sums -> conv bias grad
-        call("lego_linear_bwd_data", _ptr(self.Tt), A, w1, D, _ptr(self.dY), D, self.Rc, self.cnt(0), A, D, 1,
+        self.k("additive_bwd_data", "lego_linear_bwd_data", _ptr(self.Tt), A, w1, D, _ptr(self.dY), D, self.Rc, self.cnt(0), A, D, 1,
              _ptr(self.Y), D, keep, None, None, _ptr(G["item_op.cnn.bias"]), None, None, st)
         # category rows: dY += dpre.W1; column sums -> item linear bias grad
         call("lego_linear_bwd_data", _ptr(self.Tt), A, w1, D, _ptr(self.dY), D, self.NIc, self.cnt(1), A, D, 1,
              None, 0, 1.0, None, None, _ptr(G["item_op.linear.bias"]), self.cnt(0), self.cnt(0), st)
         # conv weight / data gradients
         self.dwt.zero_()
-        call("lego_conv3_bwd_weight", _ptr(self.dY), D, _ptr(self.H), D, _ptr(self.rowinfo), _ptr(self.dwt),
+        self.k("conv3_bwd_weight", "lego_conv3_bwd_weight", _ptr(self.dY), D, _ptr(self.H), D, _ptr(self.rowinfo), _ptr(self.dwt),
              self.Rc, self.cnt(0), D, D, st)
         call("lego_conv3_unpack_add", _ptr(self.dwt), _ptr(G["item_op.cnn.weight"]), D, D, st)
-        call("lego_conv3_bwd_data", _ptr(self.dY), D, _ptr(self.wt), _ptr(self.rowinfo), _ptr(self.dH), D,
+        self.k("conv3_bwd_data", "lego_conv3_bwd_data", _ptr(self.dY), D, _ptr(self.wt), _ptr(self.rowinfo), _ptr(self.dH), D,
              self.Rc, self.cnt(0), D, D, self.drop(self.p_proj, SITE_PROJ, training),
              _ptr(G["embedding_vocab_table.glove.linear.bias"]), st)
-        call("lego_linear_bwd_weight", _ptr(self.dH), D, _ptr(self.X), E0,
+        self.k("proj_bwd_weight", "lego_linear_bwd_weight", _ptr(self.dH), D, _ptr(self.X), E0,
              _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Rc, self.cnt(0), D, E0, None, None, st)
         # category branch: Linear weight grad, embedding grad (trainable 18 x D table)
         call("lego_linear_bwd_weight", _ptr(self.dY), D, _ptr(self.cat_emb), D, _ptr(G["item_op.linear.weight"]), D,
@@ -241,7 +255,7 @@ class NamlEngine(_Base):
              _ptr(seg_off), extra, n_cap, n_dyn, D, A, _ptr(gout), D, _ptr(wrow), dx_ptr, D,
              _ptr(G[prefix + "additive_attention.encoder.2.weight"]), _ptr(G[prefix + "additive_attention.encoder.0.bias"]), st)
         # dW1 += dpre^T . x   (x is still the forward activation)
-        call("lego_linear_bwd_weight", _ptr(t), A, x_ptr, D, _ptr(G[prefix + "additive_attention.encoder.0.weight"]), D,
+        self.k("additive_bwd_weight_" + prefix[:4], "lego_linear_bwd_weight", _ptr(t), A, x_ptr, D, _ptr(G[prefix + "additive_attention.encoder.0.weight"]), D,
              rows_cap, rows_dyn, A, D, None, None, st)
 
 

@@ -1,0 +1,130 @@
+"""One data-parallel training step of the hot path, all on device:
+
+    rows of this rank's shard -> negative sampling + history fetch (device) -> ragged forward ->
+    backward into ONE flat fp32 gradient buffer -> (N > 1) a single RCCL all-reduce of that buffer ->
+    fused Adam over the flat parameter buffer.
+
+Mirrors the reference loop `loss = legommender(batch); loss.backward(); optimizer.step();
+scheduler.step(); optimizer.zero_grad()` (trainer.py:190-204) and its Adam / linear-schedule set-up
+(base_lego.py:175-223).  The reference has no distributed layer; the sharding contract here is
+"N ranks x per-rank batch B  ==  one device with batch N*B" (CrossEntropy mean over equal shards, so the
+averaged per-rank gradients are the global-batch gradient).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import torch
+
+from ._lib import call
+from .engine import ItemTables, NamlEngine, NrmsEngine, _ptr, _stream
+
+
+class FlatParams:
+    """Trainable tensors as views into one flat fp32 buffer (+ matching grad / Adam-moment buffers)."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], frozen=(), device="cuda"):
+        self.names = [k for k in params if k not in frozen]
+        sizes = [params[k].numel() for k in self.names]
+        self.offsets, off = {}, 0
+        for k, n in zip(self.names, sizes):
+            self.offsets[k] = off
+            off += (n + 3) // 4 * 4                 # keep every tensor 16-B aligned inside the buffer
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros_like(self.flat)
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self.P: Dict[str, torch.Tensor] = {}
+        self.G: Dict[str, torch.Tensor] = {}
+        for k in params:
+            if k in frozen:
+                self.P[k] = params[k].to(device=device, dtype=torch.float32).contiguous()
+                continue
+            o, n = self.offsets[k], params[k].numel()
+            self.P[k] = self.flat[o:o + n].view(params[k].shape)
+            self.P[k].copy_(params[k])
+            self.G[k] = self.grad[o:o + n].view(params[k].shape)
+
+    def state_dict(self):
+        return {k: v.detach().clone() for k, v in self.P.items()}
+
+
+class DeviceData:
+    """Train rows + user tables resident in HBM (replaces the DataLoader worker pipeline,
+    loader/manager.py:374-381, loader/data_set.py:61-85, loader/resampler.py:139-259)."""
+
+    def __init__(self, world: dict, device, rank=0, world_size=1, seed=2023):
+        i32 = lambda a: torch.as_tensor(a).to(device=device, dtype=torch.int32).contiguous()
+        self.tables = ItemTables(world["title_tok"], world["title_len"], world["cat"], device)
+        self.user_hist, self.user_hist_len = i32(world["user_hist"]), i32(world["user_hist_len"])
+        self.neg_list, self.neg_len = i32(world["neg_list"]), i32(world["neg_len"])
+        self.neg_cap = self.neg_list.shape[1]
+        self.S = self.user_hist.shape[1]
+        self.n_items = self.tables.n_items
+        # one shared seeded permutation per epoch; rank r takes rows r::world
+        g = torch.Generator().manual_seed(seed)
+        perm = torch.randperm(len(world["row_user"]), generator=g)
+        mine = perm[rank::world_size]
+        self.row_user = i32(world["row_user"])[mine.to(device)].contiguous()
+        self.row_item = i32(world["row_item"])[mine.to(device)].contiguous()
+        self.n_rows = self.row_user.numel()
+
+
+class TrainStep:
+    def __init__(self, kind: str, params: Dict[str, torch.Tensor], data: DeviceData, B: int, K: int = 4,
+                 lr: float = 1e-3, total_steps: int = 0, warmup: int = 0, seed: int = 2023, heads: int = 8,
+                 glove: bool = True, process_group=None, world_size: int = 1, dropout: bool = True):
+        dev = data.tables.title_tok.device
+        self.data, self.B, self.C, self.K = data, B, K + 1, K
+        frozen = ("embedding_vocab_table.glove.embedding.weight",) if "embedding_vocab_table.glove.embedding.weight" in params else ()
+        self.fp = FlatParams(params, frozen, dev)
+        pd = 0.1 if dropout else 0.0
+        if kind == "naml":
+            self.engine = NamlEngine(self.fp.P, data.tables, B, self.C, data.S, seed=seed, p_proj=pd, p_conv=pd)
+        elif kind == "nrms":
+            self.engine = NrmsEngine(self.fp.P, data.tables, B, self.C, data.S, heads=heads, glove=glove, seed=seed,
+                                     p_proj=pd, p_att=pd)
+        else:
+            raise ValueError(f"unknown model kind {kind!r} (the HIP path covers naml and nrms)")
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.cand = torch.zeros(B, self.C, **i32)
+        self.hist = torch.zeros(B, data.S, **i32)
+        self.hist_len = torch.zeros(B, **i32)
+        self.lr, self.total_steps, self.warmup = lr, total_steps, warmup
+        self.seed, self.step_idx = seed, 0
+        self.pg, self.world = process_group, world_size
+        self.counter_sum = torch.zeros(8, dtype=torch.int64, device=dev)
+
+    def lr_at(self, step: int) -> float:
+        """HF get_linear_schedule_with_warmup (base_lego.py:211-223); total_steps == 0 -> constant lr."""
+        if self.total_steps <= 0:
+            return self.lr
+        if step < self.warmup:
+            return self.lr * step / max(1, self.warmup)
+        return self.lr * max(0.0, (self.total_steps - step) / max(1, self.total_steps - self.warmup))
+
+    def sample_batch(self):
+        d, B = self.data, self.B
+        start = (self.step_idx * B) % max(1, d.n_rows - B + 1)
+        st = _stream()
+        ru, ri = _ptr(d.row_user, start), _ptr(d.row_item, start)
+        call("lego_sample_negatives", ru, ri, _ptr(d.neg_list), _ptr(d.neg_len), d.neg_cap, B, self.K, d.n_items,
+             self.seed, self.step_idx, _ptr(self.cand), st)
+        call("lego_gather_history", ru, _ptr(d.user_hist), _ptr(d.user_hist_len), B, d.S, _ptr(self.hist),
+             _ptr(self.hist_len), st)
+
+    def step(self):
+        """sample -> forward -> backward -> all-reduce -> Adam.  Returns the device loss tensor (no sync)."""
+        self.sample_batch()
+        self.fp.grad.zero_()
+        _, loss = self.engine.forward(self.cand, self.hist, self.hist_len, training=True)
+        self.engine.backward(self.fp.G)
+        if self.world > 1:
+            torch.distributed.all_reduce(self.fp.grad, group=self.pg)      # one RCCL all-reduce per step
+        self.step_idx += 1
+        call("lego_adam_step", _ptr(self.fp.flat), _ptr(self.fp.grad), _ptr(self.fp.m), _ptr(self.fp.v),
+             self.fp.numel, self.lr_at(self.step_idx - 1), 0.9, 0.999, 1e-8, self.step_idx, 1.0 / self.world, _stream())
+        self.counter_sum += self.engine.counters
+        return loss

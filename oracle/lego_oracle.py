@@ -242,6 +242,40 @@ def loss_and_grads(kind, P_np, tables, cand, hist, hist_len, heads=8, glove=True
     return logits.detach().numpy(), float(loss), g
 
 
+def naml_train_step_cpu(P, opt, title_tok, cat, cand, hist, hist_len, p_drop=0.1):
+    """One TRAINING step of the reference's CPU path (`--cuda -1`), dense layout, dropout on:
+    forward (model/legommender.py:219-263 with Dropout at loader/embedding_hub.py:96 and
+    model/operators/cnn_operator.py:57), loss.backward(), Adam step (trainer.py:193-203).
+    `P` holds torch tensors (requires_grad on the trainable ones), `opt` a torch.optim.Adam over them.
+    Used as the `cpu_baseline` ("port") of bench.py and by tests; returns the loss value."""
+    ids, B, C, S = _item_ids(cand, hist)
+    tok = title_tok[ids]
+    mask = (tok > UNSET).long()
+    emb = F.linear(F.embedding(tok * mask, P["embedding_vocab_table.glove.embedding.weight"]),
+                   P["embedding_vocab_table.glove.linear.weight"], P["embedding_vocab_table.glove.linear.bias"])
+    emb = F.dropout(emb, p_drop, training=True) * mask.unsqueeze(-1).to(emb.dtype)
+    cat_emb = F.embedding(cat[ids], P["embedding_vocab_table.category.weight"]).unsqueeze(1)
+    y = F.conv1d(emb.permute(0, 2, 1), P["item_op.cnn.weight"], P["item_op.cnn.bias"], padding="same")
+    y = F.dropout(torch.relu(y.permute(0, 2, 1)) * mask.unsqueeze(-1).to(emb.dtype), p_drop, training=True)
+    c = F.linear(cat_emb, P["item_op.linear.weight"], P["item_op.linear.bias"])
+    out = torch.cat([y, c], dim=1)
+    m2 = torch.cat([mask, torch.ones_like(mask[:, :1])], dim=1)
+    items = additive_attention(out, m2, P["item_op.additive_attention.encoder.0.weight"],
+                               P["item_op.additive_attention.encoder.0.bias"],
+                               P["item_op.additive_attention.encoder.2.weight"])
+    D = items.shape[-1]
+    hmask = (torch.arange(S)[None, :] < hist_len[:, None]).long()
+    user = additive_attention(items[B * C:].view(B, S, D), hmask,
+                              P["user_op.additive_attention.encoder.0.weight"],
+                              P["user_op.additive_attention.encoder.0.bias"],
+                              P["user_op.additive_attention.encoder.2.weight"])
+    loss = ce_label0(dot_scores(user, items[: B * C].view(B, C, D)))
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    return float(loss.detach())
+
+
 # --------------------------------------------------------------------------- a13
 def linear_schedule_factor(step, total, warmup=0):
     """transformers.get_linear_schedule_with_warmup lambda (base_lego.py:211-223)."""
