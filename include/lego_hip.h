@@ -126,6 +126,15 @@ int lego_dot_ce_bwd(const float* user, int ldu, const float* items, int ldi, con
                     int B, int C, int D, float gscale /*dloss * 1/B*/, float* guser, int ldgu,
                     float* gitems, int ldgi, void* stream);
 
+/* DotPredictor.predict on already-expanded (user, item) pairs, as the plug-in interface passes them
+ * (model/legommender.py:275-283): out[r] = sum_d u[r,d]*it[r,d], and its backward. */
+int lego_rowdot_fwd(const float* u, int ldu, const float* it, int ldi, int n, int D, float* out, void* stream);
+int lego_rowdot_bwd(const float* u, int ldu, const float* it, int ldi, const float* g, int n, int D,
+                    float* gu, int ldgu, float* gi, int ldgi, void* stream);
+/* g = ref > 0 ? g*scale : 0 -- backward of ReLU/mask/Dropout of CNNOperator (cnn_operator.py:55-57) given the
+ * stored output `ref`, for callers outside the fused GEMM epilogue (operator-level API) */
+int lego_relu_bwd(float* g, int ldg, const float* ref, int ldr, int rows, int width, float scale, void* stream);
+
 /* ---- a8: nn.MultiheadAttention core of AttentionOperator (model/operators/attention_operator.py:49-55)
  * over ragged segments: per (segment, head) softmax(q k^T / sqrt(hd)) v with all keys of the segment
  * live (pads are not rows).  qkv rows are [q | k | v] (3*D) from lego_linear_fwd with in_proj. */

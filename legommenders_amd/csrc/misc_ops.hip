@@ -425,6 +425,36 @@ __global__ __launch_bounds__(256) void dot_ce_bwd_kernel(const float* __restrict
     }
 }
 
+// row-wise dot product of two [n,D] matrices and its backward (DotPredictor.predict on pre-expanded pairs)
+__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float* __restrict__ u, int ldu, const float* __restrict__ it, int ldi,
+                                                         int n, int D, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const float s = dot_row(u + (size_t)r * ldu, it + (size_t)r * ldi, D, lane);
+    if (lane == 0) out[r] = s;
+}
+__global__ void rowdot_bwd_kernel(const float* __restrict__ u, int ldu, const float* __restrict__ it, int ldi,
+                                  const float* __restrict__ g, int n, int D, float* __restrict__ gu, int ldgu,
+                                  float* __restrict__ gi, int ldgi) {
+    const long long total = (long long)n * D;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(e / D), c = (int)(e - (long long)r * D);
+        const float gr = g[r];
+        gu[(size_t)r * ldgu + c] = gr * it[(size_t)r * ldi + c];
+        gi[(size_t)r * ldgi + c] = gr * u[(size_t)r * ldu + c];
+    }
+}
+// g = ref > 0 ? g * scale : 0   (backward of ReLU -> mask -> dropout when y = ref is the stored output)
+__global__ void relu_bwd_kernel(float* __restrict__ g, int ldg, const float* __restrict__ ref, int ldr, int rows, int width, float scale) {
+    const long long total = (long long)rows * width;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(e / width), c = (int)(e - (long long)r * width);
+        const float v = g[(size_t)r * ldg + c];
+        g[(size_t)r * ldg + c] = ref[(size_t)r * ldr + c] > 0.f ? v * scale : 0.f;
+    }
+}
+
 // ------------------------------------------------------------------ Adam
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long long n, float step_size, float beta1, float beta2, float eps, float inv_sqrt_bc2, float gscale) {
@@ -616,6 +646,28 @@ extern "C" int lego_dot_ce_bwd(const float* user, int ldu, const float* items, i
     hipLaunchKernelGGL(dot_ce_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, user, ldu, items, ldi, scores, B, C, D, gscale,
                        guser, ldgu, gitems, ldgi);
     return check_launch("lego_dot_ce_bwd");
+}
+
+extern "C" int lego_rowdot_fwd(const float* u, int ldu, const float* it, int ldi, int n, int D, float* out, void* stream) {
+    LEGO_REQUIRE((D & 3) == 0 && D <= 256 * kMaxChunks, "lego_rowdot_fwd: D=%d unsupported", D);
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(rowdot_fwd_kernel, dim3((n + 3) / 4), dim3(256), 0, ST, u, ldu, it, ldi, n, D, out);
+    return check_launch("lego_rowdot_fwd");
+}
+extern "C" int lego_rowdot_bwd(const float* u, int ldu, const float* it, int ldi, const float* g, int n, int D,
+                               float* gu, int ldgu, float* gi, int ldgi, void* stream) {
+    if (n <= 0) return 0;
+    const long long total = (long long)n * D;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(rowdot_bwd_kernel, dim3(blocks), dim3(256), 0, ST, u, ldu, it, ldi, g, n, D, gu, ldgu, gi, ldgi);
+    return check_launch("lego_rowdot_bwd");
+}
+extern "C" int lego_relu_bwd(float* g, int ldg, const float* ref, int ldr, int rows, int width, float scale, void* stream) {
+    if (rows <= 0) return 0;
+    const long long total = (long long)rows * width;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks), dim3(256), 0, ST, g, ldg, ref, ldr, rows, width, scale);
+    return check_launch("lego_relu_bwd");
 }
 
 extern "C" int lego_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
