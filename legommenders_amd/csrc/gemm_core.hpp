@@ -96,13 +96,15 @@ template <int BM, int BN, int WM, int WN>
 struct TileCfg {
     static constexpr int kBM = BM, kBN = BN, kWM = WM, kWN = WN;
     static constexpr int kTM = BM / (WM * 32), kTN = BN / (WN * 32);
-    static_assert(WM * WN == 4, "256-thread workgroups");
+    static constexpr int kThreads = WM * WN * 64;
+    static_assert(WM * WN == 4 || WM * WN == 8, "256- or 512-thread workgroups");
     static_assert(kTM >= 1 && kTN >= 1, "wave tile");
 };
 
-template <bool MC, int ROWS>
+template <bool MC, int ROWS, int NT = 256>
 struct Stage {             // global -> registers -> LDS staging of one operand tile
-    static constexpr int kN = ROWS / 32;              // float4 per thread
+    static constexpr int kN = ROWS * 8 / NT;          // float4 per thread (ROWS x BK floats over NT threads)
+    static_assert(kN >= 1, "tile too small for the workgroup");
     static constexpr int kLdsFloats = MC ? BK * ROWS : ROWS * KC_LD;
 };
 
@@ -114,10 +116,10 @@ struct GemmDims {
 };
 
 template <class Cfg, bool A_MC, bool B_MC, class ALoad, class BLoad, class Epi>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmDims dims, ALoad la, BLoad lb, Epi epi) {
-    constexpr int BM = Cfg::kBM, BN = Cfg::kBN, TM = Cfg::kTM, TN = Cfg::kTN;
-    using SA = Stage<A_MC, BM>;
-    using SB = Stage<B_MC, BN>;
+__global__ __launch_bounds__(Cfg::kThreads) void gemm_kernel(GemmDims dims, ALoad la, BLoad lb, Epi epi) {
+    constexpr int BM = Cfg::kBM, BN = Cfg::kBN, TM = Cfg::kTM, TN = Cfg::kTN, NT = Cfg::kThreads, RS = NT / 8;
+    using SA = Stage<A_MC, BM, NT>;
+    using SB = Stage<B_MC, BN, NT>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const As0 = smem;
     float* const Bs0 = smem + 2 * SA::kLdsFloats;
@@ -157,17 +159,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmDims dims, ALoad la, B
     typename BLoad::Row rb[SB::kN];
     if constexpr (!A_MC) {
 #pragma unroll
-        for (int j = 0; j < SA::kN; ++j) ra[j] = la.row(m0 + (tid >> 3) + 32 * j);
+        for (int j = 0; j < SA::kN; ++j) ra[j] = la.row(m0 + (tid >> 3) + RS * j);
     }
     if constexpr (!B_MC) {
 #pragma unroll
-        for (int j = 0; j < SB::kN; ++j) rb[j] = lb.row(n0 + (tid >> 3) + 32 * j);
+        for (int j = 0; j < SB::kN; ++j) rb[j] = lb.row(n0 + (tid >> 3) + RS * j);
     }
 
     f32x4 sa[SA::kN], sb[SB::kN];
     auto fetch = [&](int k0) {
         if constexpr (A_MC) {
-            constexpr int PER = BM / 4, STEP = 256 / PER;
+            constexpr int PER = BM / 4, STEP = NT / PER;
 #pragma unroll
             for (int j = 0; j < SA::kN; ++j) sa[j] = la.get(k0 + tid / PER + STEP * j, m0 + (tid % PER) * 4);
         } else {
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmDims dims, ALoad la, B
             for (int j = 0; j < SA::kN; ++j) sa[j] = la.get(ra[j], k0 + (tid & 7) * 4);
         }
         if constexpr (B_MC) {
-            constexpr int PER = BN / 4, STEP = 256 / PER;
+            constexpr int PER = BN / 4, STEP = NT / PER;
 #pragma unroll
             for (int j = 0; j < SB::kN; ++j) sb[j] = lb.get(k0 + tid / PER + STEP * j, n0 + (tid % PER) * 4);
         } else {
@@ -185,24 +187,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmDims dims, ALoad la, B
     };
     auto commit = [&](float* A_, float* B_) {
         if constexpr (A_MC) {
-            constexpr int PER = BM / 4, STEP = 256 / PER;
+            constexpr int PER = BM / 4, STEP = NT / PER;
 #pragma unroll
             for (int j = 0; j < SA::kN; ++j)
                 *reinterpret_cast<f32x4*>(A_ + (tid / PER + STEP * j) * BM + (tid % PER) * 4) = sa[j];
         } else {
 #pragma unroll
             for (int j = 0; j < SA::kN; ++j)
-                *reinterpret_cast<f32x4*>(A_ + ((tid >> 3) + 32 * j) * KC_LD + (tid & 7) * 4) = sa[j];
+                *reinterpret_cast<f32x4*>(A_ + ((tid >> 3) + RS * j) * KC_LD + (tid & 7) * 4) = sa[j];
         }
         if constexpr (B_MC) {
-            constexpr int PER = BN / 4, STEP = 256 / PER;
+            constexpr int PER = BN / 4, STEP = NT / PER;
 #pragma unroll
             for (int j = 0; j < SB::kN; ++j)
                 *reinterpret_cast<f32x4*>(B_ + (tid / PER + STEP * j) * BN + (tid % PER) * 4) = sb[j];
         } else {
 #pragma unroll
             for (int j = 0; j < SB::kN; ++j)
-                *reinterpret_cast<f32x4*>(B_ + ((tid >> 3) + 32 * j) * KC_LD + (tid & 7) * 4) = sb[j];
+                *reinterpret_cast<f32x4*>(B_ + ((tid >> 3) + RS * j) * KC_LD + (tid & 7) * 4) = sb[j];
         }
     };
 
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmDims dims, ALoad la, B
 
 template <class Cfg, bool A_MC, bool B_MC>
 constexpr size_t gemm_lds_bytes() {
-    return 2 * (Stage<A_MC, Cfg::kBM>::kLdsFloats + Stage<B_MC, Cfg::kBN>::kLdsFloats) * sizeof(float);
+    return 2 * (Stage<A_MC, Cfg::kBM, Cfg::kThreads>::kLdsFloats + Stage<B_MC, Cfg::kBN, Cfg::kThreads>::kLdsFloats) * sizeof(float);
 }
 
 }  // namespace lego

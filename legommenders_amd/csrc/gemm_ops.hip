@@ -92,11 +92,11 @@ static int launch(const GemmDims& d, const AL& a, const BL& b, const Epi& e, int
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL(k, dim3(tiles_m, tiles_n, gz), dim3(256), lds, st, d, a, b, e);
+    hipLaunchKernelGGL(k, dim3(tiles_m, tiles_n, gz), dim3(Cfg::kThreads), lds, st, d, a, b, e);
     return check_launch(what);
 }
 
-using C128x128 = TileCfg<128, 128, 2, 2>;
+using C128x128 = TileCfg<128, 128, 4, 2>;     // 8 waves, each 32 x 64: +5-20 % over 4 waves of 64 x 64 (scratch/gemm_variants.py)
 using C128x64 = TileCfg<128, 64, 4, 1>;
 using C64x128 = TileCfg<64, 128, 1, 4>;
 using C64x64 = TileCfg<64, 64, 2, 2>;
@@ -105,6 +105,10 @@ using C64x64 = TileCfg<64, 64, 2, 2>;
 template <bool B_MC, class AL, class BL>
 static int launch_rows(const GemmDims& d, const AL& a, const BL& b, const Epi& e, hipStream_t st, const char* what) {
     const int tm = (d.M + 127) / 128;
+    if (tm * ((d.N + 127) / 128) < 128) {         // few row tiles (user / category side): 64-row tiles fill more CUs
+        if (d.N > 64) return launch<C64x128, false, B_MC>(d, a, b, e, (d.M + 63) / 64, (d.N + 127) / 128, 1, st, what);
+        return launch<C64x64, false, B_MC>(d, a, b, e, (d.M + 63) / 64, (d.N + 63) / 64, 1, st, what);
+    }
     if (d.N > 64) return launch<C128x128, false, B_MC>(d, a, b, e, tm, (d.N + 127) / 128, 1, st, what);
     return launch<C128x64, false, B_MC>(d, a, b, e, tm, (d.N + 63) / 64, 1, st, what);
 }
@@ -121,10 +125,10 @@ static int launch_tn(const GemmDims& d, const AL& a, const BL& b, const Epi& e, 
 }
 
 static int pick_split(int rows_cap, int M, int N, int taps) {
-    // enough (tile x split) blocks to cover the 256 CUs about twice; at least 128 reduction rows per block
+    // (tile x split) blocks fill the 256 CUs twice but never spill into a third round; >= 128 reduction rows per block
     const int bm = M > 64 ? 128 : 64, bn = N > 64 ? 128 : 64;
     const int tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * taps;
-    int s = (512 + tiles - 1) / tiles;
+    int s = 512 / tiles;
     const int max_s = (rows_cap + 127) / 128;
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
@@ -230,4 +234,26 @@ extern "C" int lego_conv3_bwd_weight(const float* gy, int ldg, const float* h, i
     Epi e = make_epi(dwt, Din);
     e.atomic = 1; e.tap_stride = (size_t)Dout * Din;
     return launch_tn(d, a, b, e, 3, (hipStream_t)stream, "lego_conv3_bwd_weight");
+}
+
+
+// ---- internal tuning hook (not part of the public ABI): plain NT product with a selectable tile config
+extern "C" int lego_debug_gemm_nt(int variant, const float* x, const float* W, const float* bias, float* out,
+                                  int M, int N, int K, void* stream) {
+    GemmDims d{M, N, K, nullptr, nullptr, 1};
+    KcRows a{x, K, M, K, nullptr};
+    KcRows b{W, K, N, K, nullptr};
+    Epi e = make_epi(out, N);
+    e.bias = bias;
+    hipStream_t st = (hipStream_t)stream;
+    switch (variant) {
+        case 0: return launch<TileCfg<128, 128, 2, 2>, false, false>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, 1, st, "dbg0");
+        case 1: return launch<TileCfg<128, 128, 2, 4>, false, false>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, 1, st, "dbg1");
+        case 2: return launch<TileCfg<256, 128, 4, 2>, false, false>(d, a, b, e, (M + 255) / 256, (N + 127) / 128, 1, st, "dbg2");
+        case 3: return launch<TileCfg<128, 256, 2, 4>, false, false>(d, a, b, e, (M + 127) / 128, (N + 255) / 256, 1, st, "dbg3");
+        case 4: return launch<TileCfg<64, 128, 1, 4>, false, false>(d, a, b, e, (M + 63) / 64, (N + 127) / 128, 1, st, "dbg4");
+        case 5: return launch<TileCfg<128, 128, 4, 2>, false, false>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, 1, st, "dbg5");
+        case 6: return launch<TileCfg<64, 256, 1, 4>, false, false>(d, a, b, e, (M + 63) / 64, (N + 255) / 256, 1, st, "dbg6");
+        default: return set_error("lego_debug_gemm_nt: unknown variant %d", variant);
+    }
 }

@@ -249,26 +249,30 @@ __device__ __forceinline__ float dot_row(const float* __restrict__ a, const floa
     return wave_sum(s);
 }
 
+// One 256-thread workgroup per segment; the four waves take rows l = w, w+4, ... so 4 rows of the segment
+// are in flight at once (a 31-row item segment = 8 dependent row steps per wave instead of 31), partial
+// sums meet in LDS.  Row reductions are wave-shuffle sums (dot_row).
 __global__ __launch_bounds__(256) void additive_pool_fwd_kernel(
     const float* __restrict__ t, int ldt, const float* __restrict__ x, int ldx, const float* __restrict__ w2,
     const int* __restrict__ seg_off, const int* __restrict__ rowinfo, const int* __restrict__ extra_off_dyn,
     int n_cap, const int* __restrict__ n_dyn, int D, int A, float* __restrict__ out, int ldo, float* __restrict__ wrow) {
+    __shared__ float red_acc[4][kMaxChunks * 256];
+    __shared__ float red_s[4];
     const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x;
     if (i >= n) return;
-    const int beg = seg_off[i], end = seg_off[i + 1];
+    const int beg = seg_off[i], len = seg_off[i + 1] - beg;
     const int extra = extra_off_dyn != nullptr ? *extra_off_dyn + i : -1;
-    const int cnt = (end - beg) + (extra >= 0 ? 1 : 0);
+    const int cnt = len + (extra >= 0 ? 1 : 0);
     f32x4 acc[kMaxChunks];
 #pragma unroll
     for (int j = 0; j < kMaxChunks; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float stash[kMaxSegRows / 64] = {0.f, 0.f, 0.f, 0.f};
-    float s = 0.f;
-    for (int l = 0; l < cnt; ++l) {
-        const int row = (l < end - beg) ? beg + l : extra;
+    float stash = 0.f, s = 0.f;
+    for (int l = wave, it = 0; l < cnt; l += 4, ++it) {
+        const int row = l < len ? beg + l : extra;
         const float a = dot_row(t + (size_t)row * ldt, w2, A, lane);
-        const bool live = (l < end - beg && rowinfo != nullptr) ? (rowinfo[row] & RI_LIVE) != 0 : true;
+        const bool live = (l < len && rowinfo != nullptr) ? (rowinfo[row] & RI_LIVE) != 0 : true;
         const float e = live ? expf(a) : 0.f;
         s += e;
 #pragma unroll
@@ -276,22 +280,20 @@ __global__ __launch_bounds__(256) void additive_pool_fwd_kernel(
             const int c = 4 * lane + 256 * j;
             if (c < D) acc[j] += e * *reinterpret_cast<const f32x4*>(x + (size_t)row * ldx + c);
         }
-        if ((l & 63) == lane) {
-            const int k = l >> 6;
-            if (k == 0) stash[0] = e; else if (k == 1) stash[1] = e; else if (k == 2) stash[2] = e; else stash[3] = e;
-        }
+        if (it == lane) stash = e;
     }
-    const float inv = 1.f / (s + kEps);
 #pragma unroll
     for (int j = 0; j < kMaxChunks; ++j) {
         const int c = 4 * lane + 256 * j;
-        if (c < D) *reinterpret_cast<f32x4*>(out + (size_t)i * ldo + c) = acc[j] * inv;
+        if (c < D) *reinterpret_cast<f32x4*>(&red_acc[wave][c]) = acc[j];
     }
-#pragma unroll
-    for (int k = 0; k < kMaxSegRows / 64; ++k) {
-        const int l = lane + 64 * k;
-        if (l < cnt) wrow[(l < end - beg) ? beg + l : extra] = stash[k] * inv;
-    }
+    if (lane == 0) red_s[wave] = s;
+    __syncthreads();
+    const float inv = 1.f / ((red_s[0] + red_s[1]) + (red_s[2] + red_s[3]) + kEps);
+    for (int c = threadIdx.x; c < D; c += 256)
+        out[(size_t)i * ldo + c] = ((red_acc[0][c] + red_acc[1][c]) + (red_acc[2][c] + red_acc[3][c])) * inv;
+    const int l = wave + 4 * lane;                       // the row this lane stashed
+    if (l < cnt) wrow[l < len ? beg + l : extra] = stash * inv;
 }
 
 __global__ __launch_bounds__(256) void additive_pool_bwd_kernel(
@@ -300,6 +302,7 @@ __global__ __launch_bounds__(256) void additive_pool_bwd_kernel(
     int D, int A, const float* __restrict__ gout, int ldgo, const float* __restrict__ wrow,
     float* __restrict__ dx, int lddx, float* gw2, float* gb1) {
     __shared__ float red[2][4][kMaxChunks * 256];
+    __shared__ float red_s[2][4];
     const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 aw2[kMaxChunks], ab1[kMaxChunks], w2v[kMaxChunks];
@@ -310,27 +313,25 @@ __global__ __launch_bounds__(256) void additive_pool_bwd_kernel(
         const int c = 4 * lane + 256 * j;
         w2v[j] = c < A ? *reinterpret_cast<const f32x4*>(w2 + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
-        const int beg = seg_off[i], end = seg_off[i + 1];
+    int par = 0;
+    for (int i = blockIdx.x; i < n; i += gridDim.x, par ^= 1) {
+        const int beg = seg_off[i], len = seg_off[i + 1] - beg;
         const int extra = extra_off_dyn != nullptr ? *extra_off_dyn + i : -1;
-        const int cnt = (end - beg) + (extra >= 0 ? 1 : 0);
+        const int cnt = len + (extra >= 0 ? 1 : 0);
         const float* go = gout + (size_t)i * ldgo;
-        float stash[kMaxSegRows / 64] = {0.f, 0.f, 0.f, 0.f};
-        float sdw = 0.f;
-        for (int l = 0; l < cnt; ++l) {
-            const int row = (l < end - beg) ? beg + l : extra;
+        float stash = 0.f, sdw = 0.f;
+        for (int l = wave, it = 0; l < cnt; l += 4, ++it) {
+            const int row = l < len ? beg + l : extra;
             const float dw = dot_row(go, x + (size_t)row * ldx, D, lane);
             sdw += wrow[row] * dw;
-            if ((l & 63) == lane) {
-                const int k = l >> 6;
-                if (k == 0) stash[0] = dw; else if (k == 1) stash[1] = dw; else if (k == 2) stash[2] = dw; else stash[3] = dw;
-            }
+            if (it == lane) stash = dw;
         }
-        for (int l = 0; l < cnt; ++l) {
-            const int row = (l < end - beg) ? beg + l : extra;
-            const int k = l >> 6;
-            const float mine = k == 0 ? stash[0] : k == 1 ? stash[1] : k == 2 ? stash[2] : stash[3];
-            const float dw = __shfl(mine, l & 63, 64);
+        if (lane == 0) red_s[par][wave] = sdw;
+        __syncthreads();
+        sdw = (red_s[par][0] + red_s[par][1]) + (red_s[par][2] + red_s[par][3]);
+        for (int l = wave, it = 0; l < cnt; l += 4, ++it) {
+            const int row = l < len ? beg + l : extra;
+            const float dw = __shfl(stash, it, 64);
             const float w = wrow[row];
             const float da = w * (dw - sdw);
 #pragma unroll
@@ -613,7 +614,7 @@ extern "C" int lego_additive_pool_fwd(const float* t, int ldt, const float* x, i
                  "lego_additive_pool_fwd: D=%d A=%d must be multiples of 4 and <= %d", D, A, 256 * kMaxChunks);
     LEGO_REQUIRE((ldt & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0, "lego_additive_pool_fwd: strides must be multiples of 4");
     if (n_cap <= 0) return 0;
-    hipLaunchKernelGGL(additive_pool_fwd_kernel, dim3((n_cap + 3) / 4), dim3(256), 0, ST, t, ldt, x, ldx, w2, seg_off, rowinfo,
+    hipLaunchKernelGGL(additive_pool_fwd_kernel, dim3(n_cap), dim3(256), 0, ST, t, ldt, x, ldx, w2, seg_off, rowinfo,
                        extra_off_dyn, n_cap, n_dyn, D, A, out, ldo, wrow);
     return check_launch("lego_additive_pool_fwd");
 }
@@ -625,8 +626,8 @@ extern "C" int lego_additive_pool_bwd(float* t_dpre, int ldt, const float* x, in
     LEGO_REQUIRE((D & 3) == 0 && (A & 3) == 0 && D <= 256 * kMaxChunks && A <= 256 * kMaxChunks,
                  "lego_additive_pool_bwd: D=%d A=%d must be multiples of 4 and <= %d", D, A, 256 * kMaxChunks);
     if (n_cap <= 0) return 0;
-    int blocks = (n_cap + 3) / 4;
-    if (blocks > 512) blocks = 512;
+    int blocks = n_cap;
+    if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(additive_pool_bwd_kernel, dim3(blocks), dim3(256), 0, ST, t_dpre, ldt, x, ldx, w2, seg_off, extra_off_dyn,
                        n_cap, n_dyn, D, A, gout, ldgo, wrow, dx, lddx, gw2, gb1);
     return check_launch("lego_additive_pool_bwd");

@@ -1,0 +1,28 @@
+import sys, os, ctypes, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from legommenders_amd import _lib
+L = _lib.lib()
+P, I = ctypes.c_void_p, ctypes.c_int
+L.lego_debug_gemm_nt.argtypes = [I, P, P, P, P, I, I, I, P]
+L.lego_debug_gemm_nt.restype = I
+dev = torch.device('cuda:0')
+def bench(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+names = {0: "128x128 4w(2x2)", 1: "128x128 8w(2x4)", 2: "256x128 8w(4x2)", 3: "128x256 8w(2x4)", 4: "64x128 4w(1x4)", 5: "128x128 8w(4x2)", 6: "64x256 4w(1x4)"}
+for (M, N, Kd) in [(26368, 256, 768), (32768, 256, 768), (65536, 256, 768), (26368, 256, 256), (1536, 256, 256)]:
+    x = torch.randn(M, Kd, device=dev); W = torch.randn(N, Kd, device=dev) * 0.05; b = torch.randn(N, device=dev)
+    ref = x @ W.T + b
+    for v in range(7):
+        y = torch.zeros(M, N, device=dev)
+        def run():
+            rc = L.lego_debug_gemm_nt(v, x.data_ptr(), W.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, Kd, None)
+            assert rc == 0, L.lego_last_error()
+        ms = bench(run)
+        err = (y - ref).abs().max().item() / ref.abs().max().item()
+        print(f"M={M} K={Kd} v{v} {names[v]:18s}: {ms*1e3:8.1f} us {2*M*N*Kd/ms/1e9:7.1f} TF/s  relerr {err:.1e}")
