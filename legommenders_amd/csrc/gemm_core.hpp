@@ -262,32 +262,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_kernel(GemmDims dims, ALoa
     }
 
     // epilogue: lane holds column (li) x rows {(v&3) + 8*(v>>2) + 4*lh} of each 32x32 sub-tile
-    float csum[TN];
-#pragma unroll
-    for (int b = 0; b < TN; ++b) csum[b] = 0.f;
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int c = n0 + (wn * TN + b) * 32 + li;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int r0 = m0 + (wm * TM + a) * 32 + 8 * g + 4 * lh;
-                float v[4] = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
-                if (c < N && r0 < M) {
-                    epi.apply4(r0, c, v);
-                    csum[b] += (v[0] + v[1]) + (v[2] + v[3]);
-                }
-            }
-        }
-    if (epi.colsum != nullptr) {
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int c = n0 + (wn * TN + b) * 32 + li;
-            const float s = csum[b] + __shfl_xor(csum[b], 32, 64);
-            if (lh == 0 && c < N) atomicAdd(epi.colsum + c, s);
-        }
-    }
+    epi.template run<TM, TN>(acc, m0 + wm * TM * 32, n0 + wn * TN * 32, li, lh);
 }
 
 template <class Cfg, bool A_MC, bool B_MC>

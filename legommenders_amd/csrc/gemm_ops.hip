@@ -23,55 +23,100 @@ int check_launch(const char* what) {
 }
 const char* last_error() { return g_err; }
 
-// One run-time configurable epilogue (the k-loop dominates; the branches here are noise).
-struct Epi {
+// Epilogue of every product.  The per-element memory traffic (live bits, previous C for accumulation,
+// ReLU reference, atomics) is selected at COMPILE time so that each (sub-tile, row group) issues all of its
+// loads back to back before the first use -- with run-time flags the loads sat behind branches and were
+// serialised at L2 latency (measured: the accumulate + ReLU-backward product ran at half the plain rate).
+// Cheap per-column things (bias, activation kind, dropout on/off, column sums) stay run-time.
+struct EpiArgs {
     float* C; int ldc;
     const float* bias;        // [N] or null
     int act;                  // 0 none, 1 relu, 2 tanh
-    const int* rowinfo;       // null or live-bit source (indexed by absolute row)
+    const int* rowinfo;       // live-bit source (indexed by absolute row), kind ROWINFO
     Dropout drop;             // p == 0: off
     int drop_cols;            // column count of the dropout counter space
-    int accumulate;           // add the previous C value
     const float* relu_ref; int ld_ref; float relu_scale;   // backward of ReLU(+dropout): ref>0 ? x*scale : 0
-    int atomic;               // split-K: atomicAdd into C
     float* colsum;            // += column sums of the stored values (bias gradients)
     size_t tap_stride;        // C offset per tap (TN conv weight gradient)
     const int* row_off_dyn;   // device row offset of C / rowinfo / relu_ref rows
     int M, N, row_off;
+};
 
+template <bool ROWINFO, bool ACCUM, bool RELUREF, bool ATOMIC>
+struct EpiT : EpiArgs {
     __device__ __forceinline__ void setup(int M_, int N_, int tap) {
         M = M_; N = N_;
         row_off = row_off_dyn != nullptr ? *row_off_dyn : 0;
         C += (size_t)tap * tap_stride;
     }
-    __device__ __forceinline__ void apply4(int r0, int c, float (&v)[4]) {
-        const float b = bias != nullptr ? bias[c] : 0.f;
-        float ds[4];
-        dropout_scale4(drop, r0 + row_off, c, drop_cols, ds);
+    template <int TM, int TN>
+    __device__ __forceinline__ void run(f32x16 (&acc)[TM][TN], int m_base, int n_base, int li, int lh) {
+        int col[TN], colc[TN];
+        float bcol[TN], csum[TN];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = r0 + i;
-            if (r >= M) { v[i] = 0.f; continue; }
-            const int ra = r + row_off;
-            float x = v[i] + b;
-            if (act == 1) x = fmaxf(x, 0.f);
-            else if (act == 2) x = tanhf(x);
-            if (rowinfo != nullptr && !(rowinfo[ra] & RI_LIVE)) x = 0.f;
-            x *= ds[i];
-            const size_t o = (size_t)ra * ldc + c;
-            if (accumulate) x += C[o];
-            if (relu_ref != nullptr) x = relu_ref[(size_t)ra * ld_ref + c] > 0.f ? x * relu_scale : 0.f;
-            if (atomic) atomicAdd(C + o, x); else C[o] = x;
-            v[i] = x;
+        for (int b = 0; b < TN; ++b) {
+            col[b] = n_base + b * 32 + li;
+            colc[b] = min(col[b], N - 1);
+            bcol[b] = bias != nullptr ? bias[colc[b]] : 0.f;
+            csum[b] = 0.f;
+        }
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r0 = m_base + a * 32 + 8 * g + 4 * lh;
+                if (r0 >= M) continue;                       // wave-half uniform; rows below are clamped, stores guarded
+                int ra[4];
+                bool live[4];
+                float old[TN][4], ref[TN][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {                // every load of this group is issued before the first use
+                    ra[i] = min(r0 + i, M - 1) + row_off;
+                    live[i] = ROWINFO ? (rowinfo[ra[i]] & RI_LIVE) != 0 : true;
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        old[b][i] = ACCUM ? C[(size_t)ra[i] * ldc + colc[b]] : 0.f;
+                        ref[b][i] = RELUREF ? relu_ref[(size_t)ra[i] * ld_ref + colc[b]] : 1.f;
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    float ds[4];
+                    dropout_scale4(drop, r0 + row_off, col[b], drop_cols, ds);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float x = acc[a][b][4 * g + i] + bcol[b];
+                        if (act == 1) x = fmaxf(x, 0.f);
+                        else if (act == 2) x = tanhf(x);
+                        if (ROWINFO && !live[i]) x = 0.f;
+                        x *= ds[i];
+                        if (ACCUM) x += old[b][i];
+                        if (RELUREF) x = ref[b][i] > 0.f ? x * relu_scale : 0.f;
+                        if (r0 + i < M && col[b] < N) {
+                            float* dst = C + (size_t)ra[i] * ldc + col[b];
+                            if (ATOMIC) atomicAdd(dst, x); else *dst = x;
+                            csum[b] += x;
+                        }
+                    }
+                }
+            }
+        if (colsum != nullptr) {
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const float s = csum[b] + __shfl_xor(csum[b], 32, 64);
+                if (lh == 0 && col[b] < N) atomicAdd(colsum + col[b], s);
+            }
         }
     }
 };
 
+using Epi = EpiArgs;      // host-side view; the kernel is instantiated with one EpiT<...> kind
+
 static Epi make_epi(float* C, int ldc) {
     Epi e;
     e.C = C; e.ldc = ldc; e.bias = nullptr; e.act = 0; e.rowinfo = nullptr;
-    e.drop = Dropout{0.f, 0u, 0u, 0u}; e.drop_cols = 1; e.accumulate = 0;
-    e.relu_ref = nullptr; e.ld_ref = 0; e.relu_scale = 1.f; e.atomic = 0; e.colsum = nullptr;
+    e.drop = Dropout{0.f, 0u, 0u, 0u}; e.drop_cols = 1;
+    e.relu_ref = nullptr; e.ld_ref = 0; e.relu_scale = 1.f; e.colsum = nullptr;
     e.tap_stride = 0; e.row_off_dyn = nullptr; e.M = e.N = e.row_off = 0;
     return e;
 }
@@ -82,10 +127,12 @@ static void set_drop(Epi& e, const lego_dropout* d, int cols) {
     }
 }
 
-template <class Cfg, bool A_MC, bool B_MC, class AL, class BL>
-static int launch(const GemmDims& d, const AL& a, const BL& b, const Epi& e, int tiles_m, int tiles_n, int gz,
+template <class Cfg, bool A_MC, bool B_MC, class EK, class AL, class BL>
+static int launch(const GemmDims& d, const AL& a, const BL& b, const Epi& e0, int tiles_m, int tiles_n, int gz,
                   hipStream_t st, const char* what) {
-    auto k = gemm_kernel<Cfg, A_MC, B_MC, AL, BL, Epi>;
+    EK e;
+    static_cast<EpiArgs&>(e) = e0;
+    auto k = gemm_kernel<Cfg, A_MC, B_MC, AL, BL, EK>;
     constexpr size_t lds = gemm_lds_bytes<Cfg, A_MC, B_MC>();
     static bool attr_done = false;
     if (!attr_done) {
@@ -102,33 +149,41 @@ using C64x128 = TileCfg<64, 128, 1, 4>;
 using C64x64 = TileCfg<64, 64, 2, 2>;
 
 // NT / NN: rows x N output, BM = 128, BN by N
-template <bool B_MC, class AL, class BL>
+using EpiPlain = EpiT<false, false, false, false>;
+using EpiLive = EpiT<true, false, false, false>;
+using EpiAccum = EpiT<false, true, false, false>;
+using EpiAccumRelu = EpiT<false, true, true, false>;
+using EpiAtomic = EpiT<false, false, false, true>;
+
+template <bool B_MC, class EK, class AL, class BL>
 static int launch_rows(const GemmDims& d, const AL& a, const BL& b, const Epi& e, hipStream_t st, const char* what) {
     const int tm = (d.M + 127) / 128;
     if (tm * ((d.N + 127) / 128) < 128) {         // few row tiles (user / category side): 64-row tiles fill more CUs
-        if (d.N > 64) return launch<C64x128, false, B_MC>(d, a, b, e, (d.M + 63) / 64, (d.N + 127) / 128, 1, st, what);
-        return launch<C64x64, false, B_MC>(d, a, b, e, (d.M + 63) / 64, (d.N + 63) / 64, 1, st, what);
+        if (d.N > 64) return launch<C64x128, false, B_MC, EK>(d, a, b, e, (d.M + 63) / 64, (d.N + 127) / 128, 1, st, what);
+        return launch<C64x64, false, B_MC, EK>(d, a, b, e, (d.M + 63) / 64, (d.N + 63) / 64, 1, st, what);
     }
-    if (d.N > 64) return launch<C128x128, false, B_MC>(d, a, b, e, tm, (d.N + 127) / 128, 1, st, what);
-    return launch<C128x64, false, B_MC>(d, a, b, e, tm, (d.N + 63) / 64, 1, st, what);
+    if (d.N > 64) return launch<C128x128, false, B_MC, EK>(d, a, b, e, tm, (d.N + 127) / 128, 1, st, what);
+    return launch<C128x64, false, B_MC, EK>(d, a, b, e, tm, (d.N + 63) / 64, 1, st, what);
 }
-// TN: small [M,N] output, reduction over the (ragged) rows split along gridDim.z
+// TN: small [M,N] output, reduction over the (ragged) rows split along gridDim.z.  64 x 64 tiles: the
+// atomic traffic of the split-K epilogue is (#splits x M x N x 4 B), so small tiles (= fewer splits for
+// the same number of blocks) beat 128 x 128 by 1.6x here (scratch/tn_variants.py: 44 vs 70 us).
+// (the three-tap conv product keeps 128 x 128: its shifted-row loader pays a rowinfo look-up per row and tile)
 template <class AL, class BL>
 static int launch_tn(const GemmDims& d, const AL& a, const BL& b, const Epi& e, int taps, hipStream_t st, const char* what) {
     const int gz = taps * d.split_k;
-    if (d.M > 64) {
-        if (d.N > 64) return launch<C128x128, true, true>(d, a, b, e, (d.M + 127) / 128, (d.N + 127) / 128, gz, st, what);
-        return launch<C128x64, true, true>(d, a, b, e, (d.M + 127) / 128, (d.N + 63) / 64, gz, st, what);
-    }
-    if (d.N > 64) return launch<C64x128, true, true>(d, a, b, e, (d.M + 63) / 64, (d.N + 127) / 128, gz, st, what);
-    return launch<C64x64, true, true>(d, a, b, e, (d.M + 63) / 64, (d.N + 63) / 64, gz, st, what);
+    if (taps > 1 && d.M > 64 && d.N > 64)
+        return launch<C128x128, true, true, EpiAtomic>(d, a, b, e, (d.M + 127) / 128, (d.N + 127) / 128, gz, st, what);
+    return launch<C64x64, true, true, EpiAtomic>(d, a, b, e, (d.M + 63) / 64, (d.N + 63) / 64, gz, st, what);
 }
 
 static int pick_split(int rows_cap, int M, int N, int taps) {
-    // (tile x split) blocks fill the 256 CUs twice but never spill into a third round; >= 128 reduction rows per block
-    const int bm = M > 64 ? 128 : 64, bn = N > 64 ? 128 : 64;
-    const int tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * taps;
-    int s = 512 / tiles;
+    // plain products: ~1024 blocks of 64 x 64 (4 x 32 KB of LDS per CU); conv: two rounds of 128 x 128 blocks;
+    // at least 128 reduction rows per block
+    const bool big = taps > 1 && M > 64 && N > 64;
+    const int t = big ? 128 : 64;
+    const int tiles = ((M + t - 1) / t) * ((N + t - 1) / t) * taps;
+    int s = (big ? 512 : 1024) / tiles;
     const int max_s = (rows_cap + 127) / 128;
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
@@ -156,7 +211,8 @@ extern "C" int lego_linear_fwd(const float* x, int ldx, const float* W, int ldw,
     Epi e = make_epi(out, ldo);
     e.bias = bias; e.act = act; e.rowinfo = rowinfo; e.row_off_dyn = out_row_off_dyn;
     set_drop(e, drop, N);
-    return launch_rows<false>(d, a, b, e, (hipStream_t)stream, "lego_linear_fwd");
+    if (rowinfo != nullptr) return launch_rows<false, EpiLive>(d, a, b, e, (hipStream_t)stream, "lego_linear_fwd");
+    return launch_rows<false, EpiPlain>(d, a, b, e, (hipStream_t)stream, "lego_linear_fwd");
 }
 
 extern "C" int lego_linear_bwd_data(const float* g, int ldg, const float* W, int ldw, float* dx, int lddx,
@@ -171,10 +227,20 @@ extern "C" int lego_linear_bwd_data(const float* g, int ldg, const float* W, int
     KcRows a{g, ldg, M_cap, N, g_row_off_dyn};
     McRows b{W, ldw, K, N, nullptr};
     Epi e = make_epi(dx, lddx);
-    e.accumulate = accumulate; e.relu_ref = relu_ref; e.ld_ref = ld_ref; e.relu_scale = relu_scale;
+    e.relu_ref = relu_ref; e.ld_ref = ld_ref; e.relu_scale = relu_scale;
     e.rowinfo = rowinfo; e.colsum = colsum; e.row_off_dyn = dx_row_off_dyn;
     set_drop(e, drop, K);
-    return launch_rows<true>(d, a, b, e, (hipStream_t)stream, "lego_linear_bwd_data");
+    hipStream_t st = (hipStream_t)stream;
+    if (rowinfo != nullptr) {
+        LEGO_REQUIRE(!accumulate && relu_ref == nullptr, "lego_linear_bwd_data: rowinfo cannot be combined with accumulate / relu_ref");
+        return launch_rows<true, EpiLive>(d, a, b, e, st, "lego_linear_bwd_data");
+    }
+    if (relu_ref != nullptr) {
+        LEGO_REQUIRE(accumulate, "lego_linear_bwd_data: relu_ref requires accumulate=1");
+        return launch_rows<true, EpiAccumRelu>(d, a, b, e, st, "lego_linear_bwd_data");
+    }
+    if (accumulate) return launch_rows<true, EpiAccum>(d, a, b, e, st, "lego_linear_bwd_data");
+    return launch_rows<true, EpiPlain>(d, a, b, e, st, "lego_linear_bwd_data");
 }
 
 extern "C" int lego_linear_bwd_weight(const float* g, int ldg, const float* x, int ldx, float* dW, int lddw,
@@ -187,7 +253,6 @@ extern "C" int lego_linear_bwd_weight(const float* g, int ldg, const float* x, i
     McRows a{g, ldg, N, M_cap, g_row_off_dyn};
     McRows b{x, ldx, K, M_cap, x_row_off_dyn};
     Epi e = make_epi(dW, lddw);
-    e.atomic = 1;
     return launch_tn(d, a, b, e, 1, (hipStream_t)stream, "lego_linear_bwd_weight");
 }
 
@@ -204,7 +269,7 @@ extern "C" int lego_conv3_fwd(const float* h, int ldh, const float* wt, const fl
     Epi e = make_epi(y, ldy);
     e.bias = bias; e.act = 1; e.rowinfo = rowinfo;
     set_drop(e, drop, Dout);
-    return launch_rows<false>(d, a, b, e, (hipStream_t)stream, "lego_conv3_fwd");
+    return launch_rows<false, EpiLive>(d, a, b, e, (hipStream_t)stream, "lego_conv3_fwd");
 }
 
 extern "C" int lego_conv3_bwd_data(const float* gy, int ldg, const float* wt, const int32_t* rowinfo,
@@ -220,7 +285,7 @@ extern "C" int lego_conv3_bwd_data(const float* gy, int ldg, const float* wt, co
     Epi e = make_epi(dh, lddh);
     e.rowinfo = rowinfo; e.colsum = colsum;
     set_drop(e, drop_in, Din);
-    return launch_rows<true>(d, a, b, e, (hipStream_t)stream, "lego_conv3_bwd_data");
+    return launch_rows<true, EpiLive>(d, a, b, e, (hipStream_t)stream, "lego_conv3_bwd_data");
 }
 
 extern "C" int lego_conv3_bwd_weight(const float* gy, int ldg, const float* h, int ldh, const int32_t* rowinfo,
@@ -232,7 +297,7 @@ extern "C" int lego_conv3_bwd_weight(const float* gy, int ldg, const float* h, i
     McRows a{gy, ldg, Dout, R_cap, nullptr};
     McShiftRows b{h, ldh, Din, R_cap, rowinfo, 0};
     Epi e = make_epi(dwt, Din);
-    e.atomic = 1; e.tap_stride = (size_t)Dout * Din;
+    e.tap_stride = (size_t)Dout * Din;
     return launch_tn(d, a, b, e, 3, (hipStream_t)stream, "lego_conv3_bwd_weight");
 }
 
@@ -247,13 +312,30 @@ extern "C" int lego_debug_gemm_nt(int variant, const float* x, const float* W, c
     e.bias = bias;
     hipStream_t st = (hipStream_t)stream;
     switch (variant) {
-        case 0: return launch<TileCfg<128, 128, 2, 2>, false, false>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, 1, st, "dbg0");
-        case 1: return launch<TileCfg<128, 128, 2, 4>, false, false>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, 1, st, "dbg1");
-        case 2: return launch<TileCfg<256, 128, 4, 2>, false, false>(d, a, b, e, (M + 255) / 256, (N + 127) / 128, 1, st, "dbg2");
-        case 3: return launch<TileCfg<128, 256, 2, 4>, false, false>(d, a, b, e, (M + 127) / 128, (N + 255) / 256, 1, st, "dbg3");
-        case 4: return launch<TileCfg<64, 128, 1, 4>, false, false>(d, a, b, e, (M + 63) / 64, (N + 127) / 128, 1, st, "dbg4");
-        case 5: return launch<TileCfg<128, 128, 4, 2>, false, false>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, 1, st, "dbg5");
-        case 6: return launch<TileCfg<64, 256, 1, 4>, false, false>(d, a, b, e, (M + 63) / 64, (N + 255) / 256, 1, st, "dbg6");
+        case 0: return launch<TileCfg<128, 128, 2, 2>, false, false, EpiPlain>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, 1, st, "dbg0");
+        case 1: return launch<TileCfg<128, 128, 2, 4>, false, false, EpiPlain>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, 1, st, "dbg1");
+        case 2: return launch<TileCfg<256, 128, 4, 2>, false, false, EpiPlain>(d, a, b, e, (M + 255) / 256, (N + 127) / 128, 1, st, "dbg2");
+        case 3: return launch<TileCfg<128, 256, 2, 4>, false, false, EpiPlain>(d, a, b, e, (M + 127) / 128, (N + 255) / 256, 1, st, "dbg3");
+        case 4: return launch<TileCfg<64, 128, 1, 4>, false, false, EpiPlain>(d, a, b, e, (M + 63) / 64, (N + 127) / 128, 1, st, "dbg4");
+        case 5: return launch<TileCfg<128, 128, 4, 2>, false, false, EpiPlain>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, 1, st, "dbg5");
+        case 6: return launch<TileCfg<64, 256, 1, 4>, false, false, EpiPlain>(d, a, b, e, (M + 63) / 64, (N + 255) / 256, 1, st, "dbg6");
         default: return set_error("lego_debug_gemm_nt: unknown variant %d", variant);
+    }
+}
+
+extern "C" int lego_debug_gemm_tn(int variant, int split, const float* g, const float* x, float* dW,
+                                  int R, int N, int K, void* stream) {
+    GemmDims d{N, K, R, nullptr, nullptr, split};
+    McRows a{g, N, N, R, nullptr};
+    McRows b{x, K, K, R, nullptr};
+    Epi e = make_epi(dW, K);
+    hipStream_t st = (hipStream_t)stream;
+    switch (variant) {
+        case 0: return launch<TileCfg<128, 128, 4, 2>, true, true, EpiAtomic>(d, a, b, e, (N + 127) / 128, (K + 127) / 128, split, st, "tn0");
+        case 1: return launch<TileCfg<64, 64, 2, 2>, true, true, EpiAtomic>(d, a, b, e, (N + 63) / 64, (K + 63) / 64, split, st, "tn1");
+        case 2: return launch<TileCfg<128, 64, 4, 1>, true, true, EpiAtomic>(d, a, b, e, (N + 127) / 128, (K + 63) / 64, split, st, "tn2");
+        case 3: return launch<TileCfg<64, 128, 1, 4>, true, true, EpiAtomic>(d, a, b, e, (N + 63) / 64, (K + 127) / 128, split, st, "tn3");
+        case 4: return launch<TileCfg<128, 128, 2, 2>, true, true, EpiAtomic>(d, a, b, e, (N + 127) / 128, (K + 127) / 128, split, st, "tn4");
+        default: return set_error("lego_debug_gemm_tn: unknown variant %d", variant);
     }
 }

@@ -17,6 +17,7 @@ No torch op touches the data path; torch only owns the memory and the stream.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, Optional
 
 import torch
@@ -150,113 +151,157 @@ class NamlEngine(_Base):
         self.d_cat_emb = self._f(self.NIc, D)
         self.dwt = self._f(3, D, D)
 
+    # ------------------------------------------------------------------ streams
+    # Independent branches of the step run on side HIP streams so the small category / user-side kernels
+    # and the weight-gradient GEMMs fill the CUs the big token-row GEMMs leave idle in their last wave.
+    def _lanes(self):
+        if getattr(self, "_side", None) is None:
+            self._side = [torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)]
+            self._evs = [torch.cuda.Event() for _ in range(8)]
+        m = torch.cuda.current_stream()
+        if os.environ.get("LEGO_SERIAL") == "1":     # profiling aid: one stream, so per-kernel times do not overlap
+            return m, m, m
+        return m, self._side[0], self._side[1]
+
+    @staticmethod
+    def _sp(stream):
+        return ctypes.c_void_p(stream.cuda_stream)
+
+    def _fork(self, ev, src, *dst):
+        dst = [d for d in dst if d is not src]
+        if not dst:
+            return
+        ev.record(src)
+        for d in dst:
+            d.wait_event(ev)
+
+    def kk(self, stream, tag, name, *args):
+        """launch on `stream`; with timers on, bracket the launch with HIP events on that same stream"""
+        t = self.timers
+        if t is None or tag is None:
+            return call(name, *args, self._sp(stream))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        call(name, *args, self._sp(stream))
+        e1.record(stream)
+        t.setdefault(tag, []).append((e0, e1))
+
     # ------------------------------------------------------------------ forward
     def forward(self, cand, hist, hist_len, training=False, with_loss=True):
         P, B, C, S, D, A, E0 = self.P, self.B, self.C, self.S, self.D, self.A, self.E0
-        st = _stream()
+        m, sb, sc = self._lanes()
+        ev = self._evs
         _check(cand, torch.int32, "cand"); _check(hist, torch.int32, "hist"); _check(hist_len, torch.int32, "hist_len")
         self._training = training
-        call("lego_plan_batch", _ptr(cand), _ptr(hist), _ptr(hist_len), B, C, S,
-             _ptr(self.tb.title_tok), _ptr(self.tb.title_len), self.T,
-             _ptr(self.counters), _ptr(self.inst_item), _ptr(self.seg_off), _ptr(self.hist_off),
-             _ptr(self.rowinfo), _ptr(self.row_tok), st)
-        # k1: frozen GloVe row gather, then Transformation = Dropout(Linear(.)) (embedding_hub.py:95-96)
-        self.k("gather_rows", "lego_gather_rows", _ptr(P["embedding_vocab_table.glove.embedding.weight"]), E0, E0,
-             _ptr(self.row_tok), self.Rc, self.cnt(0), _ptr(self.X), E0, 0, st)
-        self.k("proj_fwd", "lego_linear_fwd", _ptr(self.X), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
-             _ptr(P["embedding_vocab_table.glove.linear.bias"]), _ptr(self.H), D, self.Rc, self.cnt(0), D, E0, 0,
-             _ptr(self.rowinfo), self.drop(self.p_proj, SITE_PROJ, training), None, None, st)
+        self.kk(m, None, "lego_plan_batch", _ptr(cand), _ptr(hist), _ptr(hist_len), B, C, S,
+                _ptr(self.tb.title_tok), _ptr(self.tb.title_len), self.T,
+                _ptr(self.counters), _ptr(self.inst_item), _ptr(self.seg_off), _ptr(self.hist_off),
+                _ptr(self.rowinfo), _ptr(self.row_tok))
+        self._fork(ev[0], m, sb)
+        # side stream: k2/k4 category embedding + Linear on the length-1 column (cnn_operator.py:58-60) -> Y rows R..R+NI
+        self.kk(sb, None, "lego_gather_i32", _ptr(self.tb.cat), _ptr(self.inst_item), self.NIc, self.cnt(1), _ptr(self.inst_cat))
+        self.kk(sb, None, "lego_gather_rows", _ptr(P["embedding_vocab_table.category.weight"]), D, D, _ptr(self.inst_cat),
+                self.NIc, self.cnt(1), _ptr(self.cat_emb), D, 0)
+        self.kk(sb, None, "lego_linear_fwd", _ptr(self.cat_emb), D, _ptr(P["item_op.linear.weight"]), D,
+                _ptr(P["item_op.linear.bias"]), _ptr(self.Y), D, self.NIc, self.cnt(1), D, D, 0,
+                None, None, None, self.cnt(0))
+        self.kk(sb, None, "lego_conv3_pack", _ptr(P["item_op.cnn.weight"]), _ptr(self.wt), D, D)
+        # main stream: k1 frozen GloVe row gather, then Transformation = Dropout(Linear(.)) (embedding_hub.py:95-96)
+        self.kk(m, "gather_rows", "lego_gather_rows", _ptr(P["embedding_vocab_table.glove.embedding.weight"]), E0, E0,
+                _ptr(self.row_tok), self.Rc, self.cnt(0), _ptr(self.X), E0, 0)
+        self.kk(m, "proj_fwd", "lego_linear_fwd", _ptr(self.X), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
+                _ptr(P["embedding_vocab_table.glove.linear.bias"]), _ptr(self.H), D, self.Rc, self.cnt(0), D, E0, 0,
+                _ptr(self.rowinfo), self.drop(self.p_proj, SITE_PROJ, training), None, None)
+        self._fork(ev[1], sb, m)                    # conv needs the packed weights; the pool needs the category rows
         # k3: conv + relu + mask + dropout (cnn_operator.py:54-57)
-        call("lego_conv3_pack", _ptr(P["item_op.cnn.weight"]), _ptr(self.wt), D, D, st)
-        self.k("conv3_fwd", "lego_conv3_fwd", _ptr(self.H), D, _ptr(self.wt), _ptr(P["item_op.cnn.bias"]), _ptr(self.rowinfo),
-             _ptr(self.Y), D, self.Rc, self.cnt(0), D, D, self.drop(self.p_conv, SITE_CONV, training), st)
-        # k2/k4: category embedding + Linear on the length-1 column (cnn_operator.py:58-60) -> Y rows R..R+NI
-        call("lego_gather_i32", _ptr(self.tb.cat), _ptr(self.inst_item), self.NIc, self.cnt(1), _ptr(self.inst_cat), st)
-        call("lego_gather_rows", _ptr(P["embedding_vocab_table.category.weight"]), D, D, _ptr(self.inst_cat),
-             self.NIc, self.cnt(1), _ptr(self.cat_emb), D, 0, st)
-        call("lego_linear_fwd", _ptr(self.cat_emb), D, _ptr(P["item_op.linear.weight"]), D,
-             _ptr(P["item_op.linear.bias"]), _ptr(self.Y), D, self.NIc, self.cnt(1), D, D, 0,
-             None, None, None, self.cnt(0), st)
+        self.kk(m, "conv3_fwd", "lego_conv3_fwd", _ptr(self.H), D, _ptr(self.wt), _ptr(P["item_op.cnn.bias"]), _ptr(self.rowinfo),
+                _ptr(self.Y), D, self.Rc, self.cnt(0), D, D, self.drop(self.p_conv, SITE_CONV, training))
         # k5: additive attention pool over [title tokens..., category] (attention.py:31-38)
-        self._additive_fwd("item_op.", self.Y, self.Ryc, self.cnt(2), self.Tt, A, self.seg_off, None, self.cnt(0),
-                           self.NIc, self.cnt(1), self.items, self.wrow, st)
+        self._additive_fwd(m, "item_op.", _ptr(self.Y), self.Ryc, self.cnt(2), self.Tt, A, self.seg_off, self.cnt(0),
+                           self.NIc, self.cnt(1), self.items, self.wrow)
         # k7: AdaOperator = additive pool over the clicked items of each user (ada_operator.py:31-34)
-        hist_items = _ptr(self.items, self.BC * D)
-        self._additive_fwd("user_op.", hist_items, B * S, self.cnt(3), self.Tu, self.Au, self.hist_off, None, None,
-                           B, None, self.user, self.wu, st, x_is_ptr=True)
+        self._additive_fwd(m, "user_op.", _ptr(self.items, self.BC * D), B * S, self.cnt(3), self.Tu, self.Au, self.hist_off,
+                           None, B, None, self.user, self.wu)
         # k11/k12: dot predictor + CE(label 0)
         self.loss.zero_()
-        call("lego_dot_ce_fwd", _ptr(self.user), D, _ptr(self.items), D, B, C, D, _ptr(self.scores),
-             _ptr(self.loss) if with_loss else None, st)
+        self.kk(m, None, "lego_dot_ce_fwd", _ptr(self.user), D, _ptr(self.items), D, B, C, D, _ptr(self.scores),
+                _ptr(self.loss) if with_loss else None)
         self.step += 1 if training else 0
         return self.scores, self.loss
 
-    def _additive_fwd(self, prefix, x, rows_cap, rows_dyn, t, A, seg_off, rowinfo, extra, n_cap, n_dyn, out, wrow, st,
-                      x_is_ptr=False):
+    def _additive_fwd(self, st, prefix, xp, rows_cap, rows_dyn, t, A, seg_off, extra, n_cap, n_dyn, out, wrow):
         P, D = self.P, self.D
-        xp = x if x_is_ptr else _ptr(x)
-        self.k("additive_fwd_" + prefix[:4], "lego_linear_fwd", xp, D, _ptr(P[prefix + "additive_attention.encoder.0.weight"]), D,
-             _ptr(P[prefix + "additive_attention.encoder.0.bias"]), _ptr(t), A, rows_cap, rows_dyn, A, D, 2,
-             None, None, None, None, st)
-        call("lego_additive_pool_fwd", _ptr(t), A, xp, D, _ptr(P[prefix + "additive_attention.encoder.2.weight"]),
-             _ptr(seg_off), _ptr(rowinfo), extra, n_cap, n_dyn, D, A, _ptr(out), D, _ptr(wrow), st)
+        self.kk(st, "additive_fwd_" + prefix[:4], "lego_linear_fwd", xp, D, _ptr(P[prefix + "additive_attention.encoder.0.weight"]), D,
+                _ptr(P[prefix + "additive_attention.encoder.0.bias"]), _ptr(t), A, rows_cap, rows_dyn, A, D, 2,
+                None, None, None, None)
+        self.kk(st, None, "lego_additive_pool_fwd", _ptr(t), A, xp, D, _ptr(P[prefix + "additive_attention.encoder.2.weight"]),
+                _ptr(seg_off), None, extra, n_cap, n_dyn, D, A, _ptr(out), D, _ptr(wrow))
 
     # ------------------------------------------------------------------ backward
     def backward(self, G: Dict[str, torch.Tensor], gloss: float = 1.0):
         """Accumulates d(loss)/d(param) into G (reference key names); call after forward(training...)."""
         P, B, C, S, D, A, E0 = self.P, self.B, self.C, self.S, self.D, self.A, self.E0
-        st = _stream()
+        m, sb, sc = self._lanes()
+        ev = self._evs
         training = self._training
         step_save = self.step
         if training:
             self.step -= 1          # regenerate the masks of the forward pass of this step
-        call("lego_dot_ce_bwd", _ptr(self.user), D, _ptr(self.items), D, _ptr(self.scores), B, C, D,
-             float(gloss) / B, _ptr(self.d_user), D, _ptr(self.d_items), D, st)
+        self._fork(ev[2], m, sb, sc)                 # everything enqueued so far (forward, grad zeroing) precedes the side work
+        self.kk(m, None, "lego_dot_ce_bwd", _ptr(self.user), D, _ptr(self.items), D, _ptr(self.scores), B, C, D,
+                float(gloss) / B, _ptr(self.d_user), D, _ptr(self.d_items), D)
         hist_items = _ptr(self.items, self.BC * D)
         d_hist_items = _ptr(self.d_items, self.BC * D)
-        self._additive_bwd("user_op.", G, hist_items, d_hist_items, B * S, self.cnt(3), self.Tu, self.Au, self.hist_off,
-                           None, B, None, self.d_user, self.wu, st)
-        # user-side dx += dpre . W1
-        call("lego_linear_bwd_data", _ptr(self.Tu), self.Au, _ptr(P["user_op.additive_attention.encoder.0.weight"]), D,
-             d_hist_items, D, B * S, self.cnt(3), self.Au, D, 1, None, 0, 1.0, None, None, None, None, None, st)
+        self._pool_bwd(m, "user_op.", G, hist_items, d_hist_items, self.Tu, self.Au, self.hist_off, None, B, None,
+                       self.d_user, self.wu)
+        self._fork(ev[3], m, sb)
+        # side: user dW1 += dpre^T . items      main: user-side dx += dpre . W1
+        self.kk(sb, "additive_bwd_weight_user", "lego_linear_bwd_weight", _ptr(self.Tu), self.Au, hist_items, D,
+                _ptr(G["user_op.additive_attention.encoder.0.weight"]), D, B * S, self.cnt(3), self.Au, D, None, None)
+        self.kk(m, None, "lego_linear_bwd_data", _ptr(self.Tu), self.Au, _ptr(P["user_op.additive_attention.encoder.0.weight"]), D,
+                d_hist_items, D, B * S, self.cnt(3), self.Au, D, 1, None, 0, 1.0, None, None, None, None, None)
         # item-side pool backward: dY direct part, dpre in place of T
-        self._additive_bwd("item_op.", G, _ptr(self.Y), _ptr(self.dY), self.Ryc, self.cnt(2), self.Tt, A, self.seg_off,
-                           self.cnt(0), self.NIc, self.cnt(1), self.d_items, self.wrow, st)
+        self._pool_bwd(m, "item_op.", G, _ptr(self.Y), _ptr(self.dY), self.Tt, A, self.seg_off, self.cnt(0), self.NIc,
+                       self.cnt(1), self.d_items, self.wrow)
+        self._fork(ev[4], m, sb, sc)
         keep = 1.0 / (1.0 - self.p_conv) if (training and self.p_conv > 0) else 1.0
         w1 = _ptr(P["item_op.additive_attention.encoder.0.weight"])
-        # token rows: dY = relu'(.)*keep * (dY + dpre.W1); column sums -> conv bias grad
-        self.k("additive_bwd_data", "lego_linear_bwd_data", _ptr(self.Tt), A, w1, D, _ptr(self.dY), D, self.Rc, self.cnt(0), A, D, 1,
-             _ptr(self.Y), D, keep, None, None, _ptr(G["item_op.cnn.bias"]), None, None, st)
-        # category rows: dY += dpre.W1; column sums -> item linear bias grad
-        call("lego_linear_bwd_data", _ptr(self.Tt), A, w1, D, _ptr(self.dY), D, self.NIc, self.cnt(1), A, D, 1,
-             None, 0, 1.0, None, None, _ptr(G["item_op.linear.bias"]), self.cnt(0), self.cnt(0), st)
-        # conv weight / data gradients
-        self.dwt.zero_()
-        self.k("conv3_bwd_weight", "lego_conv3_bwd_weight", _ptr(self.dY), D, _ptr(self.H), D, _ptr(self.rowinfo), _ptr(self.dwt),
-             self.Rc, self.cnt(0), D, D, st)
-        call("lego_conv3_unpack_add", _ptr(self.dwt), _ptr(G["item_op.cnn.weight"]), D, D, st)
-        self.k("conv3_bwd_data", "lego_conv3_bwd_data", _ptr(self.dY), D, _ptr(self.wt), _ptr(self.rowinfo), _ptr(self.dH), D,
-             self.Rc, self.cnt(0), D, D, self.drop(self.p_proj, SITE_PROJ, training),
-             _ptr(G["embedding_vocab_table.glove.linear.bias"]), st)
-        self.k("proj_bwd_weight", "lego_linear_bwd_weight", _ptr(self.dH), D, _ptr(self.X), E0,
-             _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Rc, self.cnt(0), D, E0, None, None, st)
-        # category branch: Linear weight grad, embedding grad (trainable 18 x D table)
-        call("lego_linear_bwd_weight", _ptr(self.dY), D, _ptr(self.cat_emb), D, _ptr(G["item_op.linear.weight"]), D,
-             self.NIc, self.cnt(1), D, D, self.cnt(0), None, st)
-        call("lego_linear_bwd_data", _ptr(self.dY), D, _ptr(P["item_op.linear.weight"]), D, _ptr(self.d_cat_emb), D,
-             self.NIc, self.cnt(1), D, D, 0, None, 0, 1.0, None, None, None, self.cnt(0), None, st)
-        call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.category.weight"]), D, D, _ptr(self.inst_cat),
-             self.NIc, self.cnt(1), _ptr(self.d_cat_emb), D, st)
+        # ---- side stream B: additive weight gradient + the whole category branch
+        self.kk(sb, "additive_bwd_weight_item", "lego_linear_bwd_weight", _ptr(self.Tt), A, _ptr(self.Y), D,
+                _ptr(G["item_op.additive_attention.encoder.0.weight"]), D, self.Ryc, self.cnt(2), A, D, None, None)
+        self.kk(sb, None, "lego_linear_bwd_data", _ptr(self.Tt), A, w1, D, _ptr(self.dY), D, self.NIc, self.cnt(1), A, D, 1,
+                None, 0, 1.0, None, None, _ptr(G["item_op.linear.bias"]), self.cnt(0), self.cnt(0))
+        self.kk(sb, None, "lego_linear_bwd_weight", _ptr(self.dY), D, _ptr(self.cat_emb), D, _ptr(G["item_op.linear.weight"]), D,
+                self.NIc, self.cnt(1), D, D, self.cnt(0), None)
+        self.kk(sb, None, "lego_linear_bwd_data", _ptr(self.dY), D, _ptr(P["item_op.linear.weight"]), D, _ptr(self.d_cat_emb), D,
+                self.NIc, self.cnt(1), D, D, 0, None, 0, 1.0, None, None, None, self.cnt(0), None)
+        self.kk(sb, None, "lego_scatter_add_rows", _ptr(G["embedding_vocab_table.category.weight"]), D, D, _ptr(self.inst_cat),
+                self.NIc, self.cnt(1), _ptr(self.d_cat_emb), D)
+        # ---- main: token rows: dY = relu'(.)*keep * (dY + dpre.W1); column sums -> conv bias grad
+        self.kk(m, "additive_bwd_data", "lego_linear_bwd_data", _ptr(self.Tt), A, w1, D, _ptr(self.dY), D, self.Rc, self.cnt(0), A, D, 1,
+                _ptr(self.Y), D, keep, None, None, _ptr(G["item_op.cnn.bias"]), None, None)
+        self._fork(ev[5], m, sc)
+        # ---- side stream C: conv weight gradient
+        with torch.cuda.stream(sc):
+            self.dwt.zero_()
+        self.kk(sc, "conv3_bwd_weight", "lego_conv3_bwd_weight", _ptr(self.dY), D, _ptr(self.H), D, _ptr(self.rowinfo), _ptr(self.dwt),
+                self.Rc, self.cnt(0), D, D)
+        self.kk(sc, None, "lego_conv3_unpack_add", _ptr(self.dwt), _ptr(G["item_op.cnn.weight"]), D, D)
+        # ---- main: conv data gradient -> projection weight gradient
+        self.kk(m, "conv3_bwd_data", "lego_conv3_bwd_data", _ptr(self.dY), D, _ptr(self.wt), _ptr(self.rowinfo), _ptr(self.dH), D,
+                self.Rc, self.cnt(0), D, D, self.drop(self.p_proj, SITE_PROJ, training),
+                _ptr(G["embedding_vocab_table.glove.linear.bias"]))
+        self.kk(m, "proj_bwd_weight", "lego_linear_bwd_weight", _ptr(self.dH), D, _ptr(self.X), E0,
+                _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Rc, self.cnt(0), D, E0, None, None)
+        self._fork(ev[6], sb, m)
+        self._fork(ev[7], sc, m)
         self.step = step_save
 
-    def _additive_bwd(self, prefix, G, x_ptr, dx_ptr, rows_cap, rows_dyn, t, A, seg_off, extra, n_cap, n_dyn, gout, wrow, st):
+    def _pool_bwd(self, st, prefix, G, x_ptr, dx_ptr, t, A, seg_off, extra, n_cap, n_dyn, gout, wrow):
         P, D = self.P, self.D
-        call("lego_additive_pool_bwd", _ptr(t), A, x_ptr, D, _ptr(P[prefix + "additive_attention.encoder.2.weight"]),
-             _ptr(seg_off), extra, n_cap, n_dyn, D, A, _ptr(gout), D, _ptr(wrow), dx_ptr, D,
-             _ptr(G[prefix + "additive_attention.encoder.2.weight"]), _ptr(G[prefix + "additive_attention.encoder.0.bias"]), st)
-        # dW1 += dpre^T . x   (x is still the forward activation)
-        self.k("additive_bwd_weight_" + prefix[:4], "lego_linear_bwd_weight", _ptr(t), A, x_ptr, D, _ptr(G[prefix + "additive_attention.encoder.0.weight"]), D,
-             rows_cap, rows_dyn, A, D, None, None, st)
+        self.kk(st, None, "lego_additive_pool_bwd", _ptr(t), A, x_ptr, D, _ptr(P[prefix + "additive_attention.encoder.2.weight"]),
+                _ptr(seg_off), extra, n_cap, n_dyn, D, A, _ptr(gout), D, _ptr(wrow), dx_ptr, D,
+                _ptr(G[prefix + "additive_attention.encoder.2.weight"]), _ptr(G[prefix + "additive_attention.encoder.0.bias"]))
 
 
 class NrmsEngine(_Base):
