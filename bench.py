@@ -45,6 +45,19 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic():
+    """HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, run separately --
+    counters cannot be read from inside this process); newest profiles/r*_traffic.json, else {}."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return {}
+    try:
+        return {k: v.get("hbm_bytes_per_launch") for k, v in json.load(open(files[-1]))["kernels"].items()}
+    except Exception:
+        return {}
+
+
 def cpu_baseline(world, B, D, steps):
     """Oracle port of the reference's `--cuda -1` NAML training step, timed on this host's cores."""
     import numpy as np
@@ -160,19 +173,20 @@ def main():
             kern[tag]["tflops"] = f / (kern[tag]["avg_ms"] * 1e-3) / 1e12
             kern[tag]["frac_of_f32_mfma_peak"] = kern[tag]["tflops"] / PEAK_F32_MFMA_TFLOPS
     roofline, roofline_gather = None, None
+    traffic = pmc_traffic()
     mf = [(v["avg_ms"], k) for k, v in kern.items() if "tflops" in v]
     if mf:
         _, dom = max(mf)
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(kern[dom]["tflops"], 3),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(kern[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(kern[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic.get(dom),
                     "avg_launch_ms": round(kern[dom]["avg_ms"], 5),
                     "algorithmic_flops_per_launch": flops[dom]}
     if "gather_rows" in kern and kern["gather_rows"]["avg_ms"] > 0:
         gbytes = rows_per_launch * E0 * 4 * 2 + rows_per_launch * 4     # row read + row write + index
         gbs = gbytes / (kern["gather_rows"]["avg_ms"] * 1e-3) / 1e9
         roofline_gather = {"kernel": "gather_rows", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
-                           "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                           "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic.get("gather_rows"),
                            "avg_launch_ms": round(kern["gather_rows"]["avg_ms"], 5),
                            "algorithmic_bytes_per_launch": gbytes,
                            "dense_reference_bytes_per_launch": B * 55 * 30 * 1200}
