@@ -526,7 +526,7 @@ extern "C" int lego_plan_batch(const int32_t* cand, const int32_t* hist, const i
                                const int32_t* title_tok, const int32_t* title_len, int T,
                                int32_t* counters, int32_t* inst_item, int32_t* seg_off, int32_t* hist_off,
                                int32_t* rowinfo, int32_t* row_tok, void* stream) {
-    LEGO_REQUIRE(B > 0 && C > 0 && S >= 0 && T > 0, "lego_plan_batch: bad sizes B=%d C=%d S=%d T=%d", B, C, S, T);
+    LEGO_REQUIRE(B > 0 && C >= 0 && S >= 0 && C + S > 0 && T > 0, "lego_plan_batch: bad sizes B=%d C=%d S=%d T=%d", B, C, S, T);
     LEGO_REQUIRE((long long)B * (C + S) < (1 << 23), "lego_plan_batch: too many item instances");
     hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, ST, cand, hist, hist_len, B, C, S, title_len,
                        counters, inst_item, seg_off, hist_off);

@@ -102,6 +102,38 @@ class _Base:
             return None
         return ctypes.byref(LegoDropout(p, self.seed, site + 16 * self.step))
 
+    # ------------------------------------------------------------------ evaluation caches
+    # ItemCacher / UserCacher of the reference (loader/cacher/item_cacher.py:51-97, user_cacher.py:63-97) encode
+    # every item once and every user once per evaluation; here each page is ONE ragged launch sequence.
+    def item_vectors(self, ids: torch.Tensor) -> torch.Tensor:
+        """engine built with B=1, S=0, C>=len(ids): vectors of the given item ids (eval mode)."""
+        n = ids.numel()
+        assert self.S == 0 and self.B == 1 and n <= self.C, "item_vectors needs an engine built as (B=1, C=page, S=0)"
+        cand = torch.zeros(self.C, dtype=torch.int32, device=self.dev)
+        cand[:n] = ids.to(self.dev, torch.int32)
+        dummy = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self._training = False
+        self._plan(cand, dummy, dummy)
+        self._forward_items(False)
+        return self.items[:n].clone()
+
+    def user_vectors(self, item_repr: torch.Tensor, hist: torch.Tensor, hist_len: torch.Tensor) -> torch.Tensor:
+        """engine built with C=0: user vectors from cached item vectors (legommender.py:153-157,202-214)."""
+        assert self.C == 0, "user_vectors needs an engine built with C=0"
+        n = hist.shape[0]
+        h = torch.zeros(self.B, self.S, dtype=torch.int32, device=self.dev)
+        hl = torch.zeros(self.B, dtype=torch.int32, device=self.dev)
+        h[:n] = hist.to(self.dev, torch.int32)
+        hl[:n] = hist_len.to(self.dev, torch.int32)
+        dummy = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self._training = False
+        self._plan(dummy, h, hl)
+        D = self.D
+        call("lego_gather_rows", _ptr(item_repr), D, D, _ptr(self.inst_item), self.NIc, self.cnt(1), _ptr(self.items), D, 0,
+             _stream())
+        self._forward_users(False)
+        return self.user[:n].clone()
+
     def grads_like(self):
         return {k: torch.zeros_like(v) for k, v in self.P.items() if v.dtype == torch.float32 and k not in self.frozen}
 
@@ -113,7 +145,7 @@ class NamlEngine(_Base):
 
     frozen = ("embedding_vocab_table.glove.embedding.weight",)
 
-    def __init__(self, params, tables, B, C=5, S=50, seed=2023, p_proj=0.1, p_conv=0.1):
+    def __init__(self, params, tables, B, C=5, S=50, seed=2023, p_proj=0.1, p_conv=0.1, token_rows=True):
         super().__init__(params, tables, B, C, S, seed)
         P = params
         self.E0 = P["embedding_vocab_table.glove.embedding.weight"].shape[1]
@@ -126,11 +158,11 @@ class NamlEngine(_Base):
             _check(v, torch.float32, k)
         if D % 32:
             raise _lib.LegoHipError(f"hidden size {D} must be a multiple of 32 for the conv implicit GEMM")
-        self.Rc = self.NIc * self.T
+        self.Rc = self.NIc * self.T if token_rows else 0     # token_rows=False: user-cache engine (item vectors are given)
         self.Ryc = self.Rc + self.NIc
         i32 = dict(dtype=torch.int32, device=self.dev)
-        self.rowinfo = torch.zeros(self.Rc, **i32)
-        self.row_tok = torch.zeros(self.Rc, **i32)
+        self.rowinfo = torch.zeros(max(self.Rc, self.NIc * self.T), **i32)     # the plan kernel always writes rowinfo/row_tok
+        self.row_tok = torch.zeros(max(self.Rc, self.NIc * self.T), **i32)
         self.inst_cat = torch.zeros(self.NIc, **i32)
         self.X = self._f(self.Rc, E0)
         self.H = self._f(self.Rc, D)
@@ -193,10 +225,28 @@ class NamlEngine(_Base):
         ev = self._evs
         _check(cand, torch.int32, "cand"); _check(hist, torch.int32, "hist"); _check(hist_len, torch.int32, "hist_len")
         self._training = training
-        self.kk(m, None, "lego_plan_batch", _ptr(cand), _ptr(hist), _ptr(hist_len), B, C, S,
+        self._plan(cand, hist, hist_len)
+        self._forward_items(training)
+        self._forward_users(training)
+        # k11/k12: dot predictor + CE(label 0)
+        self.loss.zero_()
+        self.kk(m, None, "lego_dot_ce_fwd", _ptr(self.user), D, _ptr(self.items), D, B, C, D, _ptr(self.scores),
+                _ptr(self.loss) if with_loss else None)
+        self.step += 1 if training else 0
+        return self.scores, self.loss
+
+    def _plan(self, cand, hist, hist_len):
+        m, _, _ = self._lanes()
+        self.kk(m, None, "lego_plan_batch", _ptr(cand), _ptr(hist), _ptr(hist_len), self.B, self.C, self.S,
                 _ptr(self.tb.title_tok), _ptr(self.tb.title_len), self.T,
                 _ptr(self.counters), _ptr(self.inst_item), _ptr(self.seg_off), _ptr(self.hist_off),
                 _ptr(self.rowinfo), _ptr(self.row_tok))
+
+    def _forward_items(self, training):
+        """item vectors of every planned instance -> self.items[0:NI]"""
+        P, D, A, E0 = self.P, self.D, self.A, self.E0
+        m, sb, sc = self._lanes()
+        ev = self._evs
         self._fork(ev[0], m, sb)
         # side stream: k2/k4 category embedding + Linear on the length-1 column (cnn_operator.py:58-60) -> Y rows R..R+NI
         self.kk(sb, None, "lego_gather_i32", _ptr(self.tb.cat), _ptr(self.inst_item), self.NIc, self.cnt(1), _ptr(self.inst_cat))
@@ -219,15 +269,12 @@ class NamlEngine(_Base):
         # k5: additive attention pool over [title tokens..., category] (attention.py:31-38)
         self._additive_fwd(m, "item_op.", _ptr(self.Y), self.Ryc, self.cnt(2), self.Tt, A, self.seg_off, self.cnt(0),
                            self.NIc, self.cnt(1), self.items, self.wrow)
-        # k7: AdaOperator = additive pool over the clicked items of each user (ada_operator.py:31-34)
-        self._additive_fwd(m, "user_op.", _ptr(self.items, self.BC * D), B * S, self.cnt(3), self.Tu, self.Au, self.hist_off,
-                           None, B, None, self.user, self.wu)
-        # k11/k12: dot predictor + CE(label 0)
-        self.loss.zero_()
-        self.kk(m, None, "lego_dot_ce_fwd", _ptr(self.user), D, _ptr(self.items), D, B, C, D, _ptr(self.scores),
-                _ptr(self.loss) if with_loss else None)
-        self.step += 1 if training else 0
-        return self.scores, self.loss
+
+    def _forward_users(self, training):
+        """k7: AdaOperator = additive pool over the clicked items of each user (ada_operator.py:31-34)"""
+        m, _, _ = self._lanes()
+        self._additive_fwd(m, "user_op.", _ptr(self.items, self.BC * self.D), self.B * self.S, self.cnt(3), self.Tu, self.Au,
+                           self.hist_off, None, self.B, None, self.user, self.wu)
 
     def _additive_fwd(self, st, prefix, xp, rows_cap, rows_dyn, t, A, seg_off, extra, n_cap, n_dyn, out, wrow):
         P, D = self.P, self.D
@@ -311,7 +358,8 @@ class NrmsEngine(_Base):
     `glove=True`: frozen GloVe + Linear(E0->D) token embedding; `glove=False`: trainable [V,D] table
     (config/embed/null.yaml, dense-gradient semantics)."""
 
-    def __init__(self, params, tables, B, C=5, S=50, heads=8, glove=False, seed=2023, p_proj=0.1, p_att=0.1):
+    def __init__(self, params, tables, B, C=5, S=50, heads=8, glove=False, seed=2023, p_proj=0.1, p_att=0.1,
+                 token_rows=True):
         super().__init__(params, tables, B, C, S, seed)
         P = params
         self.glove, self.heads = glove, heads
@@ -339,10 +387,10 @@ class NrmsEngine(_Base):
         seq[rows, tli + 2] = -2
         self.seq_tok = seq.contiguous()
         self.seq_len = (tables.title_len + 3).contiguous()
-        self.Rc = self.NIc * self.L
+        self.Rc = self.NIc * self.L if token_rows else 0
         i32 = dict(dtype=torch.int32, device=self.dev)
-        self.rowinfo = torch.zeros(self.Rc, **i32)
-        self.row_tok = torch.zeros(self.Rc, **i32)
+        self.rowinfo = torch.zeros(max(self.Rc, self.NIc * self.L), **i32)
+        self.row_tok = torch.zeros(max(self.Rc, self.NIc * self.L), **i32)
         self.idx_tok = torch.zeros(self.Rc, **i32)
         self.idx_spec = torch.zeros(self.Rc, **i32)
         self.idx_cat = torch.zeros(self.Rc, **i32)
@@ -418,10 +466,24 @@ class NrmsEngine(_Base):
         st = _stream()
         _check(cand, torch.int32, "cand"); _check(hist, torch.int32, "hist"); _check(hist_len, torch.int32, "hist_len")
         self._training = training
-        call("lego_plan_batch", _ptr(cand), _ptr(hist), _ptr(hist_len), B, C, S,
+        self._plan(cand, hist, hist_len)
+        self._forward_items(training)
+        self._forward_users(training)
+        self.loss.zero_()
+        call("lego_dot_ce_fwd", _ptr(self.user), D, _ptr(self.items), D, B, C, D, _ptr(self.scores),
+             _ptr(self.loss) if with_loss else None, st)
+        self.step += 1 if training else 0
+        return self.scores, self.loss
+
+    def _plan(self, cand, hist, hist_len):
+        call("lego_plan_batch", _ptr(cand), _ptr(hist), _ptr(hist_len), self.B, self.C, self.S,
              _ptr(self.seq_tok), _ptr(self.seq_len), self.L,
              _ptr(self.counters), _ptr(self.inst_item), _ptr(self.seg_off), _ptr(self.hist_off),
-             _ptr(self.rowinfo), _ptr(self.row_tok), st)
+             _ptr(self.rowinfo), _ptr(self.row_tok), _stream())
+
+    def _forward_items(self, training):
+        P, D = self.P, self.D
+        st = _stream()
         call("lego_nrms_decode_rows", _ptr(self.row_tok), self.Rc, self.cnt(0), _ptr(self.idx_tok), _ptr(self.idx_spec),
              _ptr(self.idx_cat), _ptr(self.tokinfo), st)
         if self.glove:
@@ -440,13 +502,10 @@ class NrmsEngine(_Base):
              self.Rc, self.cnt(0), _ptr(self.E), D, 1, st)
         self._att_fwd("item_op.", self.item_ws, _ptr(self.E), self.cnt(0), self.seg_off, self.NIc, self.cnt(1),
                       self.items, SITE_ITEM_ATT, training, st)
-        self._att_fwd("user_op.", self.user_ws, _ptr(self.items, self.BC * D), self.cnt(3), self.hist_off, B, None,
-                      self.user, SITE_USER_ATT, training, st)
-        self.loss.zero_()
-        call("lego_dot_ce_fwd", _ptr(self.user), D, _ptr(self.items), D, B, C, D, _ptr(self.scores),
-             _ptr(self.loss) if with_loss else None, st)
-        self.step += 1 if training else 0
-        return self.scores, self.loss
+
+    def _forward_users(self, training):
+        self._att_fwd("user_op.", self.user_ws, _ptr(self.items, self.BC * self.D), self.cnt(3), self.hist_off, self.B, None,
+                      self.user, SITE_USER_ATT, training, _stream())
 
     def backward(self, G, gloss: float = 1.0):
         P, B, C, S, D = self.P, self.B, self.C, self.S, self.D

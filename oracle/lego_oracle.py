@@ -221,6 +221,31 @@ def nrms_forward(P, title_tok, title_len, cat, cand, hist, hist_len, heads=8, gl
     return dot_scores(user, cand_v)
 
 
+def eval_scores(kind, P, title_tok, title_len, cat, user_hist, user_hist_len, rows_user, rows_item, heads=8, glove=True):
+    """The reference's fast-eval path: all-item cache (loader/cacher/item_cacher.py:51-97), all-user cache from
+    `item_repr[history]` (loader/cacher/user_cacher.py:63-97, model/legommender.py:153-157,202-214), then
+    score = <user_repr[u], item_repr[i]> per evaluation row (legommender.py:282)."""
+    n_items = title_tok.shape[0]
+    S = user_hist.shape[1]
+    if kind == "naml":
+        emb, mask = glove_project(title_tok, P["embedding_vocab_table.glove.embedding.weight"],
+                                  P["embedding_vocab_table.glove.linear.weight"], P["embedding_vocab_table.glove.linear.bias"])
+        cat_emb = F.embedding(cat, P["embedding_vocab_table.category.weight"]).unsqueeze(1)
+        item_repr = cnn_operator(emb, mask, cat_emb, P)
+    else:
+        t_ids, c_ids, s_ids, mask = concat_layout(title_tok, title_len, cat, use_sep=True)
+        item_repr = attention_operator(concat_embed(t_ids, c_ids, s_ids, P, glove), mask, P, "item_op.", heads)
+    hmask = (torch.arange(S)[None, :] < user_hist_len[:, None]).long()
+    clicks = item_repr[user_hist]                                   # pads are item 0, masked below
+    if kind == "naml":
+        user_repr = additive_attention(clicks, hmask, P["user_op.additive_attention.encoder.0.weight"],
+                                       P["user_op.additive_attention.encoder.0.bias"],
+                                       P["user_op.additive_attention.encoder.2.weight"])
+    else:
+        user_repr = attention_operator(clicks, hmask, P, "user_op.", heads)
+    return (user_repr[rows_user] * item_repr[rows_item]).sum(-1), item_repr, user_repr
+
+
 def loss_and_grads(kind, P_np, tables, cand, hist, hist_len, heads=8, glove=True, frozen=()):
     """Logits, loss and d(loss)/d(param) for every trainable tensor (dropout 0).  numpy in/out."""
     P = {}

@@ -278,3 +278,40 @@ def test_train_step_runs_and_updates():
         negs = w["neg_list"][users[b], : w["neg_len"][users[b]]].tolist()
         assert O.sample_negatives_semantics(cand[b].tolist(), negs, w["n_items"], K=4)
         assert cand[b, 0] == ts.data.row_item[start + b].item()
+
+
+@pytest.mark.parametrize("name", ["naml_glove_d64", "nrms_null_d64"])
+def test_eval_path_scores_and_metrics(name):
+    """Representation caches + id-gather + dot (the fast-eval path) against the oracle's restatement of the
+    reference caches; GAUC / MRR / NDCG@k equal to 3 decimals (the north-star bar) -- here to 1e-5."""
+    from legommenders_amd import metrics as PM
+    from legommenders_amd.evaluate import Evaluator
+    from legommenders_amd.train_step import DeviceData
+    from oracle import lego_oracle as O
+    dev = _dev()
+    meta, P, G, tables, batch, _, _ = load_model_fixture(name)
+    n_items, n_users = tables["title_tok"].shape[0], tables["user_hist"].shape[0]
+    rs = np.random.RandomState(3)
+    world = dict(title_tok=tables["title_tok"], title_len=tables["title_len"], cat=tables["cat"],
+                 user_hist=tables["user_hist"], user_hist_len=tables["user_hist_len"],
+                 neg_list=np.zeros((n_users, 4), dtype=np.int64), neg_len=np.zeros(n_users, dtype=np.int64),
+                 row_user=np.zeros(4, dtype=np.int64), row_item=np.zeros(4, dtype=np.int64))
+    data = DeviceData(world, dev)
+    Pd = {k: torch.tensor(v).to(dev).contiguous() for k, v in P.items()}
+    ev = Evaluator(meta["kind"], Pd, data, item_page=50, user_page=16, heads=meta["heads"], glove=(meta["embed"] == "glove"))
+    rows_user = np.repeat(np.arange(n_users), 6)
+    rows_item = rs.randint(0, n_items, size=rows_user.size)
+    labels = np.zeros(rows_user.size, dtype=np.int64)
+    labels[::6] = 1
+    res, scores = ev.evaluate(rows_user, rows_item, labels)
+    Pt = {k: torch.tensor(v) for k, v in P.items()}
+    ref, item_repr, user_repr = O.eval_scores(
+        meta["kind"], Pt, torch.tensor(tables["title_tok"]), torch.tensor(tables["title_len"]), torch.tensor(tables["cat"]),
+        torch.tensor(tables["user_hist"]), torch.tensor(tables["user_hist_len"]), torch.tensor(rows_user),
+        torch.tensor(rows_item), heads=meta["heads"], glove=(meta["embed"] == "glove"))
+    _close(ev.item_repr.cpu(), item_repr, rtol=1e-4, what="item cache")
+    _close(ev.user_repr.cpu(), user_repr, rtol=1e-4, what="user cache")
+    _close(scores, ref.numpy(), rtol=1e-4, atol=1e-5, what="eval scores")
+    want = O.grouped_metrics(ref.numpy(), labels, rows_user)
+    for k, v in want.items():
+        assert abs(res[k] - v) < 1e-5, (k, res[k], v)

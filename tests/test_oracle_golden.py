@@ -100,3 +100,14 @@ def test_concat_layout_edges():
     assert s[0].tolist() == [-1, -1, 2, -1, 2, 0, 0]
     assert m[0].tolist() == [1, 1, 1, 1, 1, 0, 0]
     assert m[2].tolist() == [1] * 7 and s[2].tolist() == [-1, -1, -1, -1, 2, -1, 2]
+
+
+def test_product_metrics_match_metricpool_and_oracle():
+    """legommenders_amd.metrics (product) against the reference MetricPool fixture and the oracle."""
+    from legommenders_amd import metrics as PM
+    z = np.load(os.path.join(GOLDEN, "metrics.npz"))
+    names = [str(n) for n in z["names"]]
+    got = PM.calculate(z["scores"], z["labels"], z["groups"], names)
+    ref = O.grouped_metrics(z["scores"], z["labels"], z["groups"], names=names)
+    for n, v in zip(names, z["values"]):
+        assert abs(got[n] - float(v)) < 5e-7 and abs(got[n] - ref[n]) < 1e-9, n
