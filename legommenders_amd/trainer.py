@@ -1,0 +1,278 @@
+"""`trainer.py` CLI of the MI355X path (mirror of the reference's trainer.py:299-322 / base_lego.py:82-142):
+
+    python -m legommenders_amd.trainer --data config/data/synthetic.yaml --model config/model/naml.yaml \
+        --embed config/embed/glove.yaml --batch_size 64 --lr 0.001 --hidden_size 256 --cuda 0
+    torchrun --standalone --local-addr 127.0.0.1 --nproc-per-node 8 -m legommenders_amd.trainer ...   # data parallel
+
+Same flags and config schema (`--data --model --embed --exp --batch_size --lr --hidden_size --item_hidden_size
+--cuda --seed --epoch --epoch_batch --interval --patience --metric --simple_dev --load_sign`); train -> dev
+evaluation with early stopping (`Monitor`, utils/monitor.py:43-73) -> best checkpoint -> test, checkpoints at
+`checkpoints/<data>/<model>/<signature>.pt` with the reference's `state_dict` keys.  `--cuda -1` is refused:
+there is no CPU path here (run the reference for that)."""
+from __future__ import annotations
+
+import base64
+import hashlib
+import json
+import os
+import random
+import time
+from typing import Dict
+
+import numpy as np
+import torch
+
+from legommenders_amd._lib import LegoHipError
+from legommenders_amd.config_init import CommandInit, Obj
+
+
+def seeding(seed=2023):
+    """utils/function.py:58-75"""
+    random.seed(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed(seed)
+
+
+def get_signature(data, embed, model, exp) -> str:
+    """utils/function.py:146-186: 8 chars of the url-safe base64 md5 of the canonical config json"""
+    s = json.dumps({"data": data, "embed": embed, "model": model, "exp": exp}, sort_keys=True, ensure_ascii=False)
+    return base64.urlsafe_b64encode(hashlib.md5(s.encode("utf-8")).digest()).decode("utf-8").rstrip("=")[:8]
+
+
+class Monitor:
+    """early stopping (utils/monitor.py:43-73), including its first-push quirk (best_index stays 0)."""
+
+    def __init__(self, minimize: bool, patience: int = 2):
+        self.patience, self.minimize = patience, minimize
+        self.best_value, self.best_index, self.current_index = None, 0, -1
+
+    def push(self, value: float) -> str:
+        self.current_index += 1
+        if self.best_value is None:
+            self.best_value = value
+            return "best"
+        if self.minimize ^ (value > self.best_value):
+            self.best_value, self.best_index = value, self.current_index
+            return "best"
+        if self.current_index - self.best_index >= self.patience:
+            return "stop"
+        return "skip"
+
+
+def load_world(data_cfg: Obj, seed: int) -> dict:
+    """MIND tables: the synthetic MIND-small-shaped world, or npz files under data.base_dir."""
+    from legommenders_amd.synthetic import MIND_SMALL, make_world
+    base = data_cfg.base_dir
+    if base == "synthetic":
+        cfg = dict(MIND_SMALL)
+        if data_cfg.scale == "small":
+            cfg.update(n_items=3000, n_users=2000, n_rows=8000, V=5000)
+        w = make_world(seed=seed, **cfg)
+        rs = np.random.RandomState(seed + 1)
+        for split, n_u in (("valid", min(2000, cfg["n_users"])), ("test", min(4000, cfg["n_users"]))):
+            users = np.repeat(rs.choice(cfg["n_users"], size=n_u, replace=False), 10)
+            items = rs.randint(0, cfg["n_items"], size=users.size)
+            labels = np.zeros(users.size, dtype=np.int64)
+            labels[::10] = 1
+            w[split] = dict(user=users, item=items, label=labels)
+        return w
+    need = ["items", "users", "train", "valid", "test"]
+    z = {n: np.load(os.path.join(base, n + ".npz")) for n in need}
+    w = dict(title_tok=z["items"]["title_tok"], title_len=z["items"]["title_len"], cat=z["items"]["cat"],
+             user_hist=z["users"]["user_hist"], user_hist_len=z["users"]["user_hist_len"],
+             neg_list=z["users"]["neg_list"], neg_len=z["users"]["neg_len"],
+             row_user=z["train"]["row_user"], row_item=z["train"]["row_item"])
+    w.update(n_items=len(w["cat"]), n_users=len(w["user_hist_len"]), n_rows=len(w["row_user"]),
+             V=int(z["items"]["vocab_size"]), n_cat=int(w["cat"].max()) + 1, T=w["title_tok"].shape[1],
+             S=w["user_hist"].shape[1], neg_cap=w["neg_list"].shape[1])
+    for split in ("valid", "test"):
+        w[split] = dict(user=z[split]["user"], item=z[split]["item"], label=z[split]["label"])
+    return w
+
+
+def build_model(config: Obj, world: dict, device):
+    """Manager.load_model_configs + load_embeddings + Legommender (loader/manager.py:271-326) on our tables."""
+    from legommenders_amd.loader.class_hub import ClassHub
+    from legommenders_amd.loader.column_map import ColumnMap
+    from legommenders_amd.loader.embedding_hub import EmbeddingHub
+    from legommenders_amd.loader.env import Env
+    from legommenders_amd.loader.tables import Feature, Table, Vocab
+    from legommenders_amd.model.lego_config import LegoConfig
+    from legommenders_amd.model.legommender import Legommender
+    from legommenders_amd.synthetic import glove_like
+
+    model, embed, data = config.model, config.embed, config.data
+    glove_v, cat_v = Vocab("glove", world["V"]), Vocab("category", world["n_cat"])
+    item_v, user_v = Vocab("item_id", world["n_items"]), Vocab("user_id", world["n_users"])
+    tcol = "title@glove"
+    item_ut = Table([Feature("item_id", item_v), Feature(tcol, glove_v, world["T"]), Feature("category", cat_v)],
+                    {"item_id": np.arange(world["n_items"]), tcol: (world["title_tok"], world["title_len"]),
+                     "category": world["cat"]}, "item_id")
+    user_ut = Table([Feature("user_id", user_v), Feature("history", item_v, world["S"])],
+                    {"user_id": np.arange(world["n_users"]), "history": (world["user_hist"], world["user_hist_len"])}, "user_id")
+    ops, preds = ClassHub.operators(), ClassHub.predictors()
+    lc = LegoConfig(**model.config())
+    lc.set_component_classes(ops[model.meta.item], ops[model.meta.user], preds[model.meta.predictor])
+    lc.set_item_ut(item_ut, [tcol, "category"])
+    lc.set_user_ut(user_ut, ["history"])
+    lc.set_column_map(ColumnMap(**data.column_map()))
+    eh = EmbeddingHub(embedding_dim=lc.item_hidden_size, transformation=embed.transformation,
+                      transformation_dropout=embed.transformation_dropout)
+    for info in (embed.embeddings() or []):
+        if os.path.exists(info["path"]):
+            arr = np.load(info["path"])
+        elif data.base_dir == "synthetic":
+            arr = glove_like(world["V"], 300, seed=2024, device=device)
+        else:
+            raise ValueError(f"pre-trained embedding {info['path']} not found")
+        eh.load_pretrained_embedding(info["path"], vocab_name=info.get("vocab_name"), col_name=info.get("col_name"),
+                                     frozen=info.get("frozen", True), array=arr)
+    eh.register_ut(item_ut, [tcol, "category"])
+    lc.set_embedding_hub(eh)
+    lc.build_components()
+    lc.register_inputer_vocabs()
+    legommender = Legommender(lc).to(device)
+    kind = {"CNNOperator": "naml", "AttentionOperator": "nrms"}.get(type(lc.item_operator).__name__)
+    if kind is None or type(lc.predictor).__name__ != "DotPredictor":
+        raise LegoHipError("the MI355X training path covers item operators CNN / Attention with the Dot predictor")
+    return legommender, kind
+
+
+class Trainer:
+    def __init__(self, config: Obj):
+        from legommenders_amd.evaluate import Evaluator
+        from legommenders_amd.loader.env import Env
+        from legommenders_amd.train_step import DeviceData, TrainStep
+        self.config, self.exp = config, config.exp
+        config.seed = int(config.seed or 2023)
+        seeding(config.seed)
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        cuda = config.cuda if config.cuda is not None else local
+        self.device = Env.set_device(int(cuda) if self.world_size == 1 else local)     # -1 -> LegoHipError
+        torch.cuda.set_device(self.device)
+        self.pg = None
+        if self.world_size > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            torch.distributed.init_process_group("nccl", device_id=self.device)
+            self.pg = torch.distributed.group.WORLD
+        self.signature = get_signature(config.data(), config.embed(), config.model(), config.exp())
+        self.ckpt_dir = os.path.join("checkpoints", config.data.name, config.model.name)
+        if self.rank == 0:
+            os.makedirs(self.ckpt_dir, exist_ok=True)
+            json.dump(config(), open(os.path.join(self.ckpt_dir, self.signature + ".json"), "w"), default=str)
+        self.world = load_world(config.data, config.seed)
+        self.legommender, self.kind = build_model(config, self.world, self.device)
+        self.data = DeviceData(self.world, self.device, rank=self.rank, world_size=self.world_size, seed=config.seed)
+        pol = self.exp.policy
+        self.B = int(pol.batch_size)
+        self.steps_per_epoch = self.data.n_rows // self.B
+        params = {k: v.detach() for k, v in self.legommender.state_dict().items()}
+        glove = any(k.endswith("glove.embedding.weight") for k in params)
+        heads = getattr(self.legommender.item_op.config, "num_attention_heads", 8)
+        self.ts = TrainStep(self.kind, params, self.data, self.B, K=self.legommender.neg_count, lr=float(pol.lr),
+                            total_steps=self.steps_per_epoch * int(pol.epoch), warmup=int(pol.n_warmup or 0),
+                            seed=config.seed, heads=heads, glove=glove, process_group=self.pg, world_size=self.world_size)
+        self.evaluator = Evaluator(self.kind, self.ts.fp.P, self.data, heads=heads, glove=glove)
+        if self.exp.load.sign:
+            self.load(str(self.exp.load.sign).replace("@", ""))
+
+    def log(self, *a):
+        if self.rank == 0:
+            print("[%s]" % time.strftime("%H:%M:%S"), *a, flush=True)
+            with open(os.path.join(self.ckpt_dir, self.signature + ".log"), "a") as f:
+                f.write(" ".join(str(x) for x in a) + "\n")
+
+    def save(self):
+        path = os.path.join(self.ckpt_dir, self.signature + ".pt")
+        torch.save({"model": {k: v.detach().cpu() for k, v in self.ts.fp.P.items()},
+                    "optimizer": {"m": self.ts.fp.m.cpu(), "v": self.ts.fp.v.cpu(), "step": self.ts.step_idx}}, path)
+        self.log("save model to", path)
+
+    def load(self, sign):
+        path = os.path.join(self.ckpt_dir, sign + ".pt")
+        state = torch.load(path, map_location=self.device)
+        for k, v in state["model"].items():
+            if k in self.ts.fp.P:
+                self.ts.fp.P[k].copy_(v)
+            elif self.exp.load.strict:
+                raise KeyError(k)
+        self.log("load model from", path)
+
+    def evaluate(self, split, metrics):
+        rows = self.world[split]
+        res, _ = self.evaluator.evaluate(rows["user"], rows["item"], rows["label"], metrics=metrics)
+        return res
+
+    def train(self):
+        from legommenders_amd import metrics as M
+        pol, store = self.exp.policy, self.exp.store
+        monitor = Monitor(patience=int(store.patience), minimize=M.is_minimize(store.metric))
+        interval = int(pol.check_interval or 0)
+        if interval < 0:
+            interval = max(self.steps_per_epoch // (-interval), 1)
+        for epoch in range(int(pol.epoch)):
+            t0 = time.time()
+            run, n = None, 0
+            for step in range(self.steps_per_epoch):
+                loss = self.ts.step()
+                run = loss.clone() if run is None else run + loss      # no host sync inside the epoch
+                n += 1
+                if interval and (step + 1) % interval == 0:
+                    self.log(f"[epoch {epoch}] step {step + 1} / {self.steps_per_epoch}, loss {float(run) / n:.4f}")
+                if pol.epoch_batch and step > (pol.epoch_batch if pol.epoch_batch > 0
+                                               else max(self.steps_per_epoch // (-pol.epoch_batch), 1)):
+                    break
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            self.log(f"[epoch {epoch}] train loss {float(run) / max(n, 1):.4f}  "
+                     f"{n * self.B * self.world_size / dt:.0f} impressions/s ({self.world_size} GPU)")
+            action = "skip"
+            if self.rank == 0:
+                res = self.evaluate("valid", [store.metric])
+                self.log(f"[epoch {epoch}] " + " ".join(f"{k} {v:.4f}" for k, v in res.items()))
+                action = monitor.push(res[store.metric])
+                if action == "best":
+                    self.save()
+            if self.world_size > 1:
+                flag = torch.tensor([{"skip": 0, "best": 1, "stop": 2}[action]], device=self.device)
+                torch.distributed.broadcast(flag, 0)
+                action = ["skip", "best", "stop"][int(flag.item())]
+            if action == "stop":
+                self.log("Early stop triggered.")
+                break
+        self.log("Training Ended")
+
+    def test(self):
+        if self.rank != 0:
+            return {}
+        res = self.evaluate("test", list(self.exp.metrics() or ["GAUC"]))
+        self.log("[test] " + " ".join(f"{k} {v:.4f}" for k, v in res.items()))
+        with open(os.path.join(self.ckpt_dir, self.signature + ".csv"), "w") as f:
+            f.write(",".join(res.keys()) + "\n" + ",".join(f"{v:.6f}" for v in res.values()) + "\n")
+        return res
+
+    def run(self):
+        self.train()
+        if self.rank == 0 and os.path.exists(os.path.join(self.ckpt_dir, self.signature + ".pt")):
+            self.load(self.signature)
+        out = self.test()
+        if self.world_size > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return out
+
+
+def get_configurations(kwargs=None) -> Obj:
+    return CommandInit(
+        required_args=["data", "model"],
+        default_args=dict(embed="config/embed/null.yaml", exp="config/exp/default.yaml", hidden_size=256,
+                          item_hidden_size="${hidden_size}$", item_page_size=64),
+    ).parse(kwargs=kwargs)
+
+
+if __name__ == "__main__":
+    Trainer(config=get_configurations()).run()

@@ -1,0 +1,89 @@
+"""trainer.py CLI surface: argument typing, YAML template grammar, early-stopping monitor, signature,
+the refusal of the CPU path -- and (gpu) a short end-to-end train -> dev -> checkpoint -> test run."""
+import os
+
+import numpy as np
+import pytest
+
+from legommenders_amd.config_init import CommandInit, argparse, typed
+from legommenders_amd.trainer import Monitor, get_configurations, get_signature
+
+REF = "/root/reference"
+
+
+def test_cli_typing_rules():
+    kw = argparse(["--data", "x.yaml", "--batch_size", "64", "--lr", "0.001", "--cuda", "-1", "--fast_eval", "false",
+                   "--load_sign", "null", "--metric", "GAUC"])
+    assert kw == {"data": "x.yaml", "batch_size": 64, "lr": 0.001, "cuda": -1, "fast_eval": False, "load_sign": None,
+                  "metric": "GAUC"}
+    assert typed("-2") == -2 and typed("1e-3") == 1e-3 and typed("True") is True
+
+
+def test_template_grammar_on_own_configs():
+    c = get_configurations(dict(data="config/data/synthetic.yaml", model="config/model/nrms.yaml", batch_size=32, lr=0.01,
+                                hidden_size=64, num_item_heads=4))
+    m = c.model.config()
+    assert m["hidden_size"] == 64 and m["item_hidden_size"] == 64
+    assert m["item_config"]["num_attention_heads"] == 4 and m["user_config"]["num_attention_heads"] == 8
+    assert c.model.meta.item == "Attention" and c.model.meta.user == "Attention" and c.model.meta.predictor == "Dot"
+    assert c.exp.policy.batch_size == 32 and c.exp.policy.lr == 0.01 and c.exp.store.metric == "GAUC"
+    assert c.exp.policy.check_interval == -2 and c.exp.load.sign is None
+    assert c.embed.name is None and c.embed.embeddings() == []
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference is only present in the build container")
+def test_reference_yaml_files_load_unchanged():
+    """The reference's own config files resolve through our grammar (drop-in for the listed configs)."""
+    c = CommandInit(["data", "model"], dict(embed=f"{REF}/config/embed/null.yaml", exp=f"{REF}/config/exp/default.yaml",
+                                            hidden_size=256, item_hidden_size="${hidden_size}$", item_page_size=64)
+                    ).parse(dict(data=f"{REF}/config/data/mind.yaml", model=f"{REF}/config/model/naml.yaml",
+                                 embed=f"{REF}/config/embed/glove.yaml", batch_size=64, lr=0.001))
+    assert c.model.meta.item == "CNN" and c.model.meta.user == "Ada" and c.model.meta.predictor == "Dot"
+    assert c.model.config()["item_config"] == {"dropout": 0.1, "kernel_size": 3}
+    assert c.data.item.ut == "data/mind/items" and c.data.column_map.group_col == "user_id"
+    assert c.embed.embeddings()[0]["vocab_name"] == "glove" and c.embed.transformation_dropout == 0.1
+    assert c.exp.policy.epoch == 50 and c.exp.store.patience == 5 and c.exp.metrics()[0] == "GAUC"
+    n = CommandInit(["data", "model"], dict(embed=f"{REF}/config/embed/null.yaml", exp=f"{REF}/config/exp/default.yaml",
+                                            hidden_size=256, item_hidden_size="${hidden_size}$")
+                    ).parse(dict(data=f"{REF}/config/data/mind.yaml", model=f"{REF}/config/model/nrms.yaml", batch_size=64))
+    assert n.model.config()["item_config"]["inputer_config"] == {"use_cls_token": False, "use_sep_token": True}
+
+
+def test_monitor_early_stopping_sequence():
+    m = Monitor(minimize=False, patience=2)
+    assert [m.push(v) for v in (0.5, 0.6, 0.55, 0.58, 0.59)] == ["best", "best", "skip", "stop", "stop"]
+    lo = Monitor(minimize=True, patience=1)
+    assert [lo.push(v) for v in (1.0, 0.9, 0.95)] == ["best", "best", "stop"]
+
+
+def test_signature_is_stable_and_short():
+    a = get_signature({"a": 1}, {}, {"m": [1, 2]}, {"lr": 0.1})
+    assert a == get_signature({"a": 1}, {}, {"m": [1, 2]}, {"lr": 0.1}) and len(a) == 8
+    assert a != get_signature({"a": 2}, {}, {"m": [1, 2]}, {"lr": 0.1})
+
+
+def test_cpu_device_request_is_refused():
+    from legommenders_amd._lib import LegoHipError
+    from legommenders_amd.trainer import Trainer
+    cfg = get_configurations(dict(data="config/data/synthetic.yaml", model="config/model/naml.yaml",
+                                  embed="config/embed/glove.yaml", batch_size=8, hidden_size=64, cuda=-1, world="small"))
+    with pytest.raises(LegoHipError):
+        Trainer(cfg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,embed", [("naml", "glove"), ("nrms", "null")])
+def test_short_training_run_end_to_end(model, embed, tmp_path, monkeypatch):
+    from legommenders_amd.trainer import Trainer
+    monkeypatch.chdir(tmp_path)
+    cfg = get_configurations(dict(data="config/data/synthetic.yaml", model=f"config/model/{model}.yaml",
+                                  embed=f"config/embed/{embed}.yaml", batch_size=32, hidden_size=64, lr=0.001, cuda=0,
+                                  world="small", epoch=2, patience=2, interval=0))
+    tr = Trainer(cfg)
+    res = tr.run()
+    assert set(res) == {"GAUC", "MRR", "NDCG@1", "NDCG@5", "NDCG@10"} and all(np.isfinite(v) for v in res.values())
+    assert 0.3 < res["GAUC"] < 0.7                      # random labels: the metric must sit near chance
+    ck = os.path.join("checkpoints", "synthetic", cfg.model.name, tr.signature + ".pt")
+    import torch
+    state = torch.load(ck)
+    assert set(state["model"]) == set(tr.legommender.state_dict())      # checkpoint carries the reference's keys
