@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--model", default="naml", choices=["naml", "nrms"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=12)
+    ap.add_argument("--micro", type=int, default=1, help="micro-batches per step on separate HIP streams")
     ap.add_argument("--small", action="store_true", help="shrunken world for quick checks (NOT the metric config)")
     return ap.parse_args()
 
@@ -124,7 +125,7 @@ def main():
         params = init_nrms_params(D=args.hidden, V=cfg["V"], n_cat=cfg["n_cat"], glove=glove)
     B = args.batch
     ts = TrainStep(args.model, params, data, B, K=4, lr=1e-3, total_steps=0, seed=2023,
-                   process_group=pg, world_size=world_size, dropout=True)
+                   process_group=pg, world_size=world_size, dropout=True, micro=args.micro)
 
     def barrier():
         if world_size > 1:
@@ -135,7 +136,9 @@ def main():
         ts.step()
     barrier()
     ts.counter_sum.zero_()
-    ts.engine.timers = {}                            # HIP-event pairs around the tagged kernels, timed region only
+    timers = {}
+    for e in ts.engines:
+        e.timers = timers                            # HIP-event pairs around the tagged kernels, timed region only
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = ts.step()
@@ -152,12 +155,14 @@ def main():
     rows_tok, n_inst = cs[0], cs[1]                   # summed over the timed steps
     D, E0 = args.hidden, 300
     kern = {}
-    for tag, evs in (ts.engine.timers or {}).items():
+    for tag, evs in timers.items():
         ms = sum(a.elapsed_time(b) for a, b in evs) / max(1, len(evs))
         kern[tag] = {"avg_ms": ms, "launches": len(evs)}
-    ts.engine.timers = None
-    rows_per_launch = rows_tok / max(1, args.steps)
-    yrows_per_launch = (rows_tok + n_inst) / max(1, args.steps)
+    for e in ts.engines:
+        e.timers = None
+    launches = max(1, args.steps * args.micro)         # one launch of each tagged kernel per micro-batch
+    rows_per_launch = rows_tok / launches
+    yrows_per_launch = (rows_tok + n_inst) / launches
     flops = {                                          # algorithmic flops per launch
         "proj_fwd": 2.0 * rows_per_launch * D * E0,
         "conv3_fwd": 2.0 * rows_per_launch * D * 3 * D,
@@ -195,7 +200,7 @@ def main():
                            "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic.get("gather_rows"),
                            "avg_launch_ms": round(kern["gather_rows"]["avg_ms"], 5),
                            "algorithmic_bytes_per_launch": gbytes,
-                           "dense_reference_bytes_per_launch": B * 55 * 30 * 1200}
+                           "dense_reference_bytes_per_launch": B // args.micro * 55 * 30 * 1200}
 
     if rank != 0:
         if world_size > 1:
@@ -211,7 +216,8 @@ def main():
                                f"K=4 negatives S=50 T=30, full train step (sample+fwd+bwd+allreduce+Adam), dropout 0.1"
                                + (" [SMALL WORLD - not the metric config]" if args.small else ""),
                    "global_batch": B * world_size, "parallelism": f"dp{world_size}",
-                   "live_token_rows_per_step": round(rows_per_launch, 1),
+                   "micro_batches": args.micro,
+                   "live_token_rows_per_step": round(rows_tok / max(1, args.steps), 1),
                    "item_instances_per_step": round(n_inst / max(1, args.steps), 1)},
         "final_loss": round(final_loss, 5),
         "roofline": roofline, "roofline_gather": roofline_gather,

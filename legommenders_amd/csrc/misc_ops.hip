@@ -228,7 +228,7 @@ __global__ void conv3_unpack_add_kernel(const float* __restrict__ dwt, float* __
     const int per = Dout * Din;
     if (e >= 3 * per) return;
     const int oc = e / 3, tap = e - oc * 3;
-    dw[e] += dwt[(size_t)tap * per + oc];
+    atomicAdd(dw + e, dwt[(size_t)tap * per + oc]);      // micro-batches accumulate into the same gradient concurrently
 }
 
 // ------------------------------------------------------------------ additive attention pooling

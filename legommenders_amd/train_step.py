@@ -75,19 +75,30 @@ class DeviceData:
 class TrainStep:
     def __init__(self, kind: str, params: Dict[str, torch.Tensor], data: DeviceData, B: int, K: int = 4,
                  lr: float = 1e-3, total_steps: int = 0, warmup: int = 0, seed: int = 2023, heads: int = 8,
-                 glove: bool = True, process_group=None, world_size: int = 1, dropout: bool = True):
+                 glove: bool = True, process_group=None, world_size: int = 1, dropout: bool = True, micro: int = 1):
         dev = data.tables.title_tok.device
         self.data, self.B, self.C, self.K = data, B, K + 1, K
         frozen = ("embedding_vocab_table.glove.embedding.weight",) if "embedding_vocab_table.glove.embedding.weight" in params else ()
         self.fp = FlatParams(params, frozen, dev)
         pd = 0.1 if dropout else 0.0
-        if kind == "naml":
-            self.engine = NamlEngine(self.fp.P, data.tables, B, self.C, data.S, seed=seed, p_proj=pd, p_conv=pd)
-        elif kind == "nrms":
-            self.engine = NrmsEngine(self.fp.P, data.tables, B, self.C, data.S, heads=heads, glove=glove, seed=seed,
-                                     p_proj=pd, p_att=pd)
-        else:
-            raise ValueError(f"unknown model kind {kind!r} (the HIP path covers naml and nrms)")
+        # `micro` > 1: the batch is processed as `micro` equal micro-batches on their own HIP streams.  Their kernel
+        # chains are independent, so one chain's prologue / epilogue / last-wave tail overlaps the other's MFMA main
+        # loops; gradients of all micro-batches accumulate (atomics) into the same flat buffer == the full-batch mean.
+        assert B % micro == 0, "batch must be divisible by the number of micro-batches"
+        self.micro, Bm = micro, B // micro
+        self.engines = []
+        for i in range(micro):
+            if kind == "naml":
+                e = NamlEngine(self.fp.P, data.tables, Bm, self.C, data.S, seed=seed + 7919 * i, p_proj=pd, p_conv=pd)
+            elif kind == "nrms":
+                e = NrmsEngine(self.fp.P, data.tables, Bm, self.C, data.S, heads=heads, glove=glove, seed=seed + 7919 * i,
+                               p_proj=pd, p_att=pd)
+            else:
+                raise ValueError(f"unknown model kind {kind!r} (the HIP path covers naml and nrms)")
+            self.engines.append(e)
+        self.engine = self.engines[0]
+        self.streams = [torch.cuda.Stream(dev) for _ in range(micro)] if micro > 1 else [None]
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         self.cand = torch.zeros(B, self.C, **i32)
         self.hist = torch.zeros(B, data.S, **i32)
@@ -119,12 +130,31 @@ class TrainStep:
         """sample -> forward -> backward -> all-reduce -> Adam.  Returns the device loss tensor (no sync)."""
         self.sample_batch()
         self.fp.grad.zero_()
-        _, loss = self.engine.forward(self.cand, self.hist, self.hist_len, training=True)
-        self.engine.backward(self.fp.G)
+        if self.micro == 1:
+            _, loss = self.engine.forward(self.cand, self.hist, self.hist_len, training=True)
+            self.engine.backward(self.fp.G)
+        else:
+            main = torch.cuda.current_stream()
+            Bm = self.B // self.micro
+            for e, st in zip(self.engines, self.streams):
+                st.wait_stream(main)
+            for phase in ("fwd", "bwd"):                       # enqueue all forwards first so every stream has work early
+                for i, (e, st) in enumerate(zip(self.engines, self.streams)):
+                    with torch.cuda.stream(st):
+                        sl = slice(i * Bm, (i + 1) * Bm)
+                        if phase == "fwd":
+                            e.forward(self.cand[sl], self.hist[sl], self.hist_len[sl], training=True)
+                        else:
+                            e.backward(self.fp.G, gloss=1.0 / self.micro)
+            for st in self.streams:
+                main.wait_stream(st)
+            loss = self.loss
+            torch.mean(torch.stack([e.loss for e in self.engines]), dim=0, out=self.loss)
         if self.world > 1:
             torch.distributed.all_reduce(self.fp.grad, group=self.pg)      # one RCCL all-reduce per step
         self.step_idx += 1
         call("lego_adam_step", _ptr(self.fp.flat), _ptr(self.fp.grad), _ptr(self.fp.m), _ptr(self.fp.v),
              self.fp.numel, self.lr_at(self.step_idx - 1), 0.9, 0.999, 1e-8, self.step_idx, 1.0 / self.world, _stream())
-        self.counter_sum += self.engine.counters
+        for e in self.engines:
+            self.counter_sum += e.counters
         return loss
