@@ -315,3 +315,88 @@ def test_eval_path_scores_and_metrics(name):
     want = O.grouped_metrics(ref.numpy(), labels, rows_user)
     for k, v in want.items():
         assert abs(res[k] - v) < 1e-5, (k, res[k], v)
+
+
+@pytest.mark.parametrize("name", ["naml_glove_d64", "nrms_null_d64"])
+def test_training_trajectory_matches_oracle(name):
+    """Dropout-free training from the reference's weights on fixed batches: N optimiser steps of the HIP path
+    (engine forward/backward + lego_adam_step with the linear schedule) against torch-CPU autograd + torch.optim.Adam
+    on the oracle -- same loss curve, same final parameters, and dev GAUC / nDCG@10 equal to 3 decimals."""
+    from legommenders_amd import kernels as K
+    from legommenders_amd import metrics as PM
+    from legommenders_amd.engine import ItemTables, NamlEngine, NrmsEngine
+    from legommenders_amd.evaluate import Evaluator
+    from legommenders_amd.train_step import DeviceData, FlatParams
+    from oracle import lego_oracle as O
+    dev = _dev()
+    meta, P, G, tables, batch, _, _ = load_model_fixture(name)
+    kind, glove, heads = meta["kind"], meta["embed"] == "glove", meta["heads"]
+    n_items, n_users = tables["title_tok"].shape[0], tables["user_hist"].shape[0]
+    rs = np.random.RandomState(17)
+    B, C, S, steps, lr = 16, 5, 50, 12, 2e-3
+    batches = []
+    for _ in range(steps):
+        users = rs.randint(0, n_users, size=B)
+        cand = rs.randint(0, n_items, size=(B, C))
+        batches.append((cand, tables["user_hist"][users], tables["user_hist_len"][users]))
+    # ---- oracle side: torch autograd + Adam + LambdaLR (HF linear schedule, warm-up 0)
+    frozen = "embedding_vocab_table.glove.embedding.weight"
+    Pt = {k: torch.tensor(v).clone().requires_grad_(k != frozen) for k, v in P.items()}
+    opt = torch.optim.Adam([v for k, v in Pt.items() if k != frozen], lr=lr)
+    sch = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: O.linear_schedule_factor(s, steps * 2))
+    tt, tl, ct = (torch.tensor(tables[k]) for k in ("title_tok", "title_len", "cat"))
+    ref_losses = []
+    for cand, hist, hl in batches:
+        c, h, l = torch.tensor(cand), torch.tensor(hist), torch.tensor(hl)
+        logits = O.naml_forward(Pt, tt, ct, c, h, l) if kind == "naml" else O.nrms_forward(Pt, tt, tl, ct, c, h, l, heads=heads, glove=glove)
+        loss = O.ce_label0(logits)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        sch.step()
+        ref_losses.append(float(loss.detach()))
+    # ---- HIP side
+    fp = FlatParams({k: torch.tensor(v) for k, v in P.items()}, frozen=(frozen,) if glove else (), device=dev)
+    tb = ItemTables(tables["title_tok"], tables["title_len"], tables["cat"], dev)
+    eng = NamlEngine(fp.P, tb, B, C, S, p_proj=0.0, p_conv=0.0) if kind == "naml" else \
+        NrmsEngine(fp.P, tb, B, C, S, heads=heads, glove=glove, p_proj=0.0, p_att=0.0)
+    losses = []
+    for step, (cand, hist, hl) in enumerate(batches):
+        ids = [torch.tensor(a).int().to(dev).contiguous() for a in (cand, hist, hl)]
+        fp.grad.zero_()
+        _, l = eng.forward(*ids, training=True)
+        eng.backward(fp.G)
+        K.adam_step(fp.flat, fp.grad, fp.m, fp.v, lr * O.linear_schedule_factor(step, steps * 2), step + 1)
+        losses.append(float(l))
+    np.testing.assert_allclose(losses, ref_losses, rtol=2e-5, atol=2e-6)
+    gmax = max(float(np.abs(g).max()) for g in G.values())
+    for k, v in Pt.items():
+        if k == frozen:
+            continue
+        if float(np.abs(G[k]).max()) < 1e-5 * gmax:
+            continue      # gradient is cancellation noise (e.g. |g| ~ 1e-11): Adam's g/sqrt(v) turns noise into +-lr steps
+        got_p, ref_p = fp.P[k].cpu(), v.detach()
+        if k.endswith("in_proj_bias"):
+            # softmax is invariant to a key bias: its true gradient is 0, both sides see rounding noise, and Adam
+            # turns noise into +-lr steps -- compare the query / value slices only
+            Dm = ref_p.numel() // 3
+            got_p = torch.cat([got_p[:Dm], got_p[2 * Dm:]])
+            ref_p = torch.cat([ref_p[:Dm], ref_p[2 * Dm:]])
+        _close(got_p, ref_p, rtol=5e-4, what=f"trained {k}")
+    # ---- dev metrics with both sets of trained weights: equal to 3 decimals (north star)
+    world = dict(title_tok=tables["title_tok"], title_len=tables["title_len"], cat=tables["cat"],
+                 user_hist=tables["user_hist"], user_hist_len=tables["user_hist_len"],
+                 neg_list=np.zeros((n_users, 4), dtype=np.int64), neg_len=np.zeros(n_users, dtype=np.int64),
+                 row_user=np.zeros(4, dtype=np.int64), row_item=np.zeros(4, dtype=np.int64))
+    ev = Evaluator(kind, fp.P, DeviceData(world, dev), item_page=64, user_page=16, heads=heads, glove=glove)
+    rows_user = np.repeat(np.arange(n_users), 8)
+    rows_item = rs.randint(0, n_items, size=rows_user.size)
+    labels = np.zeros(rows_user.size, dtype=np.int64)
+    labels[::8] = 1
+    got, _ = ev.evaluate(rows_user, rows_item, labels, metrics=("GAUC", "NDCG@10", "MRR"))
+    ref_scores, _, _ = O.eval_scores(kind, {k: v.detach() for k, v in Pt.items()}, tt, tl, ct, torch.tensor(tables["user_hist"]),
+                                     torch.tensor(tables["user_hist_len"]), torch.tensor(rows_user), torch.tensor(rows_item),
+                                     heads=heads, glove=glove)
+    want = O.grouped_metrics(ref_scores.numpy(), labels, rows_user, names=("GAUC", "NDCG@10", "MRR"))
+    for k in want:
+        assert abs(got[k] - want[k]) < 5e-4, (k, got[k], want[k])
