@@ -60,8 +60,8 @@ int lego_gather_rows(const float* table, int ld_table, int width, const int32_t*
                      const int32_t* rows_dyn /*nullable*/, float* out, int ld_out,
                      int accumulate /*1: out[r] += row where idx >= 0 (ConcatInputer's summed look-ups)*/, void* stream);
 /* backward of a TRAINABLE table (embed/null.yaml): grad_table[idx[r]] += g[r] (dense grad semantics) */
-int lego_scatter_add_rows(float* grad_table, int ld_table, int width, const int32_t* idx, int rows_cap,
-                          const int32_t* rows_dyn, const float* g, int ld_g, void* stream);
+int lego_scatter_add_rows(float* grad_table, int ld_table, int width, int table_rows /*<= 32: LDS pre-reduction*/,
+                          const int32_t* idx, int rows_cap, const int32_t* rows_dyn, const float* g, int ld_g, void* stream);
 
 /* ---- a4/a5/a6/a8: Linear layers.  out[M,N] = act(x[M,K] . W[N,K]^T + bias) * live * dropout.
  * act: 0 none (nn.Linear: embedding_hub.py:95, cnn_operator.py:59, attention_operator.py:56),

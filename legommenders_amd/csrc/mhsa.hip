@@ -10,48 +10,42 @@ namespace lego {
 
 constexpr int kMaxL = 64;
 
+// K / V (forward, pass 1) and Q / dO (pass 2) rows are read with WAVE-UNIFORM addresses straight from global
+// memory: hipcc turns them into scalar loads and the inner products into v_fma with an SGPR operand, so there is
+// no LDS staging and no LDS-issue bottleneck (the first version, one broadcast ds_read per FMA, was LDS-bound).
 template <int HD>
 __global__ __launch_bounds__(64) void mhsa_fwd_kernel(const float* __restrict__ qkv, int ldq, const int* __restrict__ seg_off,
                                                       int n_cap, const int* __restrict__ n_dyn, int D, int heads,
                                                       float* __restrict__ out, int ldo, float* __restrict__ probs, int Lmax,
                                                       Dropout drop, int drop_cols) {
-    __shared__ float Ks[kMaxL][HD + 1];
-    __shared__ float Vs[kMaxL][HD + 1];
     const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
     const int seg = blockIdx.x, h = blockIdx.y;
     if (seg >= n) return;
     const int beg = seg_off[seg], L = seg_off[seg + 1] - beg;
-    if (L <= 0) return;
     const int lane = threadIdx.x;
+    if (L <= 0 || lane >= L) return;
     const float scale = rsqrtf((float)HD);
-    // stage K and V of this head (coalesced over the hd columns)
-    for (int e = lane; e < L * HD; e += 64) {
-        const int r = e / HD, c = e - r * HD;
-        const float* row = qkv + (size_t)(beg + r) * ldq + h * HD + c;
-        Ks[r][c] = row[D];
-        Vs[r][c] = row[2 * D];
-    }
-    __syncthreads();
-    if (lane >= L) return;
+    const float* kbase = qkv + (size_t)beg * ldq + D + h * HD;         // wave-uniform
+    const float* vbase = kbase + D;
     float q[HD];
     const float* qrow = qkv + (size_t)(beg + lane) * ldq + h * HD;
 #pragma unroll
     for (int c = 0; c < HD; ++c) q[c] = qrow[c] * scale;
-    // pass 1: row max
-    float mx = -INFINITY;
+    float mx = -INFINITY;                              // pass 1: row max
     for (int j = 0; j < L; ++j) {
+        const float* kr = kbase + (size_t)j * ldq;
         float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < HD; ++c) s += q[c] * Ks[j][c];
+        for (int c = 0; c < HD; ++c) s += q[c] * kr[c];
         mx = fmaxf(mx, s);
     }
-    // pass 2: exp / sum, keep unnormalised probabilities in the probs buffer row
     float* prow = probs + ((size_t)(beg + lane) * heads + h) * Lmax;
-    float se = 0.f;
+    float se = 0.f;                                    // pass 2: exp / sum, unnormalised probabilities parked in probs
     for (int j = 0; j < L; ++j) {
+        const float* kr = kbase + (size_t)j * ldq;
         float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < HD; ++c) s += q[c] * Ks[j][c];
+        for (int c = 0; c < HD; ++c) s += q[c] * kr[c];
         const float e = expf(s - mx);
         se += e;
         prow[j] = e;
@@ -68,11 +62,12 @@ __global__ __launch_bounds__(64) void mhsa_fwd_kernel(const float* __restrict__ 
         for (int u = 0; u < 4; ++u) {
             const int j = j0 + u;
             if (j < L) {
+                const float* vr = vbase + (size_t)j * ldq;
                 const float p = prow[j] * inv;
-                prow[j] = p;                       // saved softmax output (pre-dropout) for the backward pass
+                prow[j] = p;                           // saved softmax output (pre-dropout) for the backward pass
                 const float pd = p * ds[u];
 #pragma unroll
-                for (int c = 0; c < HD; ++c) o[c] += pd * Vs[j][c];
+                for (int c = 0; c < HD; ++c) o[c] += pd * vr[c];
             }
         }
     }
@@ -86,12 +81,7 @@ __global__ __launch_bounds__(64) void mhsa_bwd_kernel(const float* __restrict__ 
                                                       int n_cap, const int* __restrict__ n_dyn, int D, int heads,
                                                       const float* __restrict__ gout, int ldgo, const float* __restrict__ probs,
                                                       int Lmax, Dropout drop, int drop_cols, float* __restrict__ gqkv, int ldgq) {
-    __shared__ float Qs[kMaxL][HD + 1];
-    __shared__ float Ks[kMaxL][HD + 1];
-    __shared__ float Vs[kMaxL][HD + 1];
-    __shared__ float Gs[kMaxL][HD + 1];
-    __shared__ float Ps[kMaxL][kMaxL + 1];     // dropped probabilities Pd[i][j]
-    __shared__ float Ss[kMaxL][kMaxL + 1];     // dS[i][j]
+    __shared__ float dotS[kMaxL];              // sum_j dP[i,j] P[i,j] of every query row
     const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
     const int seg = blockIdx.x, h = blockIdx.y;
     if (seg >= n) return;
@@ -99,22 +89,17 @@ __global__ __launch_bounds__(64) void mhsa_bwd_kernel(const float* __restrict__ 
     if (L <= 0) return;
     const int lane = threadIdx.x;
     const float scale = rsqrtf((float)HD);
-    for (int e = lane; e < L * HD; e += 64) {
-        const int r = e / HD, c = e - r * HD;
-        const float* row = qkv + (size_t)(beg + r) * ldq + h * HD + c;
-        Qs[r][c] = row[0];
-        Ks[r][c] = row[D];
-        Vs[r][c] = row[2 * D];
-        Gs[r][c] = gout[(size_t)(beg + r) * ldgo + h * HD + c];
-    }
-    __syncthreads();
-    if (lane < L) {                                   // lane = query row i
+    const float* qbase = qkv + (size_t)beg * ldq + h * HD;             // wave-uniform bases
+    const float* kbase = qbase + D;
+    const float* vbase = qbase + 2 * D;
+    const float* gbase = gout + (size_t)beg * ldgo + h * HD;
+    if (lane < L) {                            // ---- pass 1, lane = query row i: dot_i and dQ
         const float* prow = probs + ((size_t)(beg + lane) * heads + h) * Lmax;
         const int dcol = (beg + lane) * heads + h;
         float g[HD];
 #pragma unroll
-        for (int c = 0; c < HD; ++c) g[c] = Gs[lane][c];
-        float dot = 0.f;                              // sum_j dP[i,j] P[i,j]
+        for (int c = 0; c < HD; ++c) g[c] = gbase[(size_t)lane * ldgo + c];
+        float dot = 0.f;
         for (int j0 = 0; j0 < L; j0 += 4) {
             float ds[4];
             dropout_scale4(drop, j0, dcol, drop_cols, ds);
@@ -122,41 +107,59 @@ __global__ __launch_bounds__(64) void mhsa_bwd_kernel(const float* __restrict__ 
             for (int u = 0; u < 4; ++u) {
                 const int j = j0 + u;
                 if (j < L) {
+                    const float* vr = vbase + (size_t)j * ldq;
                     float dpd = 0.f;
 #pragma unroll
-                    for (int c = 0; c < HD; ++c) dpd += g[c] * Vs[j][c];
-                    const float p = prow[j];
-                    const float dp = dpd * ds[u];
-                    Ps[lane][j] = p * ds[u];
-                    Ss[lane][j] = dp;                 // dP for now
-                    dot += dp * p;
+                    for (int c = 0; c < HD; ++c) dpd += g[c] * vr[c];
+                    dot += dpd * ds[u] * prow[j];
                 }
             }
         }
+        dotS[lane] = dot;
         float dq[HD];
 #pragma unroll
         for (int c = 0; c < HD; ++c) dq[c] = 0.f;
-        for (int j = 0; j < L; ++j) {
-            const float dS = prow[j] * (Ss[lane][j] - dot);
-            Ss[lane][j] = dS;
+        for (int j0 = 0; j0 < L; j0 += 4) {
+            float ds[4];
+            dropout_scale4(drop, j0, dcol, drop_cols, ds);
 #pragma unroll
-            for (int c = 0; c < HD; ++c) dq[c] += dS * Ks[j][c];
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u;
+                if (j < L) {
+                    const float* vr = vbase + (size_t)j * ldq;
+                    const float* kr = kbase + (size_t)j * ldq;
+                    float dpd = 0.f;
+#pragma unroll
+                    for (int c = 0; c < HD; ++c) dpd += g[c] * vr[c];
+                    const float dS = prow[j] * (dpd * ds[u] - dot);
+#pragma unroll
+                    for (int c = 0; c < HD; ++c) dq[c] += dS * kr[c];
+                }
+            }
         }
         float* gq = gqkv + (size_t)(beg + lane) * ldgq + h * HD;
 #pragma unroll
         for (int c = 0; c < HD; ++c) gq[c] = dq[c] * scale;
     }
     __syncthreads();
-    if (lane < L) {                                   // lane = key row j
-        float dk[HD], dv[HD];
+    if (lane < L) {                            // ---- pass 2, lane = key row j: dK[j], dV[j] (dS recomputed, probs read by column)
+        float own[HD], dk[HD], dv[HD];
 #pragma unroll
-        for (int c = 0; c < HD; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
+        for (int c = 0; c < HD; ++c) { own[c] = vbase[(size_t)lane * ldq + c]; dk[c] = 0.f; dv[c] = 0.f; }
         for (int i = 0; i < L; ++i) {
-            const float dS = Ss[i][lane], pd = Ps[i][lane];
+            const float* qr = qbase + (size_t)i * ldq;
+            const float* gr = gbase + (size_t)i * ldgo;
+            const float p = probs[((size_t)(beg + i) * heads + h) * Lmax + lane];
+            const float dsc = dropout_scale1(drop, lane, (beg + i) * heads + h, drop_cols);
+            float dpd = 0.f;
+#pragma unroll
+            for (int c = 0; c < HD; ++c) dpd += gr[c] * own[c];
+            const float dS = p * (dpd * dsc - dotS[i]);
+            const float pd = p * dsc;
 #pragma unroll
             for (int c = 0; c < HD; ++c) {
-                dk[c] += dS * Qs[i][c];
-                dv[c] += pd * Gs[i][c];
+                dk[c] += dS * qr[c];
+                dv[c] += pd * gr[c];
             }
         }
         float* gk = gqkv + (size_t)(beg + lane) * ldgq + D + h * HD;

@@ -322,7 +322,8 @@ class NamlEngine(_Base):
                 self.NIc, self.cnt(1), D, D, self.cnt(0), None)
         self.kk(sb, None, "lego_linear_bwd_data", _ptr(self.dY), D, _ptr(P["item_op.linear.weight"]), D, _ptr(self.d_cat_emb), D,
                 self.NIc, self.cnt(1), D, D, 0, None, 0, 1.0, None, None, None, self.cnt(0), None)
-        self.kk(sb, None, "lego_scatter_add_rows", _ptr(G["embedding_vocab_table.category.weight"]), D, D, _ptr(self.inst_cat),
+        self.kk(sb, None, "lego_scatter_add_rows", _ptr(G["embedding_vocab_table.category.weight"]), D, D,
+                G["embedding_vocab_table.category.weight"].shape[0], _ptr(self.inst_cat),
                 self.NIc, self.cnt(1), _ptr(self.d_cat_emb), D)
         # ---- main: token rows: dY = relu'(.)*keep * (dY + dpre.W1); column sums -> conv bias grad
         self.kk(m, "additive_bwd_data", "lego_linear_bwd_data", _ptr(self.Tt), A, w1, D, _ptr(self.dY), D, self.Rc, self.cnt(0), A, D, 1,
@@ -521,9 +522,10 @@ class NrmsEngine(_Base):
         self._att_bwd("item_op.", self.item_ws, G, _ptr(self.E), _ptr(self.dE), self.cnt(0), self.seg_off, self.NIc,
                       self.cnt(1), self.d_items, SITE_ITEM_ATT, training, st)
         # embedding tables: the three summed look-ups of ConcatInputer.get_embeddings
-        call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.__cat_inputer_special_ids.weight"]), D, D,
+        call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.__cat_inputer_special_ids.weight"]), D, D, 3,
              _ptr(self.idx_spec), self.Rc, self.cnt(0), _ptr(self.dE), D, st)
-        call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.category.weight"]), D, D, _ptr(self.idx_cat),
+        call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.category.weight"]), D, D,
+             G["embedding_vocab_table.category.weight"].shape[0], _ptr(self.idx_cat),
              self.Rc, self.cnt(0), _ptr(self.dE), D, st)
         if self.glove:
             E0 = self.E0
@@ -534,6 +536,7 @@ class NrmsEngine(_Base):
             call("lego_linear_bwd_weight", _ptr(self.dE), D, _ptr(self.X), E0,
                  _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Rc, self.cnt(0), D, E0, None, None, st)
         else:
-            call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.glove.weight"]), D, D, _ptr(self.idx_tok),
+            call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.glove.weight"]), D, D,
+                 G["embedding_vocab_table.glove.weight"].shape[0], _ptr(self.idx_tok),
                  self.Rc, self.cnt(0), _ptr(self.dE), D, st)
         self.step = step_save

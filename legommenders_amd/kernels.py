@@ -228,7 +228,8 @@ def gather_rows(table, idx, out=None):
 def scatter_add_rows(grad_table, idx, g):
     g = _f32(g)
     W = g.shape[1]
-    call("lego_scatter_add_rows", _ptr(grad_table), grad_table.shape[1], W, _ptr(idx), idx.numel(), None, _ptr(g), W, _stream())
+    call("lego_scatter_add_rows", _ptr(grad_table), grad_table.shape[1], W, grad_table.shape[0], _ptr(idx), idx.numel(), None,
+         _ptr(g), W, _stream())
     return grad_table
 
 
