@@ -92,9 +92,10 @@ struct McShiftRows {       // row kk + (tap-1) of p, valid when the plan says ro
 };
 
 // ------------------------------------------------------------------ the kernel
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool STAGGER = false>
 struct TileCfg {
     static constexpr int kBM = BM, kBN = BN, kWM = WM, kWN = WN;
+    static constexpr bool kStagger = STAGGER;     // upper half of the waves writes the next tile BEFORE its MFMAs
     static constexpr int kTM = BM / (WM * 32), kTN = BN / (WN * 32);
     static constexpr int kThreads = WM * WN * 64;
     static_assert(WM * WN == 4 || WM * WN == 8, "256- or 512-thread workgroups");
@@ -216,6 +217,10 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_kernel(GemmDims dims, ALoa
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
 
+    // stagger (MI355X_MICROARCH.md, two waves per SIMD running the same program): the second half of the waves
+    // waits for its prefetch and writes the next LDS tile BEFORE its MFMAs, the first half after them, so on every
+    // SIMD one wave is in its matrix phase while its partner is in its memory phase
+    const bool early = Cfg::kStagger && __builtin_amdgcn_readfirstlane(wave) >= (NT / 128);
     fetch(kbeg);
     commit(As0, Bs0);
     __syncthreads();
@@ -223,6 +228,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_kernel(GemmDims dims, ALoa
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = k0 + BK < kend;
         if (more) fetch(k0 + BK);
+        if (more && early) commit(As0 + (buf ^ 1) * SA::kLdsFloats, Bs0 + (buf ^ 1) * SB::kLdsFloats);
         const float* A_ = As0 + buf * SA::kLdsFloats;
         const float* B_ = Bs0 + buf * SB::kLdsFloats;
 #pragma unroll
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_kernel(GemmDims dims, ALoa
                     for (int b = 0; b < TN; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
         }
-        if (more) commit(As0 + (buf ^ 1) * SA::kLdsFloats, Bs0 + (buf ^ 1) * SB::kLdsFloats);
+        if (more && !early) commit(As0 + (buf ^ 1) * SA::kLdsFloats, Bs0 + (buf ^ 1) * SB::kLdsFloats);
         __syncthreads();
         buf ^= 1;
     }

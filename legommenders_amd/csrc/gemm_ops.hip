@@ -143,7 +143,7 @@ static int launch(const GemmDims& d, const AL& a, const BL& b, const Epi& e0, in
     return check_launch(what);
 }
 
-using C128x128 = TileCfg<128, 128, 4, 2>;     // 8 waves, each 32 x 64: +5-20 % over 4 waves of 64 x 64 (scratch/gemm_variants.py)
+using C128x128 = TileCfg<128, 128, 2, 4, true>;   // 8 waves of 64 x 32, staggered halves: best of scratch/gemm_variants.py at the path's row counts
 using C128x64 = TileCfg<128, 64, 4, 1>;
 using C64x128 = TileCfg<64, 128, 1, 4>;
 using C64x64 = TileCfg<64, 64, 2, 2>;
@@ -319,6 +319,8 @@ extern "C" int lego_debug_gemm_nt(int variant, const float* x, const float* W, c
         case 4: return launch<TileCfg<64, 128, 1, 4>, false, false, EpiPlain>(d, a, b, e, (M + 63) / 64, (N + 127) / 128, 1, st, "dbg4");
         case 5: return launch<TileCfg<128, 128, 4, 2>, false, false, EpiPlain>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, 1, st, "dbg5");
         case 6: return launch<TileCfg<64, 256, 1, 4>, false, false, EpiPlain>(d, a, b, e, (M + 63) / 64, (N + 255) / 256, 1, st, "dbg6");
+        case 7: return launch<TileCfg<128, 128, 4, 2, true>, false, false, EpiPlain>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, 1, st, "dbg7");
+        case 8: return launch<TileCfg<128, 128, 2, 4, true>, false, false, EpiPlain>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, 1, st, "dbg8");
         default: return set_error("lego_debug_gemm_nt: unknown variant %d", variant);
     }
 }
