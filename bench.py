@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--micro", type=int, default=1, help="micro-batches per step on separate HIP streams")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even at world size 1 (path check)")
     ap.add_argument("--small", action="store_true", help="shrunken world for quick checks (NOT the metric config)")
     return ap.parse_args()
 
@@ -103,8 +104,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
-    if world_size > 1:
+    dist_on = world_size > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
         pg = torch.distributed.group.WORLD
 
@@ -125,10 +128,10 @@ def main():
         params = init_nrms_params(D=args.hidden, V=cfg["V"], n_cat=cfg["n_cat"], glove=glove)
     B = args.batch
     ts = TrainStep(args.model, params, data, B, K=4, lr=1e-3, total_steps=0, seed=2023,
-                   process_group=pg, world_size=world_size, dropout=True, micro=args.micro)
+                   process_group=pg, world_size=world_size, dropout=True, micro=args.micro, force_allreduce=args.force_dist)
 
     def barrier():
-        if world_size > 1:
+        if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -144,7 +147,7 @@ def main():
         loss = ts.step()
     barrier()
     dt = time.perf_counter() - t0
-    if world_size > 1:
+    if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -203,7 +206,7 @@ def main():
                            "dense_reference_bytes_per_launch": B // args.micro * 55 * 30 * 1200}
 
     if rank != 0:
-        if world_size > 1:
+        if dist_on:
             torch.distributed.destroy_process_group()
         return
     out = {
@@ -228,7 +231,7 @@ def main():
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))
-    if world_size > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 

@@ -79,6 +79,31 @@ class _Base:
     def _f(self, *shape):
         return torch.zeros(*shape, dtype=torch.float32, device=self.dev)
 
+    # ---- double-buffered plans: the (tiny, latency-bound) plan kernels of step N+1 run on a side stream while
+    # step N computes, so they leave the critical path (TrainStep._prefetch)
+    _PLAN_FIELDS = ("counters", "inst_item", "seg_off", "hist_off", "rowinfo", "row_tok")
+
+    def enable_plan_slots(self):
+        if getattr(self, "_slots", None) is None:
+            cur = {k: getattr(self, k) for k in self._PLAN_FIELDS}
+            self._slots = [cur, {k: torch.zeros_like(v) for k, v in cur.items()}]
+        return self._slots
+
+    def use_slot(self, s: int):
+        for k, v in self._slots[s].items():
+            setattr(self, k, v)
+
+    def plan_on(self, stream, slot: int, cand, hist, hist_len):
+        """enqueue the ragged plan of (cand, hist, hist_len) into plan slot `slot` on `stream`"""
+        b = self._slots[slot]
+        tok, tlen, width = self._plan_tables()
+        call("lego_plan_batch", _ptr(cand), _ptr(hist), _ptr(hist_len), self.B, self.C, self.S, _ptr(tok), _ptr(tlen), width,
+             _ptr(b["counters"]), _ptr(b["inst_item"]), _ptr(b["seg_off"]), _ptr(b["hist_off"]), _ptr(b["rowinfo"]),
+             _ptr(b["row_tok"]), ctypes.c_void_p(stream.cuda_stream))
+
+    def _plan_tables(self):
+        return self.tb.title_tok, self.tb.title_len, self.T
+
     timers = None   # set to a dict to time tagged kernels with HIP events on the launch stream (bench.py)
 
     def k(self, tag, name, *args):
@@ -219,13 +244,14 @@ class NamlEngine(_Base):
         t.setdefault(tag, []).append((e0, e1))
 
     # ------------------------------------------------------------------ forward
-    def forward(self, cand, hist, hist_len, training=False, with_loss=True):
+    def forward(self, cand, hist, hist_len, training=False, with_loss=True, planned=False):
         P, B, C, S, D, A, E0 = self.P, self.B, self.C, self.S, self.D, self.A, self.E0
         m, sb, sc = self._lanes()
         ev = self._evs
         _check(cand, torch.int32, "cand"); _check(hist, torch.int32, "hist"); _check(hist_len, torch.int32, "hist_len")
         self._training = training
-        self._plan(cand, hist, hist_len)
+        if not planned:
+            self._plan(cand, hist, hist_len)
         self._forward_items(training)
         self._forward_users(training)
         # k11/k12: dot predictor + CE(label 0)
@@ -462,12 +488,16 @@ class NrmsEngine(_Base):
         call("lego_linear_bwd_data", _ptr(ws["d_qkv"]), 3 * D, _ptr(P[pre + "multi_head_attention.in_proj_weight"]), D,
              dx_ptr, D, rows, rows_dyn, 3 * D, D, 0, None, 0, 1.0, None, None, None, None, None, st)
 
-    def forward(self, cand, hist, hist_len, training=False, with_loss=True):
+    def _plan_tables(self):
+        return self.seq_tok, self.seq_len, self.L
+
+    def forward(self, cand, hist, hist_len, training=False, with_loss=True, planned=False):
         P, B, C, S, D = self.P, self.B, self.C, self.S, self.D
         st = _stream()
         _check(cand, torch.int32, "cand"); _check(hist, torch.int32, "hist"); _check(hist_len, torch.int32, "hist_len")
         self._training = training
-        self._plan(cand, hist, hist_len)
+        if not planned:
+            self._plan(cand, hist, hist_len)
         self._forward_items(training)
         self._forward_users(training)
         self.loss.zero_()

@@ -75,7 +75,8 @@ class DeviceData:
 class TrainStep:
     def __init__(self, kind: str, params: Dict[str, torch.Tensor], data: DeviceData, B: int, K: int = 4,
                  lr: float = 1e-3, total_steps: int = 0, warmup: int = 0, seed: int = 2023, heads: int = 8,
-                 glove: bool = True, process_group=None, world_size: int = 1, dropout: bool = True, micro: int = 1):
+                 glove: bool = True, process_group=None, world_size: int = 1, dropout: bool = True, micro: int = 1,
+                 force_allreduce: bool = False):
         dev = data.tables.title_tok.device
         self.data, self.B, self.C, self.K = data, B, K + 1, K
         frozen = ("embedding_vocab_table.glove.embedding.weight",) if "embedding_vocab_table.glove.embedding.weight" in params else ()
@@ -100,12 +101,22 @@ class TrainStep:
         self.streams = [torch.cuda.Stream(dev) for _ in range(micro)] if micro > 1 else [None]
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
-        self.cand = torch.zeros(B, self.C, **i32)
-        self.hist = torch.zeros(B, data.S, **i32)
-        self.hist_len = torch.zeros(B, **i32)
+        # two batch / plan slots: step N+1 is sampled and planned on `pre` while step N computes
+        self._cand = [torch.zeros(B, self.C, **i32) for _ in range(2)]
+        self._hist = [torch.zeros(B, data.S, **i32) for _ in range(2)]
+        self._hist_len = [torch.zeros(B, **i32) for _ in range(2)]
+        self.cand, self.hist, self.hist_len = self._cand[0], self._hist[0], self._hist_len[0]
+        self.prefetch = micro == 1 and str(dev) != "cpu"
+        if self.prefetch:
+            self.engine.enable_plan_slots()
+            self.pre = torch.cuda.Stream(dev)
+            self._ready = [torch.cuda.Event(), torch.cuda.Event()]
+            self._go = torch.cuda.Event()
+            self._planned_step = -1
         self.lr, self.total_steps, self.warmup = lr, total_steps, warmup
         self.seed, self.step_idx = seed, 0
         self.pg, self.world = process_group, world_size
+        self.force_allreduce = force_allreduce
         self.counter_sum = torch.zeros(8, dtype=torch.int64, device=dev)
 
     def lr_at(self, step: int) -> float:
@@ -116,22 +127,44 @@ class TrainStep:
             return self.lr * step / max(1, self.warmup)
         return self.lr * max(0.0, (self.total_steps - step) / max(1, self.total_steps - self.warmup))
 
-    def sample_batch(self):
+    def sample_batch(self, step_idx=None, slot=0, stream=None):
+        """Resampler.rebuild on device for training step `step_idx` into batch slot `slot`"""
         d, B = self.data, self.B
-        start = (self.step_idx * B) % max(1, d.n_rows - B + 1)
-        st = _stream()
+        step_idx = self.step_idx if step_idx is None else step_idx
+        start = (step_idx * B) % max(1, d.n_rows - B + 1)
+        st = _stream() if stream is None else ctypes.c_void_p(stream.cuda_stream)
         ru, ri = _ptr(d.row_user, start), _ptr(d.row_item, start)
         call("lego_sample_negatives", ru, ri, _ptr(d.neg_list), _ptr(d.neg_len), d.neg_cap, B, self.K, d.n_items,
-             self.seed, self.step_idx, _ptr(self.cand), st)
-        call("lego_gather_history", ru, _ptr(d.user_hist), _ptr(d.user_hist_len), B, d.S, _ptr(self.hist),
-             _ptr(self.hist_len), st)
+             self.seed, step_idx, _ptr(self._cand[slot]), st)
+        call("lego_gather_history", ru, _ptr(d.user_hist), _ptr(d.user_hist_len), B, d.S, _ptr(self._hist[slot]),
+             _ptr(self._hist_len[slot]), st)
+
+    def _prefetch(self, step_idx):
+        """sample + plan training step `step_idx` on the side stream `pre` (slot = step_idx % 2)"""
+        slot = step_idx % 2
+        self._go.record(torch.cuda.current_stream())
+        self.pre.wait_event(self._go)              # the slot's previous user (step_idx - 2) is complete by now
+        self.sample_batch(step_idx, slot, self.pre)
+        self.engine.plan_on(self.pre, slot, self._cand[slot], self._hist[slot], self._hist_len[slot])
+        self._ready[slot].record(self.pre)
+        self._planned_step = step_idx
 
     def step(self):
         """sample -> forward -> backward -> all-reduce -> Adam.  Returns the device loss tensor (no sync)."""
-        self.sample_batch()
+        slot = self.step_idx % 2 if self.prefetch else 0
+        self.cand, self.hist, self.hist_len = self._cand[slot], self._hist[slot], self._hist_len[slot]
+        if self.prefetch:
+            if self._planned_step != self.step_idx:
+                self._prefetch(self.step_idx)
+            torch.cuda.current_stream().wait_event(self._ready[slot])
+            self.engine.use_slot(slot)
+        else:
+            self.sample_batch()
         self.fp.grad.zero_()
         if self.micro == 1:
-            _, loss = self.engine.forward(self.cand, self.hist, self.hist_len, training=True)
+            _, loss = self.engine.forward(self.cand, self.hist, self.hist_len, training=True, planned=self.prefetch)
+            if self.prefetch:
+                self._prefetch(self.step_idx + 1)      # next batch: off the critical path
             self.engine.backward(self.fp.G)
         else:
             main = torch.cuda.current_stream()
@@ -150,7 +183,7 @@ class TrainStep:
                 main.wait_stream(st)
             loss = self.loss
             torch.mean(torch.stack([e.loss for e in self.engines]), dim=0, out=self.loss)
-        if self.world > 1:
+        if self.world > 1 or self.force_allreduce:
             torch.distributed.all_reduce(self.fp.grad, group=self.pg)      # one RCCL all-reduce per step
         self.step_idx += 1
         call("lego_adam_step", _ptr(self.fp.flat), _ptr(self.fp.grad), _ptr(self.fp.m), _ptr(self.fp.v),
