@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--micro", type=int, default=1, help="micro-batches per step on separate HIP streams")
+    ap.add_argument("--time-every", type=int, default=8, help="bracket the tagged kernels with HIP events every N-th timed step")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even at world size 1 (path check)")
     ap.add_argument("--small", action="store_true", help="shrunken world for quick checks (NOT the metric config)")
     return ap.parse_args()
@@ -139,11 +140,14 @@ def main():
         ts.step()
     barrier()
     ts.counter_sum.zero_()
-    timers = {}
-    for e in ts.engines:
-        e.timers = timers                            # HIP-event pairs around the tagged kernels, timed region only
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    timers = {}                                      # HIP-event pairs around the tagged kernels, timed region only,
+    t0 = time.perf_counter()                         # on every `time_every`-th step (22 event records per step are not free)
+    n_timed = 0
+    for i in range(args.steps):
+        on = args.time_every > 0 and i % args.time_every == 0
+        for e in ts.engines:
+            e.timers = timers if on else None
+        n_timed += int(on)
         loss = ts.step()
     barrier()
     dt = time.perf_counter() - t0

@@ -191,36 +191,26 @@ __global__ void scatter_add_rows_kernel(float* grad_table, int ld_table, int wid
 }
 
 // Scatter-add into a SMALL table (category: 18 rows, ConcatInputer specials: 3 rows): every source row hits one of a
-// handful of destination rows, so per-row atomics serialise on a few cache lines.  Each workgroup first sums its
-// 128-row chunk per destination row in LDS (thread = column, no LDS conflicts), then adds once per (row, column).
+// handful of destination rows, so per-row atomics serialise on a few cache lines.  One workgroup per (destination
+// row t, 512-source-row chunk): it scans the chunk's indices (wave-uniform scalar loads), sums the matching rows in
+// registers (thread = column) and adds ONCE per (t, column).
 constexpr int kSmallTableRows = 32;
-__global__ __launch_bounds__(256) void scatter_add_small_kernel(float* grad_table, int ld_table, int width, int table_rows,
+constexpr int kSmallChunk = 512;
+__global__ __launch_bounds__(256) void scatter_add_small_kernel(float* grad_table, int ld_table, int width,
                                                                 const int* __restrict__ idx, int rows_cap,
                                                                 const int* __restrict__ rows_dyn,
                                                                 const float* __restrict__ g, int ld_g) {
-    __shared__ float acc[kSmallTableRows][256];
-    constexpr int kChunk = 128;
-    __shared__ int sidx[kChunk];
     const int rows = rows_dyn != nullptr ? min(rows_cap, *rows_dyn) : rows_cap;
-    const int r0 = blockIdx.x * kChunk;
+    const int t = blockIdx.x;
+    const int r0 = blockIdx.y * kSmallChunk;
     if (r0 >= rows) return;
-    const int nr = min(kChunk, rows - r0);
-    for (int i = threadIdx.x; i < nr; i += 256) sidx[i] = idx[r0 + i];
-    for (int c0 = 0; c0 < width; c0 += 256) {
-        const int c = c0 + threadIdx.x;
-        for (int t = 0; t < table_rows; ++t) acc[t][threadIdx.x] = 0.f;
-        __syncthreads();
-        if (c < width)
-            for (int i = 0; i < nr; ++i) {
-                const int t = sidx[i];
-                if (t >= 0) acc[t][threadIdx.x] += g[(size_t)(r0 + i) * ld_g + c];
-            }
-        if (c < width)
-            for (int t = 0; t < table_rows; ++t) {
-                const float v = acc[t][threadIdx.x];
-                if (v != 0.f) atomicAdd(grad_table + (size_t)t * ld_table + c, v);
-            }
-        __syncthreads();
+    const int r1 = min(rows, r0 + kSmallChunk);
+    for (int c = threadIdx.x; c < width; c += 256) {
+        float acc = 0.f;
+        bool any = false;
+        for (int r = r0; r < r1; ++r)
+            if (idx[r] == t) { acc += g[(size_t)r * ld_g + c]; any = true; }
+        if (any) atomicAdd(grad_table + (size_t)t * ld_table + c, acc);
     }
 }
 
@@ -611,8 +601,8 @@ extern "C" int lego_scatter_add_rows(float* grad_table, int ld_table, int width,
                                      int rows_cap, const int32_t* rows_dyn, const float* g, int ld_g, void* stream) {
     if (rows_cap <= 0) return 0;
     if (table_rows > 0 && table_rows <= kSmallTableRows) {
-        hipLaunchKernelGGL(scatter_add_small_kernel, dim3((rows_cap + 127) / 128), dim3(256), 0, ST, grad_table, ld_table, width,
-                           table_rows, idx, rows_cap, rows_dyn, g, ld_g);
+        hipLaunchKernelGGL(scatter_add_small_kernel, dim3(table_rows, (rows_cap + kSmallChunk - 1) / kSmallChunk), dim3(256), 0, ST,
+                           grad_table, ld_table, width, idx, rows_cap, rows_dyn, g, ld_g);
         return check_launch("lego_scatter_add_rows");
     }
     const long long total = (long long)rows_cap * width;
