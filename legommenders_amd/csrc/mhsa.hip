@@ -10,51 +10,64 @@ namespace lego {
 
 constexpr int kMaxL = 64;
 
-// K / V (forward, pass 1) and Q / dO (pass 2) rows are read with WAVE-UNIFORM addresses straight from global
-// memory: hipcc turns them into scalar loads and the inner products into v_fma with an SGPR operand, so there is
-// no LDS staging and no LDS-issue bottleneck (the first version, one broadcast ds_read per FMA, was LDS-bound).
-template <int HD>
+// One wave per (segment, head).  SPLIT (L <= 32): lane = (query row i, half of the head dim) so 2L of the 64 lanes work
+// and every q.k product is two 16-wide partial dots joined by one wave shuffle; otherwise lane = query row.
+// The saved probability carries the dropout decision in its sign bit (p >= 0: kept, stored -p: dropped), so the
+// backward pass needs no Philox.  Dot products run on 4 independent accumulators (no 32-long dependent FMA chain).
+template <int W>
+__device__ __forceinline__ float dotw(const float (&a)[W], const float* __restrict__ b) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int c = 0; c < W; c += 4) {
+        s0 += a[c] * b[c]; s1 += a[c + 1] * b[c + 1]; s2 += a[c + 2] * b[c + 2]; s3 += a[c + 3] * b[c + 3];
+    }
+    return (s0 + s1) + (s2 + s3);
+}
+
+template <int HD, bool SPLIT>
 __global__ __launch_bounds__(64) void mhsa_fwd_kernel(const float* __restrict__ qkv, int ldq, const int* __restrict__ seg_off,
                                                       int n_cap, const int* __restrict__ n_dyn, int D, int heads,
                                                       float* __restrict__ out, int ldo, float* __restrict__ probs, int Lmax,
                                                       Dropout drop, int drop_cols) {
+    constexpr int W = SPLIT ? HD / 2 : HD;
     const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
     const int seg = blockIdx.x, h = blockIdx.y;
     if (seg >= n) return;
     const int beg = seg_off[seg], L = seg_off[seg + 1] - beg;
+    if (L <= 0) return;
+    if (SPLIT != (L <= 32)) return;                    // the other instantiation handles this segment
     const int lane = threadIdx.x;
-    if (L <= 0 || lane >= L) return;
+    const int i = SPLIT ? (lane & 31) : lane, half = SPLIT ? (lane >> 5) : 0;
+    const bool act = i < L;
+    const int ic = act ? i : 0;
     const float scale = rsqrtf((float)HD);
-    const float* kbase = qkv + (size_t)beg * ldq + D + h * HD;         // wave-uniform
+    const float* kbase = qkv + (size_t)beg * ldq + D + h * HD + half * W;
     const float* vbase = kbase + D;
-    float q[HD];
-    const float* qrow = qkv + (size_t)(beg + lane) * ldq + h * HD;
+    float q[W];
+    const float* qrow = qkv + (size_t)(beg + ic) * ldq + h * HD + half * W;
 #pragma unroll
-    for (int c = 0; c < HD; ++c) q[c] = qrow[c] * scale;
-    float mx = -INFINITY;                              // pass 1: row max
+    for (int c = 0; c < W; ++c) q[c] = qrow[c] * scale;
+    // the L x L score / probability tile of this (segment, head) lives in LDS as [key j][query i] (lane = i: conflict
+    // free); it is saved to `probs` in the same layout at (beg*heads + h*L)*Lmax + j*L + i, so every global access of
+    // the tile is coalesced (the first version kept one row per lane, 1 KB apart: 64 transactions per access)
+    constexpr int LT = SPLIT ? 32 : kMaxL;
+    __shared__ float Pl[LT][LT + 1];
+    float* ptile = probs + ((size_t)beg * heads + (size_t)h * L) * Lmax;
+    float mx = -INFINITY;                              // pass 1: scores and the row max
     for (int j = 0; j < L; ++j) {
-        const float* kr = kbase + (size_t)j * ldq;
-        float s = 0.f;
-#pragma unroll
-        for (int c = 0; c < HD; ++c) s += q[c] * kr[c];
+        float s = dotw<W>(q, kbase + (size_t)j * ldq);
+        if (SPLIT) s += __shfl_xor(s, 32, 64);
         mx = fmaxf(mx, s);
+        if (half == 0) Pl[j][i < LT ? i : 0] = s;
     }
-    float* prow = probs + ((size_t)(beg + lane) * heads + h) * Lmax;
-    float se = 0.f;                                    // pass 2: exp / sum, unnormalised probabilities parked in probs
-    for (int j = 0; j < L; ++j) {
-        const float* kr = kbase + (size_t)j * ldq;
-        float s = 0.f;
-#pragma unroll
-        for (int c = 0; c < HD; ++c) s += q[c] * kr[c];
-        const float e = expf(s - mx);
-        se += e;
-        prow[j] = e;
-    }
+    __syncthreads();
+    float se = 0.f;
+    for (int j = 0; j < L; ++j) se += expf(Pl[j][ic] - mx);
     const float inv = 1.f / se;
-    float o[HD];
+    float o[W];
 #pragma unroll
-    for (int c = 0; c < HD; ++c) o[c] = 0.f;
-    const int dcol = (beg + lane) * heads + h;
+    for (int c = 0; c < W; ++c) o[c] = 0.f;
+    const int dcol = (beg + ic) * heads + h;
     for (int j0 = 0; j0 < L; j0 += 4) {
         float ds[4];
         dropout_scale4(drop, j0, dcol, drop_cols, ds);
@@ -63,109 +76,105 @@ __global__ __launch_bounds__(64) void mhsa_fwd_kernel(const float* __restrict__ 
             const int j = j0 + u;
             if (j < L) {
                 const float* vr = vbase + (size_t)j * ldq;
-                const float p = prow[j] * inv;
-                prow[j] = p;                           // saved softmax output (pre-dropout) for the backward pass
+                const float p = expf(Pl[j][ic] - mx) * inv;
                 const float pd = p * ds[u];
 #pragma unroll
-                for (int c = 0; c < HD; ++c) o[c] += pd * vr[c];
+                for (int c = 0; c < W; ++c) o[c] += pd * vr[c];
+                if (act && half == 0) ptile[(size_t)j * L + i] = ds[u] > 0.f ? p : -p;   // sign bit = dropped
             }
         }
     }
-    float* orow = out + (size_t)(beg + lane) * ldo + h * HD;
+    if (act) {
+        float* orow = out + (size_t)(beg + i) * ldo + h * HD + half * W;
 #pragma unroll
-    for (int c = 0; c < HD; ++c) orow[c] = o[c];
+        for (int c = 0; c < W; ++c) orow[c] = o[c];
+    }
 }
 
-template <int HD>
+template <int HD, bool SPLIT>
 __global__ __launch_bounds__(64) void mhsa_bwd_kernel(const float* __restrict__ qkv, int ldq, const int* __restrict__ seg_off,
                                                       int n_cap, const int* __restrict__ n_dyn, int D, int heads,
                                                       const float* __restrict__ gout, int ldgo, const float* __restrict__ probs,
-                                                      int Lmax, Dropout drop, int drop_cols, float* __restrict__ gqkv, int ldgq) {
+                                                      int Lmax, float keep_scale, float* __restrict__ gqkv, int ldgq) {
+    constexpr int W = SPLIT ? HD / 2 : HD;
     __shared__ float dotS[kMaxL];              // sum_j dP[i,j] P[i,j] of every query row
     const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
     const int seg = blockIdx.x, h = blockIdx.y;
     if (seg >= n) return;
     const int beg = seg_off[seg], L = seg_off[seg + 1] - beg;
     if (L <= 0) return;
+    if (SPLIT != (L <= 32)) return;
     const int lane = threadIdx.x;
+    const int i = SPLIT ? (lane & 31) : lane, half = SPLIT ? (lane >> 5) : 0;
+    const bool act = i < L;
+    const int ic = act ? i : 0;
     const float scale = rsqrtf((float)HD);
-    const float* qbase = qkv + (size_t)beg * ldq + h * HD;             // wave-uniform bases
+    const float* qbase = qkv + (size_t)beg * ldq + h * HD + half * W;
     const float* kbase = qbase + D;
     const float* vbase = qbase + 2 * D;
-    const float* gbase = gout + (size_t)beg * ldgo + h * HD;
-    if (lane < L) {                            // ---- pass 1, lane = query row i: dot_i and dQ
-        const float* prow = probs + ((size_t)(beg + lane) * heads + h) * Lmax;
-        const int dcol = (beg + lane) * heads + h;
-        float g[HD];
+    const float* gbase = gout + (size_t)beg * ldgo + h * HD + half * W;
+    constexpr int LT = SPLIT ? 32 : kMaxL;
+    __shared__ float Pl[LT][LT + 1];           // signed probabilities [key j][query i], staged with coalesced loads
+    const float* ptile = probs + ((size_t)beg * heads + (size_t)h * L) * Lmax;
+    for (int e = lane; e < L * L; e += 64) Pl[e / L][e % L] = ptile[e];
+    __syncthreads();
+    {                                          // ---- pass 1, lane = (query row i, half): dot_i and dQ
+        float g[W];
 #pragma unroll
-        for (int c = 0; c < HD; ++c) g[c] = gbase[(size_t)lane * ldgo + c];
+        for (int c = 0; c < W; ++c) g[c] = gbase[(size_t)ic * ldgo + c];
         float dot = 0.f;
-        for (int j0 = 0; j0 < L; j0 += 4) {
-            float ds[4];
-            dropout_scale4(drop, j0, dcol, drop_cols, ds);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + u;
-                if (j < L) {
-                    const float* vr = vbase + (size_t)j * ldq;
-                    float dpd = 0.f;
-#pragma unroll
-                    for (int c = 0; c < HD; ++c) dpd += g[c] * vr[c];
-                    dot += dpd * ds[u] * prow[j];
-                }
-            }
+        for (int j = 0; j < L; ++j) {
+            float dpd = dotw<W>(g, vbase + (size_t)j * ldq);
+            if (SPLIT) dpd += __shfl_xor(dpd, 32, 64);
+            const float ps = Pl[j][ic];                                // sign bit = dropped
+            dot += (ps > 0.f ? dpd * keep_scale * ps : 0.f);
         }
-        dotS[lane] = dot;
-        float dq[HD];
+        if (act && half == 0) dotS[i] = dot;
+        float dq[W];
 #pragma unroll
-        for (int c = 0; c < HD; ++c) dq[c] = 0.f;
-        for (int j0 = 0; j0 < L; j0 += 4) {
-            float ds[4];
-            dropout_scale4(drop, j0, dcol, drop_cols, ds);
+        for (int c = 0; c < W; ++c) dq[c] = 0.f;
+        for (int j = 0; j < L; ++j) {
+            const float* kr = kbase + (size_t)j * ldq;
+            float dpd = dotw<W>(g, vbase + (size_t)j * ldq);
+            if (SPLIT) dpd += __shfl_xor(dpd, 32, 64);
+            const float ps = Pl[j][ic];
+            const float dS = fabsf(ps) * ((ps > 0.f ? dpd * keep_scale : 0.f) - dot);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + u;
-                if (j < L) {
-                    const float* vr = vbase + (size_t)j * ldq;
-                    const float* kr = kbase + (size_t)j * ldq;
-                    float dpd = 0.f;
-#pragma unroll
-                    for (int c = 0; c < HD; ++c) dpd += g[c] * vr[c];
-                    const float dS = prow[j] * (dpd * ds[u] - dot);
-#pragma unroll
-                    for (int c = 0; c < HD; ++c) dq[c] += dS * kr[c];
-                }
-            }
+            for (int c = 0; c < W; ++c) dq[c] += dS * kr[c];
         }
-        float* gq = gqkv + (size_t)(beg + lane) * ldgq + h * HD;
+        if (act) {
+            float* gq = gqkv + (size_t)(beg + i) * ldgq + h * HD + half * W;
 #pragma unroll
-        for (int c = 0; c < HD; ++c) gq[c] = dq[c] * scale;
+            for (int c = 0; c < W; ++c) gq[c] = dq[c] * scale;
+        }
     }
     __syncthreads();
-    if (lane < L) {                            // ---- pass 2, lane = key row j: dK[j], dV[j] (dS recomputed, probs read by column)
-        float own[HD], dk[HD], dv[HD];
+    {                                          // ---- pass 2, lane = (key row j, half): dK[j], dV[j]; probs read by column
+        float own[W], dk[W], dv[W];
 #pragma unroll
-        for (int c = 0; c < HD; ++c) { own[c] = vbase[(size_t)lane * ldq + c]; dk[c] = 0.f; dv[c] = 0.f; }
-        for (int i = 0; i < L; ++i) {
-            const float* qr = qbase + (size_t)i * ldq;
-            const float* gr = gbase + (size_t)i * ldgo;
-            const float p = probs[((size_t)(beg + i) * heads + h) * Lmax + lane];
-            const float dsc = dropout_scale1(drop, lane, (beg + i) * heads + h, drop_cols);
-            float dpd = 0.f;
+        for (int c = 0; c < W; ++c) { own[c] = vbase[(size_t)ic * ldq + c]; dk[c] = 0.f; dv[c] = 0.f; }
+        for (int r = 0; r < L; ++r) {
+            const float* qr = qbase + (size_t)r * ldq;
+            const float* gr = gbase + (size_t)r * ldgo;
+            const float ps = Pl[ic][r];
+            float dpd = dotw<W>(own, gr);
+            if (SPLIT) dpd += __shfl_xor(dpd, 32, 64);
+            const float keep = ps > 0.f ? keep_scale : 0.f;
+            const float p = fabsf(ps);
+            const float dS = p * (dpd * keep - dotS[r]);
+            const float pd = p * keep;
 #pragma unroll
-            for (int c = 0; c < HD; ++c) dpd += gr[c] * own[c];
-            const float dS = p * (dpd * dsc - dotS[i]);
-            const float pd = p * dsc;
-#pragma unroll
-            for (int c = 0; c < HD; ++c) {
+            for (int c = 0; c < W; ++c) {
                 dk[c] += dS * qr[c];
                 dv[c] += pd * gr[c];
             }
         }
-        float* gk = gqkv + (size_t)(beg + lane) * ldgq + D + h * HD;
-        float* gv = gqkv + (size_t)(beg + lane) * ldgq + 2 * D + h * HD;
+        if (act) {
+            float* gk = gqkv + (size_t)(beg + i) * ldgq + D + h * HD + half * W;
+            float* gv = gqkv + (size_t)(beg + i) * ldgq + 2 * D + h * HD + half * W;
 #pragma unroll
-        for (int c = 0; c < HD; ++c) { gk[c] = dk[c] * scale; gv[c] = dv[c]; }
+            for (int c = 0; c < W; ++c) { gk[c] = dk[c] * scale; gv[c] = dv[c]; }
+        }
     }
 }
 
@@ -189,7 +198,8 @@ extern "C" int lego_mhsa_core_fwd(const float* qkv, int ldq, const int32_t* seg_
     const int dc = rows_cap * heads;
     dim3 grid(n_cap, heads), block(64);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(HD) hipLaunchKernelGGL(mhsa_fwd_kernel<HD>, grid, block, 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, out, ldo, probs, Lmax, dr, dc)
+#define LAUNCH(HD) do { hipLaunchKernelGGL((mhsa_fwd_kernel<HD, true>), grid, block, 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, out, ldo, probs, Lmax, dr, dc); \
+                        if (Lmax > 32) hipLaunchKernelGGL((mhsa_fwd_kernel<HD, false>), grid, block, 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, out, ldo, probs, Lmax, dr, dc); } while (0)
     switch (hd) {
         case 8: LAUNCH(8); break;
         case 16: LAUNCH(16); break;
@@ -209,10 +219,12 @@ extern "C" int lego_mhsa_core_bwd(const float* qkv, int ldq, const int32_t* seg_
     if (n_cap <= 0) return 0;
     const int hd = D / heads;
     const Dropout dr = to_drop(drop);
-    const int dc = rows_cap * heads;
+    const float ks = dr.p > 0.f ? 1.f / (1.f - dr.p) : 1.f;     // the keep / drop decision itself is the sign of the saved probability
+    (void)rows_cap;
     dim3 grid(n_cap, heads), block(64);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(HD) hipLaunchKernelGGL(mhsa_bwd_kernel<HD>, grid, block, 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, gout, ldgo, probs, Lmax, dr, dc, gqkv, ldgq)
+#define LAUNCH(HD) do { hipLaunchKernelGGL((mhsa_bwd_kernel<HD, true>), grid, block, 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, gout, ldgo, probs, Lmax, ks, gqkv, ldgq); \
+                        if (Lmax > 32) hipLaunchKernelGGL((mhsa_bwd_kernel<HD, false>), grid, block, 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, gout, ldgo, probs, Lmax, ks, gqkv, ldgq); } while (0)
     switch (hd) {
         case 8: LAUNCH(8); break;
         case 16: LAUNCH(16); break;
