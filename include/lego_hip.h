@@ -126,6 +126,17 @@ int lego_dot_ce_bwd(const float* user, int ldu, const float* items, int ldi, con
                     int B, int C, int D, float gscale /*dloss * 1/B*/, float* guser, int ldgu,
                     float* gitems, int ldgi, void* stream);
 
+/* ---- a7 + a9 + a10 fused for TRAINING: AdaOperator pool over each user's clicked-item vectors (rows
+ * items[B*C + hist_off[b] ..]), dot scores against the user's C candidates (rows items[b*C ..]), CE(label 0), the
+ * gradient of the scores, and the backward of the pool -- one workgroup per impression instead of five dependent
+ * launches (ada_operator.py:31-34, dot_predictor.py:7-10, legommender.py:254,263 and their autograd).
+ * t_dpre rows (tanh hidden of the history rows) are overwritten with dpre; d_items gets g_c*u for candidates and
+ * w_l*du for history rows (the dpre.W1 term is added by lego_linear_bwd_data); gw2/gb1 accumulate. */
+int lego_user_tower_train(float* t_dpre, int ldt, const float* items, int ldi, const float* w2,
+                          const int32_t* hist_off, int B, int C, int S, int D, int A, float gscale /* dloss / B */,
+                          float* user /*[B,D]*/, float* scores /*[B,C]*/, float* loss /*[1] += mean*/,
+                          float* d_items, int lddi, float* gw2, float* gb1, void* stream);
+
 /* DotPredictor.predict on already-expanded (user, item) pairs, as the plug-in interface passes them
  * (model/legommender.py:275-283): out[r] = sum_d u[r,d]*it[r,d], and its backward. */
 int lego_rowdot_fwd(const float* u, int ldu, const float* it, int ldi, int n, int D, float* out, void* stream);

@@ -49,6 +49,7 @@ SIGNATURES = {
     "lego_dot_ce_bwd": [P, I, P, I, P, I, I, I, F, P, I, P, I, P],
     "lego_mhsa_core_fwd": [P, I, P, I, P, I, I, P, I, P, I, P, I, P],
     "lego_mhsa_core_bwd": [P, I, P, I, P, I, I, P, I, P, I, P, I, P, I, P],
+    "lego_user_tower_train": [P, I, P, I, P, P, I, I, I, I, I, F, P, P, P, P, I, P, P, P],
     "lego_rowdot_fwd": [P, I, P, I, I, I, P, P],
     "lego_rowdot_bwd": [P, I, P, I, P, I, I, P, I, P, I, P],
     "lego_relu_bwd": [P, I, P, I, I, I, F, P],

@@ -480,6 +480,127 @@ __global__ void relu_bwd_kernel(float* __restrict__ g, int ldg, const float* __r
     }
 }
 
+// ------------------------------------------------------------------ fused user tower (training)
+// One workgroup per impression does, back to back and without leaving the CU, what used to be five dependent
+// launches on the step's critical path: additive pool over the clicked items (AdaOperator), dot scores against the
+// C candidates, cross-entropy(label 0) and its gradient, and the backward of the pool (dx direct part, dpre in
+// place of t, parameter-gradient partials).  The tanh GEMM before it and the dpre.W1 / dpre^T.x GEMMs after it
+// stay on the MFMA core.
+__global__ __launch_bounds__(256) void user_tower_train_kernel(
+    float* __restrict__ t, int ldt, const float* __restrict__ items, int ldi, const float* __restrict__ w2,
+    const int* __restrict__ hist_off, int B, int C, int D, int A, float gscale,
+    float* __restrict__ user, float* __restrict__ scores, float* loss, float* __restrict__ d_items, int lddi,
+    float* gw2, float* gb1) {
+    __shared__ float red[4][kMaxChunks * 256];
+    __shared__ float uvec[kMaxChunks * 256], duvec[kMaxChunks * 256];
+    __shared__ float wl[kMaxSegRows], dwl[kMaxSegRows], sc[kMaxCand], red_s[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x;
+    const int BC = B * C;
+    const int beg = hist_off[b], len = hist_off[b + 1] - beg;
+    const float* xh = items + (size_t)(BC + beg) * ldi;          // this user's clicked-item vectors
+    float* th = t + (size_t)beg * ldt;
+    // ---- A: additive pool forward (model/common/attention.py:31-38)
+    f32x4 acc[kMaxChunks];
+#pragma unroll
+    for (int j = 0; j < kMaxChunks; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float s = 0.f;
+    for (int l = wave; l < len; l += 4) {
+        const float e = expf(dot_row(th + (size_t)l * ldt, w2, A, lane));
+        s += e;
+#pragma unroll
+        for (int j = 0; j < kMaxChunks; ++j) {
+            const int c = 4 * lane + 256 * j;
+            if (c < D) acc[j] += e * *reinterpret_cast<const f32x4*>(xh + (size_t)l * ldi + c);
+        }
+        if (lane == 0) wl[l] = e;
+    }
+#pragma unroll
+    for (int j = 0; j < kMaxChunks; ++j) {
+        const int c = 4 * lane + 256 * j;
+        if (c < D) *reinterpret_cast<f32x4*>(&red[wave][c]) = acc[j];
+    }
+    if (lane == 0) red_s[wave] = s;
+    __syncthreads();
+    const float inv = 1.f / ((red_s[0] + red_s[1]) + (red_s[2] + red_s[3]) + kEps);
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const float u = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) * inv;
+        uvec[c] = u;
+        user[(size_t)b * D + c] = u;
+    }
+    for (int l = threadIdx.x; l < len; l += 256) wl[l] *= inv;
+    __syncthreads();
+    // ---- B: dot scores + cross entropy with label 0 (dot_predictor.py:10, legommender.py:254,263)
+    for (int c = wave; c < C; c += 4) {
+        const float v = dot_row(uvec, items + (size_t)(b * C + c) * ldi, D, lane);
+        if (lane == 0) { sc[c] = v; scores[b * C + c] = v; }
+    }
+    __syncthreads();
+    float mx = -INFINITY, se = 0.f;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, sc[c]);
+    for (int c = 0; c < C; ++c) se += expf(sc[c] - mx);
+    if (threadIdx.x == 0 && loss != nullptr) atomicAdd(loss, (logf(se) + mx - sc[0]) / (float)B);
+    // ---- C: d scores -> d user, d candidates
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float du = 0.f;
+        const float u = uvec[d];
+        for (int c = 0; c < C; ++c) {
+            const float g = (expf(sc[c] - mx) / se - (c == 0 ? 1.f : 0.f)) * gscale;
+            du += g * items[(size_t)(b * C + c) * ldi + d];
+            d_items[(size_t)(b * C + c) * lddi + d] = g * u;
+        }
+        duvec[d] = du;
+    }
+    __syncthreads();
+    // ---- D: additive pool backward
+    float sdw = 0.f;
+    for (int l = wave; l < len; l += 4) {
+        const float dw = dot_row(duvec, xh + (size_t)l * ldi, D, lane);
+        sdw += wl[l] * dw;
+        if (lane == 0) dwl[l] = dw;
+    }
+    if (lane == 0) red_s[wave] = sdw;
+    __syncthreads();
+    sdw = (red_s[0] + red_s[1]) + (red_s[2] + red_s[3]);
+    f32x4 aw2[kMaxChunks], ab1[kMaxChunks];
+#pragma unroll
+    for (int j = 0; j < kMaxChunks; ++j) { aw2[j] = f32x4{0.f, 0.f, 0.f, 0.f}; ab1[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int l = wave; l < len; l += 4) {
+        const float w = wl[l];
+        const float da = w * (dwl[l] - sdw);
+#pragma unroll
+        for (int j = 0; j < kMaxChunks; ++j) {
+            const int c = 4 * lane + 256 * j;
+            if (c < D)
+                *reinterpret_cast<f32x4*>(d_items + (size_t)(BC + beg + l) * lddi + c) = w * *reinterpret_cast<const f32x4*>(duvec + c);
+            if (c < A) {
+                f32x4* tp = reinterpret_cast<f32x4*>(th + (size_t)l * ldt + c);
+                const f32x4 tv = *tp;
+                const f32x4 dpre = da * *reinterpret_cast<const f32x4*>(w2 + c) * (1.f - tv * tv);
+                aw2[j] += da * tv;
+                ab1[j] += dpre;
+                *tp = dpre;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kMaxChunks; ++j) {
+        const int c = 4 * lane + 256 * j;
+        if (c < A) *reinterpret_cast<f32x4*>(&red[wave][c]) = aw2[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < A; c += 256) atomicAdd(gw2 + c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kMaxChunks; ++j) {
+        const int c = 4 * lane + 256 * j;
+        if (c < A) *reinterpret_cast<f32x4*>(&red[wave][c]) = ab1[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < A; c += 256) atomicAdd(gb1 + c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+}
+
 // ------------------------------------------------------------------ Adam
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long long n, float step_size, float beta1, float beta2, float eps, float inv_sqrt_bc2, float gscale) {
@@ -676,6 +797,18 @@ extern "C" int lego_dot_ce_bwd(const float* user, int ldu, const float* items, i
     hipLaunchKernelGGL(dot_ce_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, user, ldu, items, ldi, scores, B, C, D, gscale,
                        guser, ldgu, gitems, ldgi);
     return check_launch("lego_dot_ce_bwd");
+}
+
+extern "C" int lego_user_tower_train(float* t_dpre, int ldt, const float* items, int ldi, const float* w2,
+                                     const int32_t* hist_off, int B, int C, int S, int D, int A, float gscale,
+                                     float* user, float* scores, float* loss, float* d_items, int lddi,
+                                     float* gw2, float* gb1, void* stream) {
+    LEGO_REQUIRE((D & 3) == 0 && (A & 3) == 0 && D <= 256 * kMaxChunks && A <= 256 * kMaxChunks && C <= kMaxCand && S < kMaxSegRows,
+                 "lego_user_tower_train: D=%d A=%d C=%d S=%d unsupported", D, A, C, S);
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(user_tower_train_kernel, dim3(B), dim3(256), 0, ST, t_dpre, ldt, items, ldi, w2, hist_off, B, C, D, A,
+                       gscale, user, scores, loss, d_items, lddi, gw2, gb1);
+    return check_launch("lego_user_tower_train");
 }
 
 extern "C" int lego_rowdot_fwd(const float* u, int ldu, const float* it, int ldi, int n, int D, float* out, void* stream) {

@@ -159,6 +159,12 @@ class _Base:
         self._forward_users(False)
         return self.user[:n].clone()
 
+    fused_grads = None      # set by bind_grads(): enables the fused user tower (forward writes its gradient partials)
+
+    def bind_grads(self, G):
+        """Let training forwards write gradient partials directly (TrainStep binds its flat grad views once)."""
+        self.fused_grads = G
+
     def grads_like(self):
         return {k: torch.zeros_like(v) for k, v in self.P.items() if v.dtype == torch.float32 and k not in self.frozen}
 
@@ -244,7 +250,7 @@ class NamlEngine(_Base):
         t.setdefault(tag, []).append((e0, e1))
 
     # ------------------------------------------------------------------ forward
-    def forward(self, cand, hist, hist_len, training=False, with_loss=True, planned=False):
+    def forward(self, cand, hist, hist_len, training=False, with_loss=True, planned=False, gloss=1.0):
         P, B, C, S, D, A, E0 = self.P, self.B, self.C, self.S, self.D, self.A, self.E0
         m, sb, sc = self._lanes()
         ev = self._evs
@@ -253,11 +259,26 @@ class NamlEngine(_Base):
         if not planned:
             self._plan(cand, hist, hist_len)
         self._forward_items(training)
-        self._forward_users(training)
-        # k11/k12: dot predictor + CE(label 0)
+        self._fused = bool(training and with_loss and self.fused_grads is not None)
         self.loss.zero_()
-        self.kk(m, None, "lego_dot_ce_fwd", _ptr(self.user), D, _ptr(self.items), D, B, C, D, _ptr(self.scores),
-                _ptr(self.loss) if with_loss else None)
+        if self._fused:
+            # tanh GEMM over the clicked-item rows, then ONE kernel for pool + dot + CE + their backward
+            G = self.fused_grads
+            self.kk(m, "additive_fwd_user", "lego_linear_fwd", _ptr(self.items, self.BC * D), D,
+                    _ptr(P["user_op.additive_attention.encoder.0.weight"]), D,
+                    _ptr(P["user_op.additive_attention.encoder.0.bias"]), _ptr(self.Tu), self.Au, B * S, self.cnt(3),
+                    self.Au, D, 2, None, None, None, None)
+            self.kk(m, None, "lego_user_tower_train", _ptr(self.Tu), self.Au, _ptr(self.items), D,
+                    _ptr(P["user_op.additive_attention.encoder.2.weight"]), _ptr(self.hist_off), B, C, S, D, self.Au,
+                    float(gloss) / B, _ptr(self.user), _ptr(self.scores), _ptr(self.loss), _ptr(self.d_items), D,
+                    _ptr(G["user_op.additive_attention.encoder.2.weight"]),
+                    _ptr(G["user_op.additive_attention.encoder.0.bias"]))
+            self._fused_gloss = float(gloss)
+        else:
+            self._forward_users(training)
+            # k11/k12: dot predictor + CE(label 0)
+            self.kk(m, None, "lego_dot_ce_fwd", _ptr(self.user), D, _ptr(self.items), D, B, C, D, _ptr(self.scores),
+                    _ptr(self.loss) if with_loss else None)
         self.step += 1 if training else 0
         return self.scores, self.loss
 
@@ -321,12 +342,16 @@ class NamlEngine(_Base):
         if training:
             self.step -= 1          # regenerate the masks of the forward pass of this step
         self._fork(ev[2], m, sb, sc)                 # everything enqueued so far (forward, grad zeroing) precedes the side work
-        self.kk(m, None, "lego_dot_ce_bwd", _ptr(self.user), D, _ptr(self.items), D, _ptr(self.scores), B, C, D,
-                float(gloss) / B, _ptr(self.d_user), D, _ptr(self.d_items), D)
         hist_items = _ptr(self.items, self.BC * D)
         d_hist_items = _ptr(self.d_items, self.BC * D)
-        self._pool_bwd(m, "user_op.", G, hist_items, d_hist_items, self.Tu, self.Au, self.hist_off, None, B, None,
-                       self.d_user, self.wu)
+        if getattr(self, "_fused", False):
+            if G is not self.fused_grads or abs(float(gloss) - self._fused_gloss) > 0:
+                raise _lib.LegoHipError("fused user tower: backward() must use the bound gradient buffers and the forward's gloss")
+        else:
+            self.kk(m, None, "lego_dot_ce_bwd", _ptr(self.user), D, _ptr(self.items), D, _ptr(self.scores), B, C, D,
+                    float(gloss) / B, _ptr(self.d_user), D, _ptr(self.d_items), D)
+            self._pool_bwd(m, "user_op.", G, hist_items, d_hist_items, self.Tu, self.Au, self.hist_off, None, B, None,
+                           self.d_user, self.wu)
         self._fork(ev[3], m, sb)
         # side: user dW1 += dpre^T . items      main: user-side dx += dpre . W1
         self.kk(sb, "additive_bwd_weight_user", "lego_linear_bwd_weight", _ptr(self.Tu), self.Au, hist_items, D,

@@ -97,6 +97,8 @@ class TrainStep:
             else:
                 raise ValueError(f"unknown model kind {kind!r} (the HIP path covers naml and nrms)")
             self.engines.append(e)
+        if micro == 1 and kind == "naml":
+            self.engines[0].bind_grads(self.fp.G)          # fused user tower: forward writes its gradient partials
         self.engine = self.engines[0]
         self.streams = [torch.cuda.Stream(dev) for _ in range(micro)] if micro > 1 else [None]
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)

@@ -400,3 +400,25 @@ def test_training_trajectory_matches_oracle(name):
     want = O.grouped_metrics(ref_scores.numpy(), labels, rows_user, names=("GAUC", "NDCG@10", "MRR"))
     for k in want:
         assert abs(got[k] - want[k]) < 5e-4, (k, got[k], want[k])
+
+
+def test_fused_user_tower_matches_unfused():
+    """Training forward with bound gradient buffers (fused pool + dot + CE + backward kernel) against the same
+    engine run unfused: identical loss, scores and every gradient."""
+    from legommenders_amd.engine import ItemTables, NamlEngine
+    dev = _dev()
+    meta, P, G, tables, batch, logits, loss = load_model_fixture("naml_glove_cfg1")
+    Pd = {k: torch.tensor(v).to(dev).contiguous() for k, v in P.items()}
+    tb = ItemTables(tables["title_tok"], tables["title_len"], tables["cat"], dev)
+    B, C = batch["cand"].shape
+    S = batch["hist"].shape[1]
+    ids = [torch.tensor(batch[k]).int().to(dev).contiguous() for k in ("cand", "hist", "hist_len")]
+    eng = NamlEngine(Pd, tb, B, C, S, p_proj=0.0, p_conv=0.0)
+    g_fused = eng.grads_like()
+    eng.bind_grads(g_fused)
+    scores, l = eng.forward(*ids, training=True)
+    eng.backward(g_fused)
+    torch.cuda.synchronize()
+    _close(scores.cpu(), logits, rtol=1e-4, atol=2e-5, what="fused logits")
+    assert abs(float(l) - loss) < 2e-5
+    _grads_close(g_fused, G, "fused")
