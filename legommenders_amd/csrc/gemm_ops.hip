@@ -143,7 +143,7 @@ static int launch(const GemmDims& d, const AL& a, const BL& b, const Epi& e0, in
     return check_launch(what);
 }
 
-using C128x128 = TileCfg<128, 128, 2, 4, true>;   // 8 waves of 64 x 32, staggered halves: best of scratch/gemm_variants.py at the path's row counts
+using C128x128 = TileCfg<128, 128, 2, 4, true>;   // 8 waves of 64 x 32, staggered halves: best of tools/gemm_variants.py at the path's row counts
 using C128x64 = TileCfg<128, 64, 4, 1>;
 using C64x128 = TileCfg<64, 128, 1, 4>;
 using C64x64 = TileCfg<64, 64, 2, 2>;
@@ -167,7 +167,7 @@ static int launch_rows(const GemmDims& d, const AL& a, const BL& b, const Epi& e
 }
 // TN: small [M,N] output, reduction over the (ragged) rows split along gridDim.z.  64 x 64 tiles: the
 // atomic traffic of the split-K epilogue is (#splits x M x N x 4 B), so small tiles (= fewer splits for
-// the same number of blocks) beat 128 x 128 by 1.6x here (scratch/tn_variants.py: 44 vs 70 us).
+// the same number of blocks) beat 128 x 128 by 1.6x here (tools/tn_variants.py: 44 vs 70 us).
 // (the three-tap conv product keeps 128 x 128: its shifted-row loader pays a rowinfo look-up per row and tile)
 template <class AL, class BL>
 static int launch_tn(const GemmDims& d, const AL& a, const BL& b, const Epi& e, int taps, hipStream_t st, const char* what) {

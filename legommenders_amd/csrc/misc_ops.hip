@@ -130,22 +130,37 @@ __global__ void plan_dense_kernel(const int* __restrict__ mask, int n, int L, in
 // ------------------------------------------------------------------ gather / scatter
 // out[r, :] = table[idx[r], :]; the rows are swept as one flat float4 stream so both the
 // 1200-B (E0 = 300) source rows and the destination are read/written in whole 16-B pieces.
-__global__ void gather_rows_kernel(const float* __restrict__ table, int ld_table, int w4,
-                                   const int* __restrict__ idx, int rows_cap, const int* __restrict__ rows_dyn,
-                                   float* __restrict__ out, int ld_out, int accumulate) {
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, int ld_table, int w4,
+                                                          const int* __restrict__ idx, int rows_cap,
+                                                          const int* __restrict__ rows_dyn, float* __restrict__ out, int ld_out,
+                                                          int accumulate) {
     const int rows = rows_dyn != nullptr ? min(rows_cap, *rows_dyn) : rows_cap;
     const long long total = (long long)rows * w4;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const int r = (int)(e / w4);
-        const int c = (int)(e - (long long)r * w4) * 4;
-        const int i = idx[r];
-        f32x4* dst = reinterpret_cast<f32x4*>(out + (size_t)r * ld_out + c);
-        if (accumulate) {
-            if (i >= 0) *dst += *reinterpret_cast<const f32x4*>(table + (size_t)i * ld_table + c);
-        } else {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (i >= 0) v = *reinterpret_cast<const f32x4*>(table + (size_t)i * ld_table + c);
-            *dst = v;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    constexpr int U = 4;                                // 4 independent 16-B row pieces in flight per lane
+    for (long long e0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += U * stride) {
+        f32x4 v[U];
+        f32x4* dst[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long e = e0 + u * stride;
+            live[u] = false;
+            dst[u] = nullptr;
+            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (e < total) {
+                const int r = (int)(e / w4);
+                const int c = (int)(e - (long long)r * w4) * 4;
+                const int i = idx[r];
+                dst[u] = reinterpret_cast<f32x4*>(out + (size_t)r * ld_out + c);
+                if (i >= 0) { v[u] = *reinterpret_cast<const f32x4*>(table + (size_t)i * ld_table + c); live[u] = true; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (dst[u] == nullptr) continue;
+            if (accumulate) { if (live[u]) *dst[u] += v[u]; }
+            else *dst[u] = v[u];
         }
     }
 }
@@ -694,7 +709,8 @@ extern "C" int lego_gather_rows(const float* table, int ld_table, int width, con
     LEGO_REQUIRE((width & 3) == 0 && (ld_table & 3) == 0 && (ld_out & 3) == 0, "lego_gather_rows: width/ld must be multiples of 4");
     if (rows_cap <= 0) return 0;
     const long long total = (long long)rows_cap * (width / 4);
-    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    const long long want = (total + 4 * 256 - 1) / (4 * 256);
+    const int blocks = (int)(want < 8192 ? (want > 0 ? want : 1) : 8192);
     hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, ST, table, ld_table, width / 4, idx, rows_cap, rows_dyn, out, ld_out, accumulate);
     return check_launch("lego_gather_rows");
 }
