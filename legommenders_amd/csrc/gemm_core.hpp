@@ -28,6 +28,7 @@ struct KcRows {            // plain rows, optionally behind a device row offset
     const float* p; int ld; int ext; int K; const int* row_off_dyn;
     struct Row { const float* base; };
     __device__ __forceinline__ void prepare(int) { if (row_off_dyn != nullptr) p += (size_t)(*row_off_dyn) * ld; }
+    __device__ __forceinline__ void tile(int) {}
     __device__ __forceinline__ Row row(int r) const { return {r < ext ? p + (size_t)r * ld : nullptr}; }
     __device__ __forceinline__ f32x4 get(const Row& R, int k) const {
         if (R.base != nullptr && k < K) return *reinterpret_cast<const f32x4*>(R.base + k);
@@ -37,32 +38,39 @@ struct KcRows {            // plain rows, optionally behind a device row offset
 
 struct KcConvA {           // logical K = 3*C: k -> (tap = k / C, c = k % C); source row r + dir*(tap-1)
     const float* p; int ld; int ext; int K; const int* rowinfo; int C; int dir;
+    int need, koff; ptrdiff_t shift;           // per-k-tile scalars (C % BK == 0: a tile never straddles two taps)
     struct Row { const float* base; int flags; };
     __device__ __forceinline__ void prepare(int) {}
+    __device__ __forceinline__ void tile(int k0) {
+        const int tap = k0 / C;
+        const int s = dir * (tap - 1);
+        koff = tap * C;
+        shift = (ptrdiff_t)s * ld;
+        need = s == 0 ? 0 : (s < 0 ? RI_LEFT : RI_RIGHT);
+    }
     __device__ __forceinline__ Row row(int r) const {
         if (r >= ext) return {nullptr, 0};
         return {p + (size_t)r * ld, rowinfo[r]};
     }
     __device__ __forceinline__ f32x4 get(const Row& R, int k) const {
-        if (R.base == nullptr || k >= K) return f32x4{0.f, 0.f, 0.f, 0.f};
-        const int tap = k / C;
-        const int c = k - tap * C;
-        const int s = dir * (tap - 1);
-        const bool ok = (s == 0) || (s < 0 ? (R.flags & RI_LEFT) != 0 : (R.flags & RI_RIGHT) != 0);
-        if (!ok) return f32x4{0.f, 0.f, 0.f, 0.f};
-        return *reinterpret_cast<const f32x4*>(R.base + (ptrdiff_t)s * ld + c);
+        if (R.base == nullptr || k >= K || (need != 0 && !(R.flags & need))) return f32x4{0.f, 0.f, 0.f, 0.f};
+        return *reinterpret_cast<const f32x4*>(R.base + shift + (k - koff));
     }
 };
 
 struct KcTapW {            // B of the conv forward: B[o][tap*C + c] = wt[tap][o][c]  (tap-major packed weights)
     const float* p; int ld /*= C*/; int ext /*= Dout*/; int K; int C; size_t tap_stride /*= Dout*C*/;
+    ptrdiff_t toff;                            // per-k-tile: tap * tap_stride - tap * C
     struct Row { const float* base; };
     __device__ __forceinline__ void prepare(int) {}
+    __device__ __forceinline__ void tile(int k0) {
+        const int tap = k0 / C;
+        toff = (ptrdiff_t)tap * (ptrdiff_t)tap_stride - (ptrdiff_t)tap * C;
+    }
     __device__ __forceinline__ Row row(int r) const { return {r < ext ? p + (size_t)r * ld : nullptr}; }
     __device__ __forceinline__ f32x4 get(const Row& R, int k) const {
         if (R.base == nullptr || k >= K) return f32x4{0.f, 0.f, 0.f, 0.f};
-        const int tap = k / C;
-        return *reinterpret_cast<const f32x4*>(R.base + (size_t)tap * tap_stride + (k - tap * C));
+        return *reinterpret_cast<const f32x4*>(R.base + toff + k);
     }
 };
 
@@ -71,6 +79,7 @@ struct McRows {
     const float* p; int ld; int ext; int K; const int* row_off_dyn;
     struct Row {};
     __device__ __forceinline__ void prepare(int) { if (row_off_dyn != nullptr) p += (size_t)(*row_off_dyn) * ld; }
+    __device__ __forceinline__ void tile(int) {}
     __device__ __forceinline__ f32x4 get(int kk, int c) const {
         if (kk < K && c < ext) return *reinterpret_cast<const f32x4*>(p + (size_t)kk * ld + c);
         return f32x4{0.f, 0.f, 0.f, 0.f};
@@ -81,6 +90,7 @@ struct McShiftRows {       // row kk + (tap-1) of p, valid when the plan says ro
     const float* p; int ld; int ext; int K; const int* rowinfo; int s;
     struct Row {};
     __device__ __forceinline__ void prepare(int tap) { s = tap - 1; }
+    __device__ __forceinline__ void tile(int) {}
     __device__ __forceinline__ f32x4 get(int kk, int c) const {
         if (kk < K && c < ext) {
             const int f = rowinfo[kk];
@@ -169,6 +179,8 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_kernel(GemmDims dims, ALoa
 
     f32x4 sa[SA::kN], sb[SB::kN];
     auto fetch = [&](int k0) {
+        la.tile(k0);
+        lb.tile(k0);
         if constexpr (A_MC) {
             constexpr int PER = BM / 4, STEP = NT / PER;
 #pragma unroll

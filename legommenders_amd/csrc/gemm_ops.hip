@@ -264,8 +264,8 @@ extern "C" int lego_conv3_fwd(const float* h, int ldh, const float* wt, const fl
     if (R_cap <= 0) return 0;
     // y[r,o] = relu(sum_tap sum_c h[r+tap-1,c] wt[tap][o][c] + b[o]): NT product with K = 3*Din
     GemmDims d{R_cap, Dout, 3 * Din, R_dyn, nullptr, 1};
-    KcConvA a{h, ldh, R_cap, 3 * Din, rowinfo, Din, +1};
-    KcTapW b{wt, Din, Dout, 3 * Din, Din, (size_t)Dout * Din};
+    KcConvA a{h, ldh, R_cap, 3 * Din, rowinfo, Din, +1, 0, 0, 0};
+    KcTapW b{wt, Din, Dout, 3 * Din, Din, (size_t)Dout * Din, 0};
     Epi e = make_epi(y, ldy);
     e.bias = bias; e.act = 1; e.rowinfo = rowinfo;
     set_drop(e, drop, Dout);
@@ -280,7 +280,7 @@ extern "C" int lego_conv3_bwd_data(const float* gy, int ldg, const float* wt, co
     if (R_cap <= 0) return 0;
     // dh[r,c] = sum_tap sum_o gy[r-(tap-1),o] wt[tap][o][c]: NN product, K = 3*Dout, wt is [3*Dout][Din] row-major
     GemmDims d{R_cap, Din, 3 * Dout, R_dyn, nullptr, 1};
-    KcConvA a{gy, ldg, R_cap, 3 * Dout, rowinfo, Dout, -1};
+    KcConvA a{gy, ldg, R_cap, 3 * Dout, rowinfo, Dout, -1, 0, 0, 0};
     McRows b{wt, Din, Din, 3 * Dout, nullptr};
     Epi e = make_epi(dh, lddh);
     e.rowinfo = rowinfo; e.colsum = colsum;
