@@ -94,11 +94,12 @@ int lego_conv3_pack(const float* w /*[Dout,Din,3]*/, float* wt /*[3,Dout,Din]*/,
 int lego_conv3_unpack_add(const float* dwt /*[3,Dout,Din]*/, float* dw /*[Dout,Din,3], +=*/, int Dout, int Din, void* stream);
 int lego_conv3_fwd(const float* h, int ldh, const float* wt, const float* bias, const int32_t* rowinfo,
                    float* y, int ldy, int R_cap, const int32_t* R_dyn, int Dout, int Din,
-                   const lego_dropout* drop, void* stream);
+                   const lego_dropout* drop, int mask_rows /*0: every row is live (ragged plan), skip the live-bit loads*/,
+                   void* stream);
 /* dh = live*dropout_in * sum_tap gy[r-(tap-1)] . Wt[tap];  colsum(dh) -> bias grad of the input projection */
 int lego_conv3_bwd_data(const float* gy, int ldg, const float* wt, const int32_t* rowinfo,
                         float* dh, int lddh, int R_cap, const int32_t* R_dyn, int Dout, int Din,
-                        const lego_dropout* drop_in, float* colsum, void* stream);
+                        const lego_dropout* drop_in, float* colsum, int mask_rows, void* stream);
 /* dwt[tap] += gy^T . h[r+tap-1] */
 int lego_conv3_bwd_weight(const float* gy, int ldg, const float* h, int ldh, const int32_t* rowinfo,
                           float* dwt, int R_cap, const int32_t* R_dyn, int Dout, int Din, void* stream);

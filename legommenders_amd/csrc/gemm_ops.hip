@@ -258,7 +258,7 @@ extern "C" int lego_linear_bwd_weight(const float* g, int ldg, const float* x, i
 
 extern "C" int lego_conv3_fwd(const float* h, int ldh, const float* wt, const float* bias, const int32_t* rowinfo,
                               float* y, int ldy, int R_cap, const int32_t* R_dyn, int Dout, int Din,
-                              const lego_dropout* drop, void* stream) {
+                              const lego_dropout* drop, int mask_rows, void* stream) {
     CHECK4(ldh);
     LEGO_REQUIRE(Din % BK == 0, "lego_conv3_fwd: Din=%d must be a multiple of %d", Din, BK);
     if (R_cap <= 0) return 0;
@@ -269,12 +269,13 @@ extern "C" int lego_conv3_fwd(const float* h, int ldh, const float* wt, const fl
     Epi e = make_epi(y, ldy);
     e.bias = bias; e.act = 1; e.rowinfo = rowinfo;
     set_drop(e, drop, Dout);
+    if (!mask_rows) return launch_rows<false, EpiPlain>(d, a, b, e, (hipStream_t)stream, "lego_conv3_fwd");
     return launch_rows<false, EpiLive>(d, a, b, e, (hipStream_t)stream, "lego_conv3_fwd");
 }
 
 extern "C" int lego_conv3_bwd_data(const float* gy, int ldg, const float* wt, const int32_t* rowinfo,
                                    float* dh, int lddh, int R_cap, const int32_t* R_dyn, int Dout, int Din,
-                                   const lego_dropout* drop_in, float* colsum, void* stream) {
+                                   const lego_dropout* drop_in, float* colsum, int mask_rows, void* stream) {
     CHECK4(ldg); CHECK4(Din);
     LEGO_REQUIRE(Dout % BK == 0, "lego_conv3_bwd_data: Dout=%d must be a multiple of %d", Dout, BK);
     if (R_cap <= 0) return 0;
@@ -285,6 +286,7 @@ extern "C" int lego_conv3_bwd_data(const float* gy, int ldg, const float* wt, co
     Epi e = make_epi(dh, lddh);
     e.rowinfo = rowinfo; e.colsum = colsum;
     set_drop(e, drop_in, Din);
+    if (!mask_rows) return launch_rows<true, EpiPlain>(d, a, b, e, (hipStream_t)stream, "lego_conv3_bwd_data");
     return launch_rows<true, EpiLive>(d, a, b, e, (hipStream_t)stream, "lego_conv3_bwd_data");
 }
 

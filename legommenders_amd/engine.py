@@ -308,11 +308,11 @@ class NamlEngine(_Base):
                 _ptr(self.row_tok), self.Rc, self.cnt(0), _ptr(self.X), E0, 0)
         self.kk(m, "proj_fwd", "lego_linear_fwd", _ptr(self.X), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
                 _ptr(P["embedding_vocab_table.glove.linear.bias"]), _ptr(self.H), D, self.Rc, self.cnt(0), D, E0, 0,
-                _ptr(self.rowinfo), self.drop(self.p_proj, SITE_PROJ, training), None, None)
+                None, self.drop(self.p_proj, SITE_PROJ, training), None, None)      # every planned row is live
         self._fork(ev[1], sb, m)                    # conv needs the packed weights; the pool needs the category rows
         # k3: conv + relu + mask + dropout (cnn_operator.py:54-57)
         self.kk(m, "conv3_fwd", "lego_conv3_fwd", _ptr(self.H), D, _ptr(self.wt), _ptr(P["item_op.cnn.bias"]), _ptr(self.rowinfo),
-                _ptr(self.Y), D, self.Rc, self.cnt(0), D, D, self.drop(self.p_conv, SITE_CONV, training))
+                _ptr(self.Y), D, self.Rc, self.cnt(0), D, D, self.drop(self.p_conv, SITE_CONV, training), 0)
         # k5: additive attention pool over [title tokens..., category] (attention.py:31-38)
         self._additive_fwd(m, "item_op.", _ptr(self.Y), self.Ryc, self.cnt(2), self.Tt, A, self.seg_off, self.cnt(0),
                            self.NIc, self.cnt(1), self.items, self.wrow)
@@ -389,7 +389,7 @@ class NamlEngine(_Base):
         # ---- main: conv data gradient -> projection weight gradient
         self.kk(m, "conv3_bwd_data", "lego_conv3_bwd_data", _ptr(self.dY), D, _ptr(self.wt), _ptr(self.rowinfo), _ptr(self.dH), D,
                 self.Rc, self.cnt(0), D, D, self.drop(self.p_proj, SITE_PROJ, training),
-                _ptr(G["embedding_vocab_table.glove.linear.bias"]))
+                _ptr(G["embedding_vocab_table.glove.linear.bias"]), 0)
         self.kk(m, "proj_bwd_weight", "lego_linear_bwd_weight", _ptr(self.dH), D, _ptr(self.X), E0,
                 _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Rc, self.cnt(0), D, E0, None, None)
         self._fork(ev[6], sb, m)

@@ -112,7 +112,7 @@ def conv3_fwd(h, wt, b, plan: DensePlan, drop=None):
     Dout = wt.shape[1]
     y = torch.empty(R, Dout, dtype=torch.float32, device=h.device)
     call("lego_conv3_fwd", _ptr(h), Din, _ptr(wt), _ptr(_f32(b)), _ptr(plan.rowinfo), _ptr(y), Dout, R, None, Dout, Din,
-         _drop(drop), _stream())
+         _drop(drop), 1, _stream())
     return y
 
 
@@ -121,7 +121,7 @@ def conv3_bwd_data(gy, wt, plan: DensePlan, Din, drop_in=None, colsum_out=None):
     R, Dout = gy.shape
     dh = torch.empty(R, Din, dtype=torch.float32, device=gy.device)
     call("lego_conv3_bwd_data", _ptr(gy), Dout, _ptr(wt), _ptr(plan.rowinfo), _ptr(dh), Din, R, None, Dout, Din,
-         _drop(drop_in), _ptr(colsum_out), _stream())
+         _drop(drop_in), _ptr(colsum_out), 1, _stream())
     return dh
 
 
