@@ -91,7 +91,7 @@ int lego_colsum(const float* x, int ldx, int M_cap, const int32_t* M_dyn, const 
  * -> ReLU -> *mask -> Dropout as an implicit GEMM over token rows (taps = rows r-1,r,r+1 of the
  * same item, from rowinfo).  Wt is the tap-major copy [3][Dout][Din] made by lego_conv3_pack. */
 int lego_conv3_pack(const float* w /*[Dout,Din,3]*/, float* wt /*[3,Dout,Din]*/, int Dout, int Din, void* stream);
-int lego_conv3_unpack_add(const float* dwt /*[3,Dout,Din]*/, float* dw /*[Dout,Din,3], +=*/, int Dout, int Din, void* stream);
+int lego_conv3_unpack_add(float* dwt /*[3,Dout,Din], cleared on return*/, float* dw /*[Dout,Din,3], +=*/, int Dout, int Din, void* stream);
 int lego_conv3_fwd(const float* h, int ldh, const float* wt, const float* bias, const int32_t* rowinfo,
                    float* y, int ldy, int R_cap, const int32_t* R_dyn, int Dout, int Din,
                    const lego_dropout* drop, int mask_rows /*0: every row is live (ragged plan), skip the live-bit loads*/,
@@ -158,9 +158,10 @@ int lego_mhsa_core_bwd(const float* qkv, int ldq, const int32_t* seg_off, int n_
                        const lego_dropout* drop, int rows_cap, float* gqkv, int ldgq, void* stream);
 
 /* ---- a13: torch.optim.Adam (defaults, base_lego.py:201-204) over one flat fp32 buffer;
- * grad is multiplied by grad_scale first (1/world after the RCCL all-reduce). step is 1-based. */
-int lego_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                   float eps, int step, float grad_scale, void* stream);
+ * grad is multiplied by grad_scale first (1/world after the RCCL all-reduce). step is 1-based.
+ * zero_grad != 0: g is cleared as it is consumed (optimizer.zero_grad() of the next step, trainer.py:199). */
+int lego_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                   float eps, int step, float grad_scale, int zero_grad, void* stream);
 
 /* ---- a11: negative sampling of Resampler.rebuild_candidates (loader/resampler.py:159-171) on
  * device: cand[b,0] = positive; min(K,len) distinct draws from the user's true-negative list,

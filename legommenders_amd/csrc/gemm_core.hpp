@@ -22,39 +22,47 @@ constexpr int KC_LD = BK + 4;   // +16 B pad: the 16 lanes of a ds_read_b128 gro
 
 // ------------------------------------------------------------------ operand loaders
 // Every loader has: ext (rows of a KC operand / columns of an MC operand), K (reduction bound, set by
-// the kernel to the end of its k range) and prepare(tap), called once in the kernel prologue.
+// the kernel to the end of its k range), prepare(tap), called once in the kernel prologue, and tile(k0),
+// called once per k tile.
+// The element loads are BRANCH-FREE: load() reads from an address clamped into the operand and keep() says
+// whether the value counts; the kernels apply the zeroing select when they write the staged registers to LDS
+// (a tile later), so the k loop stays one basic block and nothing waits on a load where it is issued.  Rows / columns beyond ext are NOT zeroed: they
+// only feed output elements that the epilogue never stores.  Requires ext >= 1 and K >= 4.
+__device__ __forceinline__ f32x4 zero_unless(bool keep, f32x4 v) {
+    return f32x4{keep ? v[0] : 0.f, keep ? v[1] : 0.f, keep ? v[2] : 0.f, keep ? v[3] : 0.f};
+}
+
 // KC loaders: tile row -> matrix row, k contiguous.  row(r) is evaluated once per thread.
 struct KcRows {            // plain rows, optionally behind a device row offset
     const float* p; int ld; int ext; int K; const int* row_off_dyn;
     struct Row { const float* base; };
     __device__ __forceinline__ void prepare(int) { if (row_off_dyn != nullptr) p += (size_t)(*row_off_dyn) * ld; }
     __device__ __forceinline__ void tile(int) {}
-    __device__ __forceinline__ Row row(int r) const { return {r < ext ? p + (size_t)r * ld : nullptr}; }
-    __device__ __forceinline__ f32x4 get(const Row& R, int k) const {
-        if (R.base != nullptr && k < K) return *reinterpret_cast<const f32x4*>(R.base + k);
-        return f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    __device__ __forceinline__ Row row(int r) const { return {p + (size_t)min(r, ext - 1) * ld}; }
+    __device__ __forceinline__ f32x4 load(const Row& R, int k) const { return *reinterpret_cast<const f32x4*>(R.base + min(k, K - 4)); }
+    __device__ __forceinline__ bool keep(const Row&, int k) const { return k < K; }
 };
 
 struct KcConvA {           // logical K = 3*C: k -> (tap = k / C, c = k % C); source row r + dir*(tap-1)
     const float* p; int ld; int ext; int K; const int* rowinfo; int C; int dir;
-    int need, koff; ptrdiff_t shift;           // per-k-tile scalars (C % BK == 0: a tile never straddles two taps)
+    int need, koff, shift;                     // per-k-tile scalars (C % BK == 0: a tile never straddles two taps)
     struct Row { const float* base; int flags; };
     __device__ __forceinline__ void prepare(int) {}
     __device__ __forceinline__ void tile(int k0) {
         const int tap = k0 / C;
         const int s = dir * (tap - 1);
         koff = tap * C;
-        shift = (ptrdiff_t)s * ld;
+        shift = s * ld;
         need = s == 0 ? 0 : (s < 0 ? RI_LEFT : RI_RIGHT);
     }
     __device__ __forceinline__ Row row(int r) const {
-        if (r >= ext) return {nullptr, 0};
-        return {p + (size_t)r * ld, rowinfo[r]};
+        const int rc = min(r, ext - 1);
+        return {p + (size_t)rc * ld, rowinfo[rc]};
     }
-    __device__ __forceinline__ f32x4 get(const Row& R, int k) const {
-        if (R.base == nullptr || k >= K || (need != 0 && !(R.flags & need))) return f32x4{0.f, 0.f, 0.f, 0.f};
-        return *reinterpret_cast<const f32x4*>(R.base + shift + (k - koff));
+    // keep: the plan says the neighbour row exists (same item)
+    __device__ __forceinline__ bool keep(const Row& R, int) const { return need == 0 || (R.flags & need) != 0; }
+    __device__ __forceinline__ f32x4 load(const Row& R, int k) const {
+        return *reinterpret_cast<const f32x4*>(R.base + (keep(R, k) ? shift : 0) + (k - koff));
     }
 };
 
@@ -67,22 +75,20 @@ struct KcTapW {            // B of the conv forward: B[o][tap*C + c] = wt[tap][o
         const int tap = k0 / C;
         toff = (ptrdiff_t)tap * (ptrdiff_t)tap_stride - (ptrdiff_t)tap * C;
     }
-    __device__ __forceinline__ Row row(int r) const { return {r < ext ? p + (size_t)r * ld : nullptr}; }
-    __device__ __forceinline__ f32x4 get(const Row& R, int k) const {
-        if (R.base == nullptr || k >= K) return f32x4{0.f, 0.f, 0.f, 0.f};
-        return *reinterpret_cast<const f32x4*>(R.base + toff + k);
-    }
+    __device__ __forceinline__ Row row(int r) const { return {p + (size_t)min(r, ext - 1) * ld}; }
+    __device__ __forceinline__ f32x4 load(const Row& R, int k) const { return *reinterpret_cast<const f32x4*>(R.base + toff + k); }
+    __device__ __forceinline__ bool keep(const Row&, int) const { return true; }
 };
 
-// MC loaders: the reduction index is the memory row, tile columns are contiguous.
+// MC loaders: the reduction index is the memory row, tile columns are contiguous (ext % 4 == 0).
 struct McRows {
     const float* p; int ld; int ext; int K; const int* row_off_dyn;
     struct Row {};
     __device__ __forceinline__ void prepare(int) { if (row_off_dyn != nullptr) p += (size_t)(*row_off_dyn) * ld; }
     __device__ __forceinline__ void tile(int) {}
-    __device__ __forceinline__ f32x4 get(int kk, int c) const {
-        if (kk < K && c < ext) return *reinterpret_cast<const f32x4*>(p + (size_t)kk * ld + c);
-        return f32x4{0.f, 0.f, 0.f, 0.f};
+    __device__ __forceinline__ f32x4 load(int kk, int c, bool& keep) const {
+        keep = kk < K;
+        return *reinterpret_cast<const f32x4*>(p + (size_t)min(kk, K - 1) * ld + min(c, ext - 4));
     }
 };
 
@@ -91,13 +97,12 @@ struct McShiftRows {       // row kk + (tap-1) of p, valid when the plan says ro
     struct Row {};
     __device__ __forceinline__ void prepare(int tap) { s = tap - 1; }
     __device__ __forceinline__ void tile(int) {}
-    __device__ __forceinline__ f32x4 get(int kk, int c) const {
-        if (kk < K && c < ext) {
-            const int f = rowinfo[kk];
-            const bool ok = (s == 0) || (s < 0 ? (f & RI_LEFT) != 0 : (f & RI_RIGHT) != 0);
-            if (ok) return *reinterpret_cast<const f32x4*>(p + (ptrdiff_t)(kk + s) * ld + c);
-        }
-        return f32x4{0.f, 0.f, 0.f, 0.f};
+    __device__ __forceinline__ f32x4 load(int kk, int c, bool& keep) const {
+        const int kc = min(kk, K - 1);
+        const int f = rowinfo[kc];
+        const bool ok = (s == 0) || (s < 0 ? (f & RI_LEFT) != 0 : (f & RI_RIGHT) != 0);
+        keep = ok && kk < K;
+        return *reinterpret_cast<const f32x4*>(p + (ptrdiff_t)(kc + (ok ? s : 0)) * ld + min(c, ext - 4));
     }
 };
 
@@ -178,24 +183,25 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_kernel(GemmDims dims, ALoa
     }
 
     f32x4 sa[SA::kN], sb[SB::kN];
+    bool pa[SA::kN], pb[SB::kN];
     auto fetch = [&](int k0) {
         la.tile(k0);
         lb.tile(k0);
         if constexpr (A_MC) {
             constexpr int PER = BM / 4, STEP = NT / PER;
 #pragma unroll
-            for (int j = 0; j < SA::kN; ++j) sa[j] = la.get(k0 + tid / PER + STEP * j, m0 + (tid % PER) * 4);
+            for (int j = 0; j < SA::kN; ++j) sa[j] = la.load(k0 + tid / PER + STEP * j, m0 + (tid % PER) * 4, pa[j]);
         } else {
 #pragma unroll
-            for (int j = 0; j < SA::kN; ++j) sa[j] = la.get(ra[j], k0 + (tid & 7) * 4);
+            for (int j = 0; j < SA::kN; ++j) { sa[j] = la.load(ra[j], k0 + (tid & 7) * 4); pa[j] = la.keep(ra[j], k0 + (tid & 7) * 4); }
         }
         if constexpr (B_MC) {
             constexpr int PER = BN / 4, STEP = NT / PER;
 #pragma unroll
-            for (int j = 0; j < SB::kN; ++j) sb[j] = lb.get(k0 + tid / PER + STEP * j, n0 + (tid % PER) * 4);
+            for (int j = 0; j < SB::kN; ++j) sb[j] = lb.load(k0 + tid / PER + STEP * j, n0 + (tid % PER) * 4, pb[j]);
         } else {
 #pragma unroll
-            for (int j = 0; j < SB::kN; ++j) sb[j] = lb.get(rb[j], k0 + (tid & 7) * 4);
+            for (int j = 0; j < SB::kN; ++j) { sb[j] = lb.load(rb[j], k0 + (tid & 7) * 4); pb[j] = lb.keep(rb[j], k0 + (tid & 7) * 4); }
         }
     };
     auto commit = [&](float* A_, float* B_) {
@@ -203,21 +209,21 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_kernel(GemmDims dims, ALoa
             constexpr int PER = BM / 4, STEP = NT / PER;
 #pragma unroll
             for (int j = 0; j < SA::kN; ++j)
-                *reinterpret_cast<f32x4*>(A_ + (tid / PER + STEP * j) * BM + (tid % PER) * 4) = sa[j];
+                *reinterpret_cast<f32x4*>(A_ + (tid / PER + STEP * j) * BM + (tid % PER) * 4) = zero_unless(pa[j], sa[j]);
         } else {
 #pragma unroll
             for (int j = 0; j < SA::kN; ++j)
-                *reinterpret_cast<f32x4*>(A_ + ((tid >> 3) + RS * j) * KC_LD + (tid & 7) * 4) = sa[j];
+                *reinterpret_cast<f32x4*>(A_ + ((tid >> 3) + RS * j) * KC_LD + (tid & 7) * 4) = zero_unless(pa[j], sa[j]);
         }
         if constexpr (B_MC) {
             constexpr int PER = BN / 4, STEP = NT / PER;
 #pragma unroll
             for (int j = 0; j < SB::kN; ++j)
-                *reinterpret_cast<f32x4*>(B_ + (tid / PER + STEP * j) * BN + (tid % PER) * 4) = sb[j];
+                *reinterpret_cast<f32x4*>(B_ + (tid / PER + STEP * j) * BN + (tid % PER) * 4) = zero_unless(pb[j], sb[j]);
         } else {
 #pragma unroll
             for (int j = 0; j < SB::kN; ++j)
-                *reinterpret_cast<f32x4*>(B_ + ((tid >> 3) + RS * j) * KC_LD + (tid & 7) * 4) = sb[j];
+                *reinterpret_cast<f32x4*>(B_ + ((tid >> 3) + RS * j) * KC_LD + (tid & 7) * 4) = zero_unless(pb[j], sb[j]);
         }
     };
 

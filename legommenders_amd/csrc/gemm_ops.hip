@@ -4,7 +4,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include "../../include/lego_hip.h"
-#include "gemm_core.hpp"
+#include "gemm_strip.hpp"
 
 namespace lego {
 
@@ -108,6 +108,66 @@ struct EpiT : EpiArgs {
             }
         }
     }
+    // 16 x 16 fragments of the row-strip kernel: lane holds column l16 x rows 4*g4 + {0..3} of fragment (a, b)
+    template <int NF>
+    __device__ __forceinline__ void run16(f32x4 (&acc)[NF][2], int m_base, int m_end, int n_base, int l16, int g4) {
+        int col[2], colc[2];
+        float bcol[2], csum[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            col[b] = n_base + b * 16 + l16;
+            colc[b] = min(col[b], N - 1);
+            bcol[b] = bias != nullptr ? bias[colc[b]] : 0.f;
+            csum[b] = 0.f;
+        }
+#pragma unroll
+        for (int a = 0; a < NF; ++a) {
+            const int r0 = m_base + a * 16 + 4 * g4;
+            if (r0 >= m_end) continue;
+            int ra[4];
+            bool live[4];
+            float old[2][4], ref[2][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[i] = min(r0 + i, m_end - 1) + row_off;
+                live[i] = ROWINFO ? (rowinfo[ra[i]] & RI_LIVE) != 0 : true;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    old[b][i] = ACCUM ? C[(size_t)ra[i] * ldc + colc[b]] : 0.f;
+                    ref[b][i] = RELUREF ? relu_ref[(size_t)ra[i] * ld_ref + colc[b]] : 1.f;
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                float ds[4];
+                dropout_scale4(drop, r0 + row_off, col[b], drop_cols, ds);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float x = acc[a][b][i] + bcol[b];
+                    if (act == 1) x = fmaxf(x, 0.f);
+                    else if (act == 2) x = tanhf(x);
+                    if (ROWINFO && !live[i]) x = 0.f;
+                    x *= ds[i];
+                    if (ACCUM) x += old[b][i];
+                    if (RELUREF) x = ref[b][i] > 0.f ? x * relu_scale : 0.f;
+                    if (r0 + i < m_end && col[b] < N) {
+                        float* dst = C + (size_t)ra[i] * ldc + col[b];
+                        if (ATOMIC) atomicAdd(dst, x); else *dst = x;
+                        csum[b] += x;
+                    }
+                }
+            }
+        }
+        if (colsum != nullptr) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                float s = csum[b];
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                if (g4 == 0 && col[b] < N) atomicAdd(colsum + col[b], s);
+            }
+        }
+    }
 };
 
 using Epi = EpiArgs;      // host-side view; the kernel is instantiated with one EpiT<...> kind
@@ -155,9 +215,37 @@ using EpiAccum = EpiT<false, true, false, false>;
 using EpiAccumRelu = EpiT<false, true, true, false>;
 using EpiAtomic = EpiT<false, false, false, true>;
 
+static int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+// one block per CU, each a strip of ceil(M / #CU) rows x all N <= 256 columns (gemm_strip.hpp)
+template <bool B_MC, class EK, class AL, class BL, int DBG = 0>
+static int launch_strip(const GemmDims& d, const AL& a, const BL& b, const Epi& e0, hipStream_t st, const char* what) {
+    EK e;
+    static_cast<EpiArgs&>(e) = e0;
+    auto k = strip_kernel<B_MC, AL, BL, EK, DBG>;
+    constexpr size_t lds = strip_lds_bytes<B_MC>();
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(num_cus()), dim3(STRIP_THREADS), lds, st, d, a, b, e);
+    return check_launch(what);
+}
+
 template <bool B_MC, class EK, class AL, class BL>
 static int launch_rows(const GemmDims& d, const AL& a, const BL& b, const Epi& e, hipStream_t st, const char* what) {
     const int tm = (d.M + 127) / 128;
+    if (d.N <= STRIP_BN && d.M >= 32 * num_cus()) return launch_strip<B_MC, EK>(d, a, b, e, st, what);
     if (tm * ((d.N + 127) / 128) < 128) {         // few row tiles (user / category side): 64-row tiles fill more CUs
         if (d.N > 64) return launch<C64x128, false, B_MC, EK>(d, a, b, e, (d.M + 63) / 64, (d.N + 127) / 128, 1, st, what);
         return launch<C64x64, false, B_MC, EK>(d, a, b, e, (d.M + 63) / 64, (d.N + 63) / 64, 1, st, what);
@@ -323,6 +411,9 @@ extern "C" int lego_debug_gemm_nt(int variant, const float* x, const float* W, c
         case 6: return launch<TileCfg<64, 256, 1, 4>, false, false, EpiPlain>(d, a, b, e, (M + 63) / 64, (N + 255) / 256, 1, st, "dbg6");
         case 7: return launch<TileCfg<128, 128, 4, 2, true>, false, false, EpiPlain>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, 1, st, "dbg7");
         case 8: return launch<TileCfg<128, 128, 2, 4, true>, false, false, EpiPlain>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, 1, st, "dbg8");
+        case 9: return launch_strip<false, EpiPlain>(d, a, b, e, st, "dbg9");
+        case 10: return launch_strip<false, EpiPlain, KcRows, KcRows, 1>(d, a, b, e, st, "dbg10");
+        case 11: return launch_strip<false, EpiPlain, KcRows, KcRows, 3>(d, a, b, e, st, "dbg11");
         default: return set_error("lego_debug_gemm_nt: unknown variant %d", variant);
     }
 }

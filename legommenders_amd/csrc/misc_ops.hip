@@ -206,26 +206,42 @@ __global__ void scatter_add_rows_kernel(float* grad_table, int ld_table, int wid
 }
 
 // Scatter-add into a SMALL table (category: 18 rows, ConcatInputer specials: 3 rows): every source row hits one of a
-// handful of destination rows, so per-row atomics serialise on a few cache lines.  One workgroup per (destination
-// row t, 512-source-row chunk): it scans the chunk's indices (wave-uniform scalar loads), sums the matching rows in
-// registers (thread = column) and adds ONCE per (t, column).
+// handful of destination rows, so per-row global atomics serialise on a few cache lines.  One workgroup per 64 source
+// rows x 256 columns: the waves add their rows into an LDS image of the table (ds_add_f32; lane = 4 columns), then
+// the touched table rows are added to memory ONCE per (workgroup, row, column).
 constexpr int kSmallTableRows = 32;
-constexpr int kSmallChunk = 512;
-__global__ __launch_bounds__(256) void scatter_add_small_kernel(float* grad_table, int ld_table, int width,
+constexpr int kSmallChunk = 64;
+__global__ __launch_bounds__(256) void scatter_add_small_kernel(float* grad_table, int ld_table, int width, int table_rows,
                                                                 const int* __restrict__ idx, int rows_cap,
                                                                 const int* __restrict__ rows_dyn,
                                                                 const float* __restrict__ g, int ld_g) {
+    __shared__ float tab[kSmallTableRows][256];
+    __shared__ int touched[kSmallTableRows];
     const int rows = rows_dyn != nullptr ? min(rows_cap, *rows_dyn) : rows_cap;
-    const int t = blockIdx.x;
-    const int r0 = blockIdx.y * kSmallChunk;
+    const int r0 = blockIdx.x * kSmallChunk;
     if (r0 >= rows) return;
     const int r1 = min(rows, r0 + kSmallChunk);
-    for (int c = threadIdx.x; c < width; c += 256) {
-        float acc = 0.f;
-        bool any = false;
-        for (int r = r0; r < r1; ++r)
-            if (idx[r] == t) { acc += g[(size_t)r * ld_g + c]; any = true; }
-        if (any) atomicAdd(grad_table + (size_t)t * ld_table + c, acc);
+    const int c0 = blockIdx.y * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e = threadIdx.x; e < kSmallTableRows * 256; e += 256) (&tab[0][0])[e] = 0.f;
+    if (threadIdx.x < kSmallTableRows) touched[threadIdx.x] = 0;
+    __syncthreads();
+    const int c = c0 + 4 * lane;
+    for (int r = r0 + wave; r < r1; r += 4) {
+        const int t = idx[r];
+        if (t < 0 || t >= table_rows) continue;          // wave-uniform
+        if (lane == 0) touched[t] = 1;
+        if (c < width) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(g + (size_t)r * ld_g + c);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) atomicAdd(&tab[t][4 * lane + i], v[i]);
+        }
+    }
+    __syncthreads();
+    for (int t = 0; t < table_rows; ++t) {
+        if (!touched[t]) continue;
+        const int cc = c0 + threadIdx.x;
+        if (cc < width) atomicAdd(grad_table + (size_t)t * ld_table + cc, tab[t][threadIdx.x]);
     }
 }
 
@@ -262,12 +278,14 @@ __global__ void conv3_pack_kernel(const float* __restrict__ w, float* __restrict
     const int tap = e / per, oc = e - tap * per;
     wt[e] = w[(size_t)oc * 3 + tap];
 }
-__global__ void conv3_unpack_add_kernel(const float* __restrict__ dwt, float* __restrict__ dw, int Dout, int Din) {
+__global__ void conv3_unpack_add_kernel(float* __restrict__ dwt, float* __restrict__ dw, int Dout, int Din) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;      // over [o][c][tap]
     const int per = Dout * Din;
     if (e >= 3 * per) return;
     const int oc = e / 3, tap = e - oc * 3;
-    atomicAdd(dw + e, dwt[(size_t)tap * per + oc]);      // micro-batches accumulate into the same gradient concurrently
+    float* src = dwt + (size_t)tap * per + oc;
+    atomicAdd(dw + e, *src);      // micro-batches accumulate into the same gradient concurrently
+    *src = 0.f;                   // the split-K accumulator is handed back clean: no fill launch before the next backward
 }
 
 // ------------------------------------------------------------------ additive attention pooling
@@ -617,10 +635,12 @@ __global__ __launch_bounds__(256) void user_tower_train_kernel(
 }
 
 // ------------------------------------------------------------------ Adam
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            long long n, float step_size, float beta1, float beta2, float eps, float inv_sqrt_bc2, float gscale) {
+__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long long n, float step_size, float beta1, float beta2, float eps, float inv_sqrt_bc2, float gscale,
+                            int zero_grad) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float gr = g[i] * gscale;
+        if (zero_grad) g[i] = 0.f;            // the next step accumulates into a clean buffer: no separate fill launch
         const float mi = beta1 * m[i] + (1.f - beta1) * gr;
         const float vi = beta2 * v[i] + (1.f - beta2) * gr * gr;
         m[i] = mi; v[i] = vi;
@@ -738,8 +758,9 @@ extern "C" int lego_scatter_add_rows(float* grad_table, int ld_table, int width,
                                      int rows_cap, const int32_t* rows_dyn, const float* g, int ld_g, void* stream) {
     if (rows_cap <= 0) return 0;
     if (table_rows > 0 && table_rows <= kSmallTableRows) {
-        hipLaunchKernelGGL(scatter_add_small_kernel, dim3(table_rows, (rows_cap + kSmallChunk - 1) / kSmallChunk), dim3(256), 0, ST,
-                           grad_table, ld_table, width, idx, rows_cap, rows_dyn, g, ld_g);
+        LEGO_REQUIRE((width & 3) == 0 && (ld_g & 3) == 0, "lego_scatter_add_rows: width=%d and ld_g=%d must be multiples of 4", width, ld_g);
+        hipLaunchKernelGGL(scatter_add_small_kernel, dim3((rows_cap + kSmallChunk - 1) / kSmallChunk, (width + 255) / 256), dim3(256), 0, ST,
+                           grad_table, ld_table, width, table_rows, idx, rows_cap, rows_dyn, g, ld_g);
         return check_launch("lego_scatter_add_rows");
     }
     const long long total = (long long)rows_cap * width;
@@ -766,7 +787,7 @@ extern "C" int lego_conv3_pack(const float* w, float* wt, int Dout, int Din, voi
     hipLaunchKernelGGL(conv3_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, ST, w, wt, Dout, Din);
     return check_launch("lego_conv3_pack");
 }
-extern "C" int lego_conv3_unpack_add(const float* dwt, float* dw, int Dout, int Din, void* stream) {
+extern "C" int lego_conv3_unpack_add(float* dwt, float* dw, int Dout, int Din, void* stream) {
     const int n = 3 * Dout * Din;
     hipLaunchKernelGGL(conv3_unpack_add_kernel, dim3((n + 255) / 256), dim3(256), 0, ST, dwt, dw, Dout, Din);
     return check_launch("lego_conv3_unpack_add");
@@ -849,8 +870,8 @@ extern "C" int lego_relu_bwd(float* g, int ldg, const float* ref, int ldr, int r
     return check_launch("lego_relu_bwd");
 }
 
-extern "C" int lego_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                              float eps, int step, float grad_scale, void* stream) {
+extern "C" int lego_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                              float eps, int step, float grad_scale, int zero_grad, void* stream) {
     LEGO_REQUIRE(step >= 1, "lego_adam_step: step is 1-based (got %d)", step);
     if (n <= 0) return 0;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
@@ -859,7 +880,7 @@ extern "C" int lego_adam_step(float* p, const float* g, float* m, float* v, int6
     const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, ST, p, g, m, v, (long long)n, step_size, beta1, beta2, eps,
-                       inv_sqrt_bc2, grad_scale);
+                       inv_sqrt_bc2, grad_scale, zero_grad);
     return check_launch("lego_adam_step");
 }
 

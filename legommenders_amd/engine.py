@@ -220,7 +220,7 @@ class NamlEngine(_Base):
     def _lanes(self):
         if getattr(self, "_side", None) is None:
             self._side = [torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)]
-            self._evs = [torch.cuda.Event() for _ in range(8)]
+            self._evs = [torch.cuda.Event() for _ in range(10)]
         m = torch.cuda.current_stream()
         if os.environ.get("LEGO_SERIAL") == "1":     # profiling aid: one stream, so per-kernel times do not overlap
             return m, m, m
@@ -250,7 +250,9 @@ class NamlEngine(_Base):
         t.setdefault(tag, []).append((e0, e1))
 
     # ------------------------------------------------------------------ forward
-    def forward(self, cand, hist, hist_len, training=False, with_loss=True, planned=False, gloss=1.0):
+    def forward(self, cand, hist, hist_len, training=False, with_loss=True, planned=False, gloss=1.0, fork_ev=None):
+        """`fork_ev`: an event the caller has already recorded on the current stream after everything this forward
+        depends on (TrainStep records ONE per step and shares it with its prefetch stream); None = record one here."""
         P, B, C, S, D, A, E0 = self.P, self.B, self.C, self.S, self.D, self.A, self.E0
         m, sb, sc = self._lanes()
         ev = self._evs
@@ -258,9 +260,9 @@ class NamlEngine(_Base):
         self._training = training
         if not planned:
             self._plan(cand, hist, hist_len)
-        self._forward_items(training)
+            fork_ev = None                           # the plan was enqueued after the caller's event
+        self._forward_items(training, fork_ev, zero_loss=True)
         self._fused = bool(training and with_loss and self.fused_grads is not None)
-        self.loss.zero_()
         if self._fused:
             # tanh GEMM over the clicked-item rows, then ONE kernel for pool + dot + CE + their backward
             G = self.fused_grads
@@ -289,30 +291,45 @@ class NamlEngine(_Base):
                 _ptr(self.counters), _ptr(self.inst_item), _ptr(self.seg_off), _ptr(self.hist_off),
                 _ptr(self.rowinfo), _ptr(self.row_tok))
 
-    def _forward_items(self, training):
+    def _forward_items(self, training, fork_ev=None, zero_loss=False):
         """item vectors of every planned instance -> self.items[0:NI]"""
         P, D, A, E0 = self.P, self.D, self.A, self.E0
         m, sb, sc = self._lanes()
         ev = self._evs
-        self._fork(ev[0], m, sb)
-        # side stream: k2/k4 category embedding + Linear on the length-1 column (cnn_operator.py:58-60) -> Y rows R..R+NI
+        if fork_ev is not None and sb is not m:
+            sb.wait_event(fork_ev)
+        else:
+            self._fork(ev[0], m, sb)
+        # side stream, in the order the main stream needs things: the tap-major conv weights first (their own event:
+        # the conv must not wait for the category GEMM), then the loss accumulator, then
+        # k2/k4 category embedding + Linear on the length-1 column (cnn_operator.py:58-60) -> Y rows R..R+NI
+        self.kk(sb, None, "lego_conv3_pack", _ptr(P["item_op.cnn.weight"]), _ptr(self.wt), D, D)
+        if sb is not m:
+            ev[8].record(sb)
+        if zero_loss:
+            with torch.cuda.stream(sb):
+                self.loss.zero_()
         self.kk(sb, None, "lego_gather_i32", _ptr(self.tb.cat), _ptr(self.inst_item), self.NIc, self.cnt(1), _ptr(self.inst_cat))
         self.kk(sb, None, "lego_gather_rows", _ptr(P["embedding_vocab_table.category.weight"]), D, D, _ptr(self.inst_cat),
                 self.NIc, self.cnt(1), _ptr(self.cat_emb), D, 0)
         self.kk(sb, None, "lego_linear_fwd", _ptr(self.cat_emb), D, _ptr(P["item_op.linear.weight"]), D,
                 _ptr(P["item_op.linear.bias"]), _ptr(self.Y), D, self.NIc, self.cnt(1), D, D, 0,
                 None, None, None, self.cnt(0))
-        self.kk(sb, None, "lego_conv3_pack", _ptr(P["item_op.cnn.weight"]), _ptr(self.wt), D, D)
+        if sb is not m:
+            ev[1].record(sb)
         # main stream: k1 frozen GloVe row gather, then Transformation = Dropout(Linear(.)) (embedding_hub.py:95-96)
         self.kk(m, "gather_rows", "lego_gather_rows", _ptr(P["embedding_vocab_table.glove.embedding.weight"]), E0, E0,
                 _ptr(self.row_tok), self.Rc, self.cnt(0), _ptr(self.X), E0, 0)
         self.kk(m, "proj_fwd", "lego_linear_fwd", _ptr(self.X), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
                 _ptr(P["embedding_vocab_table.glove.linear.bias"]), _ptr(self.H), D, self.Rc, self.cnt(0), D, E0, 0,
                 None, self.drop(self.p_proj, SITE_PROJ, training), None, None)      # every planned row is live
-        self._fork(ev[1], sb, m)                    # conv needs the packed weights; the pool needs the category rows
+        if sb is not m:
+            m.wait_event(ev[8])                      # packed conv weights (long done: first thing on the side stream)
         # k3: conv + relu + mask + dropout (cnn_operator.py:54-57)
         self.kk(m, "conv3_fwd", "lego_conv3_fwd", _ptr(self.H), D, _ptr(self.wt), _ptr(P["item_op.cnn.bias"]), _ptr(self.rowinfo),
                 _ptr(self.Y), D, self.Rc, self.cnt(0), D, D, self.drop(self.p_conv, SITE_CONV, training), 0)
+        if sb is not m:
+            m.wait_event(ev[1])                      # category rows of Y, zeroed loss
         # k5: additive attention pool over [title tokens..., category] (attention.py:31-38)
         self._additive_fwd(m, "item_op.", _ptr(self.Y), self.Ryc, self.cnt(2), self.Tt, A, self.seg_off, self.cnt(0),
                            self.NIc, self.cnt(1), self.items, self.wrow)
@@ -341,7 +358,6 @@ class NamlEngine(_Base):
         step_save = self.step
         if training:
             self.step -= 1          # regenerate the masks of the forward pass of this step
-        self._fork(ev[2], m, sb, sc)                 # everything enqueued so far (forward, grad zeroing) precedes the side work
         hist_items = _ptr(self.items, self.BC * D)
         d_hist_items = _ptr(self.d_items, self.BC * D)
         if getattr(self, "_fused", False):
@@ -352,19 +368,20 @@ class NamlEngine(_Base):
                     float(gloss) / B, _ptr(self.d_user), D, _ptr(self.d_items), D)
             self._pool_bwd(m, "user_op.", G, hist_items, d_hist_items, self.Tu, self.Au, self.hist_off, None, B, None,
                            self.d_user, self.wu)
-        self._fork(ev[3], m, sb)
-        # side: user dW1 += dpre^T . items      main: user-side dx += dpre . W1
-        self.kk(sb, "additive_bwd_weight_user", "lego_linear_bwd_weight", _ptr(self.Tu), self.Au, hist_items, D,
-                _ptr(G["user_op.additive_attention.encoder.0.weight"]), D, B * S, self.cnt(3), self.Au, D, None, None)
+        # main: user-side dx += dpre . W1   (the user dW1 product runs on the side stream after the ONE fork below:
+        # every event recorded on the main stream costs it a few microseconds, tools/event_cost.py)
         self.kk(m, None, "lego_linear_bwd_data", _ptr(self.Tu), self.Au, _ptr(P["user_op.additive_attention.encoder.0.weight"]), D,
                 d_hist_items, D, B * S, self.cnt(3), self.Au, D, 1, None, 0, 1.0, None, None, None, None, None)
         # item-side pool backward: dY direct part, dpre in place of T
         self._pool_bwd(m, "item_op.", G, _ptr(self.Y), _ptr(self.dY), self.Tt, A, self.seg_off, self.cnt(0), self.NIc,
                        self.cnt(1), self.d_items, self.wrow)
-        self._fork(ev[4], m, sb, sc)
+        conv_w_main = os.environ.get("LEGO_CONVW", "main") == "main"
+        self._fork(ev[4], m, sb)
         keep = 1.0 / (1.0 - self.p_conv) if (training and self.p_conv > 0) else 1.0
         w1 = _ptr(P["item_op.additive_attention.encoder.0.weight"])
-        # ---- side stream B: additive weight gradient + the whole category branch
+        # ---- side stream B: additive weight gradients + the whole category branch
+        self.kk(sb, "additive_bwd_weight_user", "lego_linear_bwd_weight", _ptr(self.Tu), self.Au, hist_items, D,
+                _ptr(G["user_op.additive_attention.encoder.0.weight"]), D, B * S, self.cnt(3), self.Au, D, None, None)
         self.kk(sb, "additive_bwd_weight_item", "lego_linear_bwd_weight", _ptr(self.Tt), A, _ptr(self.Y), D,
                 _ptr(G["item_op.additive_attention.encoder.0.weight"]), D, self.Ryc, self.cnt(2), A, D, None, None)
         self.kk(sb, None, "lego_linear_bwd_data", _ptr(self.Tt), A, w1, D, _ptr(self.dY), D, self.NIc, self.cnt(1), A, D, 1,
@@ -379,21 +396,28 @@ class NamlEngine(_Base):
         # ---- main: token rows: dY = relu'(.)*keep * (dY + dpre.W1); column sums -> conv bias grad
         self.kk(m, "additive_bwd_data", "lego_linear_bwd_data", _ptr(self.Tt), A, w1, D, _ptr(self.dY), D, self.Rc, self.cnt(0), A, D, 1,
                 _ptr(self.Y), D, keep, None, None, _ptr(G["item_op.cnn.bias"]), None, None)
-        self._fork(ev[5], m, sc)
-        # ---- side stream C: conv weight gradient
-        with torch.cuda.stream(sc):
-            self.dwt.zero_()
-        self.kk(sc, "conv3_bwd_weight", "lego_conv3_bwd_weight", _ptr(self.dY), D, _ptr(self.H), D, _ptr(self.rowinfo), _ptr(self.dwt),
-                self.Rc, self.cnt(0), D, D)
-        self.kk(sc, None, "lego_conv3_unpack_add", _ptr(self.dwt), _ptr(G["item_op.cnn.weight"]), D, D)
+        cw = m if conv_w_main else sc
+        if cw is not m:
+            self._fork(ev[5], m, sc)
+        # ---- conv weight gradient (side stream C, or LEGO_CONVW=main: after the data gradient on the main stream)
+
+        def conv_w():
+            self.kk(cw, "conv3_bwd_weight", "lego_conv3_bwd_weight", _ptr(self.dY), D, _ptr(self.H), D, _ptr(self.rowinfo),
+                    _ptr(self.dwt), self.Rc, self.cnt(0), D, D)
+            self.kk(cw, None, "lego_conv3_unpack_add", _ptr(self.dwt), _ptr(G["item_op.cnn.weight"]), D, D)
+        if cw is not m:
+            conv_w()
         # ---- main: conv data gradient -> projection weight gradient
         self.kk(m, "conv3_bwd_data", "lego_conv3_bwd_data", _ptr(self.dY), D, _ptr(self.wt), _ptr(self.rowinfo), _ptr(self.dH), D,
                 self.Rc, self.cnt(0), D, D, self.drop(self.p_proj, SITE_PROJ, training),
                 _ptr(G["embedding_vocab_table.glove.linear.bias"]), 0)
+        if cw is m:
+            conv_w()
         self.kk(m, "proj_bwd_weight", "lego_linear_bwd_weight", _ptr(self.dH), D, _ptr(self.X), E0,
                 _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Rc, self.cnt(0), D, E0, None, None)
         self._fork(ev[6], sb, m)
-        self._fork(ev[7], sc, m)
+        if cw is not m:
+            self._fork(ev[7], sc, m)
         self.step = step_save
 
     def _pool_bwd(self, st, prefix, G, x_ptr, dx_ptr, t, A, seg_off, extra, n_cap, n_dyn, gout, wrow):
@@ -516,7 +540,7 @@ class NrmsEngine(_Base):
     def _plan_tables(self):
         return self.seq_tok, self.seq_len, self.L
 
-    def forward(self, cand, hist, hist_len, training=False, with_loss=True, planned=False):
+    def forward(self, cand, hist, hist_len, training=False, with_loss=True, planned=False, fork_ev=None):
         P, B, C, S, D = self.P, self.B, self.C, self.S, self.D
         st = _stream()
         _check(cand, torch.int32, "cand"); _check(hist, torch.int32, "hist"); _check(hist_len, torch.int32, "hist_len")

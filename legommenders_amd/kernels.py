@@ -197,7 +197,7 @@ def dot_ce_bwd(user, items, scores, gloss=1.0):
 def adam_step(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
     n = p.numel()
     call("lego_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), n, float(lr), float(betas[0]), float(betas[1]), float(eps),
-         int(step), float(grad_scale), _stream())
+         int(step), float(grad_scale), 0, _stream())
 
 
 # --------------------------------------------------------------------------- MHSA (dense API, any 0/1 mask)

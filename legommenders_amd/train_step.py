@@ -120,6 +120,7 @@ class TrainStep:
         self.pg, self.world = process_group, world_size
         self.force_allreduce = force_allreduce
         self.counter_sum = torch.zeros(8, dtype=torch.int64, device=dev)
+        self._grad_clean = True                    # FlatParams allocates a zeroed gradient buffer
 
     def lr_at(self, step: int) -> float:
         """HF get_linear_schedule_with_warmup (base_lego.py:211-223); total_steps == 0 -> constant lr."""
@@ -141,13 +142,17 @@ class TrainStep:
         call("lego_gather_history", ru, _ptr(d.user_hist), _ptr(d.user_hist_len), B, d.S, _ptr(self._hist[slot]),
              _ptr(self._hist_len[slot]), st)
 
-    def _prefetch(self, step_idx):
+    def _prefetch(self, step_idx, go=None):
         """sample + plan training step `step_idx` on the side stream `pre` (slot = step_idx % 2)"""
         slot = step_idx % 2
-        self._go.record(torch.cuda.current_stream())
-        self.pre.wait_event(self._go)              # the slot's previous user (step_idx - 2) is complete by now
+        if go is None:
+            go = self._go
+            go.record(torch.cuda.current_stream())
+        self.pre.wait_event(go)                    # the slot's previous user (step_idx - 2) is complete by then
         self.sample_batch(step_idx, slot, self.pre)
         self.engine.plan_on(self.pre, slot, self._cand[slot], self._hist[slot], self._hist_len[slot])
+        with torch.cuda.stream(self.pre):          # row statistics of the planned batch (bench.py), off the main stream
+            self.counter_sum += self.engine._slots[slot]["counters"]
         self._ready[slot].record(self.pre)
         self._planned_step = step_idx
 
@@ -162,11 +167,17 @@ class TrainStep:
             self.engine.use_slot(slot)
         else:
             self.sample_batch()
-        self.fp.grad.zero_()
+        if not self._grad_clean:
+            self.fp.grad.zero_()
         if self.micro == 1:
-            _, loss = self.engine.forward(self.cand, self.hist, self.hist_len, training=True, planned=self.prefetch)
+            go = None
             if self.prefetch:
-                self._prefetch(self.step_idx + 1)      # next batch: off the critical path
+                # ONE event on the main stream per step: everything before this step's forward.  The prefetch stream
+                # (next batch's sample + plan) and the engine's side stream both start from it.
+                go = self._go
+                go.record(torch.cuda.current_stream())
+                self._prefetch(self.step_idx + 1, go)
+            _, loss = self.engine.forward(self.cand, self.hist, self.hist_len, training=True, planned=self.prefetch, fork_ev=go)
             self.engine.backward(self.fp.G)
         else:
             main = torch.cuda.current_stream()
@@ -189,7 +200,9 @@ class TrainStep:
             torch.distributed.all_reduce(self.fp.grad, group=self.pg)      # one RCCL all-reduce per step
         self.step_idx += 1
         call("lego_adam_step", _ptr(self.fp.flat), _ptr(self.fp.grad), _ptr(self.fp.m), _ptr(self.fp.v),
-             self.fp.numel, self.lr_at(self.step_idx - 1), 0.9, 0.999, 1e-8, self.step_idx, 1.0 / self.world, _stream())
-        for e in self.engines:
-            self.counter_sum += e.counters
+             self.fp.numel, self.lr_at(self.step_idx - 1), 0.9, 0.999, 1e-8, self.step_idx, 1.0 / self.world, 1, _stream())
+        self._grad_clean = True                    # Adam cleared the gradient buffer as it consumed it
+        if not self.prefetch:
+            for e in self.engines:
+                self.counter_sum += e.counters
         return loss

@@ -39,5 +39,5 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 
 def test_argument_validation_without_gpu(handle):
     # argument checks run before any kernel launch, so they are testable on CPU
-    rc = handle.lego_adam_step(None, None, None, None, ctypes.c_int64(4), 1e-3, 0.9, 0.999, 1e-8, 0, 1.0, None)
+    rc = handle.lego_adam_step(None, None, None, None, ctypes.c_int64(4), 1e-3, 0.9, 0.999, 1e-8, 0, 1.0, 0, None)
     assert rc != 0 and b"1-based" in handle.lego_last_error()
