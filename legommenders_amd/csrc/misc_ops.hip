@@ -206,11 +206,12 @@ __global__ void scatter_add_rows_kernel(float* grad_table, int ld_table, int wid
 }
 
 // Scatter-add into a SMALL table (category: 18 rows, ConcatInputer specials: 3 rows): every source row hits one of a
-// handful of destination rows, so per-row global atomics serialise on a few cache lines.  One workgroup per 64 source
-// rows x 256 columns: the waves add their rows into an LDS image of the table (ds_add_f32; lane = 4 columns), then
-// the touched table rows are added to memory ONCE per (workgroup, row, column).
+// handful of destination rows, so per-row global atomics serialise on a few cache lines.  One workgroup per 16 source
+// rows x 256 columns: each wave loads its 4 rows at once (lane = columns lane, lane+64, ...: coalesced, and the LDS
+// adds below are bank-conflict free), adds them into an LDS image of the table (ds_add_f32), then the touched table
+// rows are added to memory ONCE per (workgroup, row, column).
 constexpr int kSmallTableRows = 32;
-constexpr int kSmallChunk = 64;
+constexpr int kSmallChunk = 16;
 __global__ __launch_bounds__(256) void scatter_add_small_kernel(float* grad_table, int ld_table, int width, int table_rows,
                                                                 const int* __restrict__ idx, int rows_cap,
                                                                 const int* __restrict__ rows_dyn,
@@ -220,28 +221,36 @@ __global__ __launch_bounds__(256) void scatter_add_small_kernel(float* grad_tabl
     const int rows = rows_dyn != nullptr ? min(rows_cap, *rows_dyn) : rows_cap;
     const int r0 = blockIdx.x * kSmallChunk;
     if (r0 >= rows) return;
-    const int r1 = min(rows, r0 + kSmallChunk);
     const int c0 = blockIdx.y * 256;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int e = threadIdx.x; e < kSmallTableRows * 256; e += 256) (&tab[0][0])[e] = 0.f;
-    if (threadIdx.x < kSmallTableRows) touched[threadIdx.x] = 0;
-    __syncthreads();
-    const int c = c0 + 4 * lane;
-    for (int r = r0 + wave; r < r1; r += 4) {
-        const int t = idx[r];
-        if (t < 0 || t >= table_rows) continue;          // wave-uniform
-        if (lane == 0) touched[t] = 1;
-        if (c < width) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(g + (size_t)r * ld_g + c);
+    int t[4];
+    float v[4][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) atomicAdd(&tab[t][4 * lane + i], v[i]);
+    for (int u = 0; u < 4; ++u) {                      // all 16 loads of the wave are in flight before the first use
+        const int r = r0 + wave * 4 + u;
+        t[u] = r < rows ? idx[r] : -1;
+        if (t[u] >= table_rows) t[u] = -1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + lane + 64 * i;
+            v[u][i] = (t[u] >= 0 && c < width) ? g[(size_t)r * ld_g + c] : 0.f;
         }
     }
+    for (int e = threadIdx.x; e < table_rows * 256; e += 256) (&tab[0][0])[e] = 0.f;
+    if (threadIdx.x < kSmallTableRows) touched[threadIdx.x] = 0;
     __syncthreads();
-    for (int t = 0; t < table_rows; ++t) {
-        if (!touched[t]) continue;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (t[u] < 0) continue;                        // wave-uniform
+        if (lane == 0) touched[t[u]] = 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(&tab[t[u]][lane + 64 * i], v[u][i]);
+    }
+    __syncthreads();
+    for (int tr = 0; tr < table_rows; ++tr) {
+        if (!touched[tr]) continue;
         const int cc = c0 + threadIdx.x;
-        if (cc < width) atomicAdd(grad_table + (size_t)t * ld_table + cc, tab[t][threadIdx.x]);
+        if (cc < width) atomicAdd(grad_table + (size_t)tr * ld_table + cc, tab[tr][threadIdx.x]);
     }
 }
 
