@@ -214,6 +214,23 @@ class NamlEngine(_Base):
         self.d_cat_emb = self._f(self.NIc, D)
         self.dwt = self._f(3, D, D)
 
+    # ------------------------------------------------------------------ prefetched token-row gather
+    # The GloVe table is frozen, so the gathered rows X of a batch depend on its plan only: with plan slots enabled
+    # (TrainStep) the gather of step N+1 runs right after its plan on the prefetch stream, off the critical path.
+    _PLAN_FIELDS = _Base._PLAN_FIELDS + ("X",)
+
+    def gather_tokens(self, stream=None, into=None):
+        """k1: X[r, :] = glove[row_tok[r], :] for the planned token rows (embedding_hub.py:95, frozen table)"""
+        b = self.__dict__ if into is None else into
+        st = _stream() if stream is None else ctypes.c_void_p(stream.cuda_stream)
+        call("lego_gather_rows", _ptr(self.P["embedding_vocab_table.glove.embedding.weight"]), self.E0, self.E0,
+             _ptr(b["row_tok"]), self.Rc, _ptr(b["counters"], 0), _ptr(b["X"]), self.E0, 0, st)
+
+    def plan_on(self, stream, slot, cand, hist, hist_len):
+        super().plan_on(stream, slot, cand, hist, hist_len)
+        if self.Rc > 0:
+            self.gather_tokens(stream, self._slots[slot])
+
     # ------------------------------------------------------------------ streams
     # Independent branches of the step run on side HIP streams so the small category / user-side kernels
     # and the weight-gradient GEMMs fill the CUs the big token-row GEMMs leave idle in their last wave.
@@ -250,9 +267,12 @@ class NamlEngine(_Base):
         t.setdefault(tag, []).append((e0, e1))
 
     # ------------------------------------------------------------------ forward
-    def forward(self, cand, hist, hist_len, training=False, with_loss=True, planned=False, gloss=1.0, fork_ev=None):
+    def forward(self, cand, hist, hist_len, training=False, with_loss=True, planned=False, gloss=1.0, fork_ev=None,
+                neck_ev=None):
         """`fork_ev`: an event the caller has already recorded on the current stream after everything this forward
-        depends on (TrainStep records ONE per step and shares it with its prefetch stream); None = record one here."""
+        depends on; None = record one here.  `neck_ev`: recorded after the item tower, where the step enters its
+        latency-bound user-side chain and most CUs idle -- TrainStep starts the next batch's sample / plan / gather
+        there (any earlier and the gather competes with the row-strip GEMMs, which own every CU)."""
         P, B, C, S, D, A, E0 = self.P, self.B, self.C, self.S, self.D, self.A, self.E0
         m, sb, sc = self._lanes()
         ev = self._evs
@@ -261,7 +281,9 @@ class NamlEngine(_Base):
         if not planned:
             self._plan(cand, hist, hist_len)
             fork_ev = None                           # the plan was enqueued after the caller's event
-        self._forward_items(training, fork_ev, zero_loss=True)
+        self._forward_items(training, fork_ev, zero_loss=True, gathered=planned and getattr(self, "_slots", None) is not None)
+        if neck_ev is not None:
+            neck_ev.record(m)
         self._fused = bool(training and with_loss and self.fused_grads is not None)
         if self._fused:
             # tanh GEMM over the clicked-item rows, then ONE kernel for pool + dot + CE + their backward
@@ -291,7 +313,7 @@ class NamlEngine(_Base):
                 _ptr(self.counters), _ptr(self.inst_item), _ptr(self.seg_off), _ptr(self.hist_off),
                 _ptr(self.rowinfo), _ptr(self.row_tok))
 
-    def _forward_items(self, training, fork_ev=None, zero_loss=False):
+    def _forward_items(self, training, fork_ev=None, zero_loss=False, gathered=False):
         """item vectors of every planned instance -> self.items[0:NI]"""
         P, D, A, E0 = self.P, self.D, self.A, self.E0
         m, sb, sc = self._lanes()
@@ -318,8 +340,9 @@ class NamlEngine(_Base):
         if sb is not m:
             ev[1].record(sb)
         # main stream: k1 frozen GloVe row gather, then Transformation = Dropout(Linear(.)) (embedding_hub.py:95-96)
-        self.kk(m, "gather_rows", "lego_gather_rows", _ptr(P["embedding_vocab_table.glove.embedding.weight"]), E0, E0,
-                _ptr(self.row_tok), self.Rc, self.cnt(0), _ptr(self.X), E0, 0)
+        if not gathered:                             # else: done with the plan on the prefetch stream (plan_on)
+            self.kk(m, "gather_rows", "lego_gather_rows", _ptr(P["embedding_vocab_table.glove.embedding.weight"]), E0, E0,
+                    _ptr(self.row_tok), self.Rc, self.cnt(0), _ptr(self.X), E0, 0)
         self.kk(m, "proj_fwd", "lego_linear_fwd", _ptr(self.X), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
                 _ptr(P["embedding_vocab_table.glove.linear.bias"]), _ptr(self.H), D, self.Rc, self.cnt(0), D, E0, 0,
                 None, self.drop(self.p_proj, SITE_PROJ, training), None, None)      # every planned row is live
@@ -540,7 +563,7 @@ class NrmsEngine(_Base):
     def _plan_tables(self):
         return self.seq_tok, self.seq_len, self.L
 
-    def forward(self, cand, hist, hist_len, training=False, with_loss=True, planned=False, fork_ev=None):
+    def forward(self, cand, hist, hist_len, training=False, with_loss=True, planned=False, fork_ev=None, neck_ev=None):
         P, B, C, S, D = self.P, self.B, self.C, self.S, self.D
         st = _stream()
         _check(cand, torch.int32, "cand"); _check(hist, torch.int32, "hist"); _check(hist_len, torch.int32, "hist_len")
@@ -548,6 +571,8 @@ class NrmsEngine(_Base):
         if not planned:
             self._plan(cand, hist, hist_len)
         self._forward_items(training)
+        if neck_ev is not None:
+            neck_ev.record(torch.cuda.current_stream())
         self._forward_users(training)
         self.loss.zero_()
         call("lego_dot_ce_fwd", _ptr(self.user), D, _ptr(self.items), D, B, C, D, _ptr(self.scores),

@@ -114,6 +114,7 @@ class TrainStep:
             self.pre = torch.cuda.Stream(dev)
             self._ready = [torch.cuda.Event(), torch.cuda.Event()]
             self._go = torch.cuda.Event()
+            self._neck = torch.cuda.Event()
             self._planned_step = -1
         self.lr, self.total_steps, self.warmup = lr, total_steps, warmup
         self.seed, self.step_idx = seed, 0
@@ -170,14 +171,14 @@ class TrainStep:
         if not self._grad_clean:
             self.fp.grad.zero_()
         if self.micro == 1:
-            go = None
+            go = neck = None
             if self.prefetch:
-                # ONE event on the main stream per step: everything before this step's forward.  The prefetch stream
-                # (next batch's sample + plan) and the engine's side stream both start from it.
-                go = self._go
-                go.record(torch.cuda.current_stream())
-                self._prefetch(self.step_idx + 1, go)
-            _, loss = self.engine.forward(self.cand, self.hist, self.hist_len, training=True, planned=self.prefetch, fork_ev=go)
+                go, neck = self._go, self._neck
+                go.record(torch.cuda.current_stream())         # everything before this step's forward
+            _, loss = self.engine.forward(self.cand, self.hist, self.hist_len, training=True, planned=self.prefetch,
+                                          fork_ev=go, neck_ev=neck)
+            if self.prefetch:
+                self._prefetch(self.step_idx + 1, neck)        # next batch: starts where this step's item tower ends
             self.engine.backward(self.fp.G)
         else:
             main = torch.cuda.current_stream()
