@@ -92,6 +92,23 @@ int lego_colsum(const float* x, int ldx, int M_cap, const int32_t* M_dyn, const 
  * same item, from rowinfo).  Wt is the tap-major copy [3][Dout][Din] made by lego_conv3_pack. */
 int lego_conv3_pack(const float* w /*[Dout,Din,3]*/, float* wt /*[3,Dout,Din]*/, int Dout, int Din, void* stream);
 int lego_conv3_unpack_add(float* dwt /*[3,Dout,Din], cleared on return*/, float* dw /*[Dout,Din,3], +=*/, int Dout, int Din, void* stream);
+/* Winograd F(2,3) form of the same conv over ROW PAIRS (two thirds of the direct form's MFMA work; same result up to
+ * fp32 rounding).  lego_plan_pairs derives the pairs from seg_off: pair_info[p] = first_row << 3 | has_second |
+ * has_left << 1 | has_right2 << 2, *n_pairs_out = P.  u / du are the transformed weights [4][Dout][Din]
+ * (lego_conv3_wino_pack; lego_conv3_wino_unpack_add adds the transposed transform of du into dw and clears du).
+ * Every planned row must be live (ragged plans).  Din, Dout multiples of 32, <= 256. */
+int lego_plan_pairs(const int32_t* seg_off, int n_cap, const int32_t* n_dyn, int32_t* pair_info, int32_t* n_pairs_out,
+                    void* stream);
+int lego_conv3_wino_pack(const float* w /*[Dout,Din,3]*/, float* u /*[4,Dout,Din]*/, int Dout, int Din, void* stream);
+int lego_conv3_wino_unpack_add(float* du /*[4,Dout,Din], cleared*/, float* dw /*[Dout,Din,3], +=*/, int Dout, int Din, void* stream);
+int lego_conv3_wino_fwd(const float* h, int ldh, const float* u, const float* bias, const int32_t* pair_info,
+                        int P_cap, const int32_t* P_dyn, float* y, int ldy, int Dout, int Din,
+                        const lego_dropout* drop, void* stream);
+int lego_conv3_wino_bwd_data(const float* gy, int ldg, const float* u, const int32_t* pair_info,
+                             int P_cap, const int32_t* P_dyn, float* dh, int lddh, int Dout, int Din,
+                             const lego_dropout* drop_in, float* colsum, void* stream);
+int lego_conv3_wino_bwd_weight(const float* gy, int ldg, const float* h, int ldh, const int32_t* pair_info,
+                               int P_cap, const int32_t* P_dyn, float* du, int Dout, int Din, void* stream);
 int lego_conv3_fwd(const float* h, int ldh, const float* wt, const float* bias, const int32_t* rowinfo,
                    float* y, int ldy, int R_cap, const int32_t* R_dyn, int Dout, int Din,
                    const lego_dropout* drop, int mask_rows /*0: every row is live (ragged plan), skip the live-bit loads*/,

@@ -13,6 +13,7 @@
 //   * the k order inside a BK step is permuted (lane half h takes k = 8q+4h+j for MFMA j)
 //     identically for A and B, so one ds_read_b128 feeds four MFMAs.
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 
 namespace lego {
@@ -106,6 +107,11 @@ struct McShiftRows {       // row kk + (tap-1) of p, valid when the plan says ro
     }
 };
 
+// loaders whose element is a combination of TWO loads (gemm_wino.hpp) declare kDual = true and provide
+// load2(kk, c, v1, keep1, v2, keep2) + combine(v1, keep1, v2, keep2); MC operands only
+template <class L, class = void> struct IsDual : std::false_type {};
+template <class L> struct IsDual<L, std::void_t<decltype(L::kDual)>> : std::bool_constant<L::kDual> {};
+
 // ------------------------------------------------------------------ the kernel
 template <int BM, int BN, int WM, int WN, bool STAGGER = false>
 struct TileCfg {
@@ -182,15 +188,19 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_kernel(GemmDims dims, ALoa
         for (int j = 0; j < SB::kN; ++j) rb[j] = lb.row(n0 + (tid >> 3) + RS * j);
     }
 
-    f32x4 sa[SA::kN], sb[SB::kN];
-    bool pa[SA::kN], pb[SB::kN];
+    constexpr bool A2 = A_MC && IsDual<ALoad>::value, B2 = B_MC && IsDual<BLoad>::value;
+    f32x4 sa[SA::kN], sb[SB::kN], sa2[A2 ? SA::kN : 1], sb2[B2 ? SB::kN : 1];
+    bool pa[SA::kN], pb[SB::kN], pa2[A2 ? SA::kN : 1], pb2[B2 ? SB::kN : 1];
     auto fetch = [&](int k0) {
         la.tile(k0);
         lb.tile(k0);
         if constexpr (A_MC) {
             constexpr int PER = BM / 4, STEP = NT / PER;
 #pragma unroll
-            for (int j = 0; j < SA::kN; ++j) sa[j] = la.load(k0 + tid / PER + STEP * j, m0 + (tid % PER) * 4, pa[j]);
+            for (int j = 0; j < SA::kN; ++j) {
+                if constexpr (A2) la.load2(k0 + tid / PER + STEP * j, m0 + (tid % PER) * 4, sa[j], pa[j], sa2[j], pa2[j]);
+                else sa[j] = la.load(k0 + tid / PER + STEP * j, m0 + (tid % PER) * 4, pa[j]);
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < SA::kN; ++j) { sa[j] = la.load(ra[j], k0 + (tid & 7) * 4); pa[j] = la.keep(ra[j], k0 + (tid & 7) * 4); }
@@ -198,7 +208,10 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_kernel(GemmDims dims, ALoa
         if constexpr (B_MC) {
             constexpr int PER = BN / 4, STEP = NT / PER;
 #pragma unroll
-            for (int j = 0; j < SB::kN; ++j) sb[j] = lb.load(k0 + tid / PER + STEP * j, n0 + (tid % PER) * 4, pb[j]);
+            for (int j = 0; j < SB::kN; ++j) {
+                if constexpr (B2) lb.load2(k0 + tid / PER + STEP * j, n0 + (tid % PER) * 4, sb[j], pb[j], sb2[j], pb2[j]);
+                else sb[j] = lb.load(k0 + tid / PER + STEP * j, n0 + (tid % PER) * 4, pb[j]);
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < SB::kN; ++j) { sb[j] = lb.load(rb[j], k0 + (tid & 7) * 4); pb[j] = lb.keep(rb[j], k0 + (tid & 7) * 4); }
@@ -208,8 +221,11 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_kernel(GemmDims dims, ALoa
         if constexpr (A_MC) {
             constexpr int PER = BM / 4, STEP = NT / PER;
 #pragma unroll
-            for (int j = 0; j < SA::kN; ++j)
-                *reinterpret_cast<f32x4*>(A_ + (tid / PER + STEP * j) * BM + (tid % PER) * 4) = zero_unless(pa[j], sa[j]);
+            for (int j = 0; j < SA::kN; ++j) {
+                f32x4 v;
+                if constexpr (A2) v = la.combine(sa[j], pa[j], sa2[j], pa2[j]); else v = zero_unless(pa[j], sa[j]);
+                *reinterpret_cast<f32x4*>(A_ + (tid / PER + STEP * j) * BM + (tid % PER) * 4) = v;
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < SA::kN; ++j)
@@ -218,8 +234,11 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_kernel(GemmDims dims, ALoa
         if constexpr (B_MC) {
             constexpr int PER = BN / 4, STEP = NT / PER;
 #pragma unroll
-            for (int j = 0; j < SB::kN; ++j)
-                *reinterpret_cast<f32x4*>(B_ + (tid / PER + STEP * j) * BN + (tid % PER) * 4) = zero_unless(pb[j], sb[j]);
+            for (int j = 0; j < SB::kN; ++j) {
+                f32x4 v;
+                if constexpr (B2) v = lb.combine(sb[j], pb[j], sb2[j], pb2[j]); else v = zero_unless(pb[j], sb[j]);
+                *reinterpret_cast<f32x4*>(B_ + (tid / PER + STEP * j) * BN + (tid % PER) * 4) = v;
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < SB::kN; ++j)

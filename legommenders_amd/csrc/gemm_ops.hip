@@ -3,6 +3,7 @@
 // 1e-3 on fp32 logits, so no reduced-precision inputs are used).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "../../include/lego_hip.h"
 #include "gemm_strip.hpp"
 
@@ -171,6 +172,10 @@ struct EpiT : EpiArgs {
 };
 
 using Epi = EpiArgs;      // host-side view; the kernel is instantiated with one EpiT<...> kind
+
+}  // namespace lego
+#include "gemm_wino.hpp"
+namespace lego {
 
 static Epi make_epi(float* C, int ldc) {
     Epi e;
@@ -391,6 +396,60 @@ extern "C" int lego_conv3_bwd_weight(const float* gy, int ldg, const float* h, i
     return launch_tn(d, a, b, e, 3, (hipStream_t)stream, "lego_conv3_bwd_weight");
 }
 
+
+// ---- Winograd F(2,3) form of the conv over row pairs (gemm_wino.hpp)
+template <bool B_MC>
+static int launch_wino(const WinoArgs& w, const Epi& e, hipStream_t st, const char* what) {
+    auto k = wino_kernel<B_MC>;
+    constexpr size_t lds = wino_lds_bytes<B_MC>();
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(num_cus()), dim3(STRIP_THREADS), lds, st, w, e);
+    return check_launch(what);
+}
+
+extern "C" int lego_conv3_wino_fwd(const float* h, int ldh, const float* u, const float* bias, const int32_t* pair_info,
+                                   int P_cap, const int32_t* P_dyn, float* y, int ldy, int Dout, int Din,
+                                   const lego_dropout* drop, void* stream) {
+    CHECK4(ldh);
+    LEGO_REQUIRE(Din % BK == 0 && Dout % 4 == 0 && Dout <= STRIP_BN, "lego_conv3_wino_fwd: Din=%d must be a multiple of %d, Dout=%d a multiple of 4 and <= %d", Din, BK, Dout, STRIP_BN);
+    if (P_cap <= 0) return 0;
+    static const int dbg = getenv("LEGO_WINO_DBG") ? atoi(getenv("LEGO_WINO_DBG")) : 0;
+    WinoArgs w{h, ldh, u, Din, Dout, pair_info, P_cap, P_dyn, 0, dbg};
+    Epi e = make_epi(y, ldy);
+    e.bias = bias; e.act = 1;
+    set_drop(e, drop, Dout);
+    return launch_wino<false>(w, e, (hipStream_t)stream, "lego_conv3_wino_fwd");
+}
+
+extern "C" int lego_conv3_wino_bwd_data(const float* gy, int ldg, const float* u, const int32_t* pair_info,
+                                        int P_cap, const int32_t* P_dyn, float* dh, int lddh, int Dout, int Din,
+                                        const lego_dropout* drop_in, float* colsum, void* stream) {
+    CHECK4(ldg);
+    LEGO_REQUIRE(Dout % BK == 0 && Din % 4 == 0 && Din <= STRIP_BN, "lego_conv3_wino_bwd_data: Dout=%d must be a multiple of %d, Din=%d a multiple of 4 and <= %d", Dout, BK, Din, STRIP_BN);
+    if (P_cap <= 0) return 0;
+    WinoArgs w{gy, ldg, u, Dout, Din, pair_info, P_cap, P_dyn, 1, 0};
+    Epi e = make_epi(dh, lddh);
+    e.colsum = colsum;
+    set_drop(e, drop_in, Din);
+    return launch_wino<true>(w, e, (hipStream_t)stream, "lego_conv3_wino_bwd_data");
+}
+
+extern "C" int lego_conv3_wino_bwd_weight(const float* gy, int ldg, const float* h, int ldh, const int32_t* pair_info,
+                                          int P_cap, const int32_t* P_dyn, float* du, int Dout, int Din, void* stream) {
+    CHECK4(ldg); CHECK4(ldh); CHECK4(Dout); CHECK4(Din);
+    if (P_cap <= 0) return 0;
+    // du[set][o][c] += sum_pairs dM_set[o] * A_set[c]: four TN products over the pair rows (gridDim.z = 4 * split)
+    GemmDims d{Dout, Din, P_cap, nullptr, P_dyn, pick_split(P_cap, Dout, Din, 4)};
+    McPair a{gy, ldg, Dout, P_cap, pair_info, 1, 0};
+    McPair b{h, ldh, Din, P_cap, pair_info, 0, 0};
+    Epi e = make_epi(du, Din);
+    e.tap_stride = (size_t)Dout * Din;
+    return launch_tn(d, a, b, e, 4, (hipStream_t)stream, "lego_conv3_wino_bwd_weight");
+}
 
 // ---- internal tuning hook (not part of the public ABI): plain NT product with a selectable tile config
 extern "C" int lego_debug_gemm_nt(int variant, const float* x, const float* W, const float* bias, float* out,

@@ -114,6 +114,57 @@ __global__ void plan_rows_kernel(const int* __restrict__ counters, const int* __
     }
 }
 
+// Row pairs of the Winograd F(2,3) conv (gemm_wino.hpp): pair q of an item instance covers its rows 2q, 2q+1.
+// pair_info[p] = (first row << 3) | has_second | has_left << 1 | has_right2 << 2; counters_out[0] = #pairs.
+__global__ __launch_bounds__(1024) void plan_pairs_kernel(const int* __restrict__ seg_off, int n_cap,
+                                                          const int* __restrict__ n_dyn, int* __restrict__ pair_info,
+                                                          int* counters_out) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x;
+    const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        int beg = 0, len = 0;
+        if (i < n) { beg = seg_off[i]; len = seg_off[i + 1] - beg; }
+        const int np = (len + 1) >> 1;
+        const int inc = block_incl_scan_1024(np, wsum);
+        const int carry = carry_s;
+        int p = carry + inc - np;
+        for (int q = 0; q < np; ++q, ++p)
+            pair_info[p] = ((beg + 2 * q) << 3) | (2 * q + 1 < len ? 1 : 0) | (q > 0 ? 2 : 0) | (2 * q + 2 < len ? 4 : 0);
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + inc;
+        __syncthreads();
+    }
+    if (tid == 0) counters_out[0] = carry_s;
+}
+
+// Winograd F(2,3) weight transform: u[0] = g0, u[1] = (g0+g1+g2)/2, u[2] = (g0-g1+g2)/2, u[3] = g2 with g_t = w[:, :, t]
+__global__ void conv3_wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Dout, int Din) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;      // over [o][c]
+    const int per = Dout * Din;
+    if (e >= per) return;
+    const float g0 = w[3 * e], g1 = w[3 * e + 1], g2 = w[3 * e + 2];
+    u[e] = g0;
+    u[per + e] = 0.5f * (g0 + g1 + g2);
+    u[2 * per + e] = 0.5f * (g0 - g1 + g2);
+    u[3 * per + e] = g2;
+}
+// ... and its transpose for the gradient: dw[:, :, 0] += du0 + (du1+du2)/2, [1] += (du1-du2)/2, [2] += (du1+du2)/2 + du3
+__global__ void conv3_wino_unpack_add_kernel(float* __restrict__ du, float* __restrict__ dw, int Dout, int Din) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = Dout * Din;
+    if (e >= per) return;
+    const float a = du[e], b = du[per + e], c = du[2 * per + e], d = du[3 * per + e];
+    atomicAdd(dw + 3 * e, a + 0.5f * (b + c));
+    atomicAdd(dw + 3 * e + 1, 0.5f * (b - c));
+    atomicAdd(dw + 3 * e + 2, 0.5f * (b + c) + d);
+    du[e] = 0.f; du[per + e] = 0.f; du[2 * per + e] = 0.f; du[3 * per + e] = 0.f;    // accumulator handed back clean
+}
+
 __global__ void plan_dense_kernel(const int* __restrict__ mask, int n, int L, int* counters, int* seg_off, int* rowinfo) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r == 0) {
@@ -723,6 +774,24 @@ extern "C" int lego_plan_batch(const int32_t* cand, const int32_t* hist, const i
     hipLaunchKernelGGL(plan_rows_kernel, dim3((NI_cap * 32 + 255) / 256), dim3(256), 0, ST, counters, inst_item, seg_off,
                        title_tok, title_len, T, NI_cap, rowinfo, row_tok);
     return check_launch("lego_plan_batch");
+}
+
+extern "C" int lego_plan_pairs(const int32_t* seg_off, int n_cap, const int32_t* n_dyn, int32_t* pair_info,
+                               int32_t* n_pairs_out, void* stream) {
+    LEGO_REQUIRE(n_cap > 0, "lego_plan_pairs: n_cap=%d", n_cap);
+    hipLaunchKernelGGL(plan_pairs_kernel, dim3(1), dim3(1024), 0, ST, seg_off, n_cap, n_dyn, pair_info, n_pairs_out);
+    return check_launch("lego_plan_pairs");
+}
+
+extern "C" int lego_conv3_wino_pack(const float* w, float* u, int Dout, int Din, void* stream) {
+    const int n = Dout * Din;
+    hipLaunchKernelGGL(conv3_wino_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, ST, w, u, Dout, Din);
+    return check_launch("lego_conv3_wino_pack");
+}
+extern "C" int lego_conv3_wino_unpack_add(float* du, float* dw, int Dout, int Din, void* stream) {
+    const int n = Dout * Din;
+    hipLaunchKernelGGL(conv3_wino_unpack_add_kernel, dim3((n + 255) / 256), dim3(256), 0, ST, du, dw, Dout, Din);
+    return check_launch("lego_conv3_wino_unpack_add");
 }
 
 extern "C" int lego_plan_dense(const int32_t* mask, int n, int L, int32_t* counters, int32_t* seg_off, int32_t* rowinfo,

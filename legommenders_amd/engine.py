@@ -206,6 +206,13 @@ class NamlEngine(_Base):
         self.wu = self._f(B * S)
         self.user = self._f(B, D)
         self.wt = self._f(3, D, D)
+        # Winograd F(2,3) conv over row pairs (csrc/gemm_wino.hpp): two thirds of the direct conv's MFMA work.
+        # LEGO_WINO=0 keeps the direct three-tap implicit GEMM (also used when D > 256).
+        self.wino = os.environ.get("LEGO_WINO", "1") != "0" and D <= 256 and self.Rc > 0
+        self.Pc = self.NIc * ((self.T + 1) // 2)
+        self.pair_info = torch.zeros(max(self.Pc, 1), **i32)
+        self.wino_u = self._f(4, D, D)
+        self.wino_du = self._f(4, D, D)
         # backward workspace
         self.d_user = self._f(B, D)
         self.d_items = self._f(self.NIc, D)
@@ -217,7 +224,7 @@ class NamlEngine(_Base):
     # ------------------------------------------------------------------ prefetched token-row gather
     # The GloVe table is frozen, so the gathered rows X of a batch depend on its plan only: with plan slots enabled
     # (TrainStep) the gather of step N+1 runs right after its plan on the prefetch stream, off the critical path.
-    _PLAN_FIELDS = _Base._PLAN_FIELDS + ("X",)
+    _PLAN_FIELDS = _Base._PLAN_FIELDS + ("X", "pair_info")
 
     def gather_tokens(self, stream=None, into=None):
         """k1: X[r, :] = glove[row_tok[r], :] for the planned token rows (embedding_hub.py:95, frozen table)"""
@@ -226,9 +233,18 @@ class NamlEngine(_Base):
         call("lego_gather_rows", _ptr(self.P["embedding_vocab_table.glove.embedding.weight"]), self.E0, self.E0,
              _ptr(b["row_tok"]), self.Rc, _ptr(b["counters"], 0), _ptr(b["X"]), self.E0, 0, st)
 
+    def plan_pairs(self, stream=None, into=None):
+        """row pairs of the Winograd conv from the plan's seg_off; the pair count lands in counters[5]"""
+        b = self.__dict__ if into is None else into
+        st = _stream() if stream is None else ctypes.c_void_p(stream.cuda_stream)
+        call("lego_plan_pairs", _ptr(b["seg_off"]), self.NIc, _ptr(b["counters"], 1), _ptr(b["pair_info"]),
+             _ptr(b["counters"], 5), st)
+
     def plan_on(self, stream, slot, cand, hist, hist_len):
         super().plan_on(stream, slot, cand, hist, hist_len)
         if self.Rc > 0:
+            if self.wino:
+                self.plan_pairs(stream, self._slots[slot])
             self.gather_tokens(stream, self._slots[slot])
 
     # ------------------------------------------------------------------ streams
@@ -312,6 +328,8 @@ class NamlEngine(_Base):
                 _ptr(self.tb.title_tok), _ptr(self.tb.title_len), self.T,
                 _ptr(self.counters), _ptr(self.inst_item), _ptr(self.seg_off), _ptr(self.hist_off),
                 _ptr(self.rowinfo), _ptr(self.row_tok))
+        if self.wino:
+            self.plan_pairs(m)
 
     def _forward_items(self, training, fork_ev=None, zero_loss=False, gathered=False):
         """item vectors of every planned instance -> self.items[0:NI]"""
@@ -325,7 +343,10 @@ class NamlEngine(_Base):
         # side stream, in the order the main stream needs things: the tap-major conv weights first (their own event:
         # the conv must not wait for the category GEMM), then the loss accumulator, then
         # k2/k4 category embedding + Linear on the length-1 column (cnn_operator.py:58-60) -> Y rows R..R+NI
-        self.kk(sb, None, "lego_conv3_pack", _ptr(P["item_op.cnn.weight"]), _ptr(self.wt), D, D)
+        if self.wino:
+            self.kk(sb, None, "lego_conv3_wino_pack", _ptr(P["item_op.cnn.weight"]), _ptr(self.wino_u), D, D)
+        else:
+            self.kk(sb, None, "lego_conv3_pack", _ptr(P["item_op.cnn.weight"]), _ptr(self.wt), D, D)
         if sb is not m:
             ev[8].record(sb)
         if zero_loss:
@@ -349,8 +370,13 @@ class NamlEngine(_Base):
         if sb is not m:
             m.wait_event(ev[8])                      # packed conv weights (long done: first thing on the side stream)
         # k3: conv + relu + mask + dropout (cnn_operator.py:54-57)
-        self.kk(m, "conv3_fwd", "lego_conv3_fwd", _ptr(self.H), D, _ptr(self.wt), _ptr(P["item_op.cnn.bias"]), _ptr(self.rowinfo),
-                _ptr(self.Y), D, self.Rc, self.cnt(0), D, D, self.drop(self.p_conv, SITE_CONV, training), 0)
+        if self.wino:
+            self.kk(m, "conv3_fwd", "lego_conv3_wino_fwd", _ptr(self.H), D, _ptr(self.wino_u), _ptr(P["item_op.cnn.bias"]),
+                    _ptr(self.pair_info), self.Pc, self.cnt(5), _ptr(self.Y), D, D, D,
+                    self.drop(self.p_conv, SITE_CONV, training))
+        else:
+            self.kk(m, "conv3_fwd", "lego_conv3_fwd", _ptr(self.H), D, _ptr(self.wt), _ptr(P["item_op.cnn.bias"]), _ptr(self.rowinfo),
+                    _ptr(self.Y), D, self.Rc, self.cnt(0), D, D, self.drop(self.p_conv, SITE_CONV, training), 0)
         if sb is not m:
             m.wait_event(ev[1])                      # category rows of Y, zeroed loss
         # k5: additive attention pool over [title tokens..., category] (attention.py:31-38)
@@ -425,15 +451,25 @@ class NamlEngine(_Base):
         # ---- conv weight gradient (side stream C, or LEGO_CONVW=main: after the data gradient on the main stream)
 
         def conv_w():
+            if self.wino:
+                self.kk(cw, "conv3_bwd_weight", "lego_conv3_wino_bwd_weight", _ptr(self.dY), D, _ptr(self.H), D,
+                        _ptr(self.pair_info), self.Pc, self.cnt(5), _ptr(self.wino_du), D, D)
+                self.kk(cw, None, "lego_conv3_wino_unpack_add", _ptr(self.wino_du), _ptr(G["item_op.cnn.weight"]), D, D)
+                return
             self.kk(cw, "conv3_bwd_weight", "lego_conv3_bwd_weight", _ptr(self.dY), D, _ptr(self.H), D, _ptr(self.rowinfo),
                     _ptr(self.dwt), self.Rc, self.cnt(0), D, D)
             self.kk(cw, None, "lego_conv3_unpack_add", _ptr(self.dwt), _ptr(G["item_op.cnn.weight"]), D, D)
         if cw is not m:
             conv_w()
         # ---- main: conv data gradient -> projection weight gradient
-        self.kk(m, "conv3_bwd_data", "lego_conv3_bwd_data", _ptr(self.dY), D, _ptr(self.wt), _ptr(self.rowinfo), _ptr(self.dH), D,
-                self.Rc, self.cnt(0), D, D, self.drop(self.p_proj, SITE_PROJ, training),
-                _ptr(G["embedding_vocab_table.glove.linear.bias"]), 0)
+        if self.wino:
+            self.kk(m, "conv3_bwd_data", "lego_conv3_wino_bwd_data", _ptr(self.dY), D, _ptr(self.wino_u), _ptr(self.pair_info),
+                    self.Pc, self.cnt(5), _ptr(self.dH), D, D, D, self.drop(self.p_proj, SITE_PROJ, training),
+                    _ptr(G["embedding_vocab_table.glove.linear.bias"]))
+        else:
+            self.kk(m, "conv3_bwd_data", "lego_conv3_bwd_data", _ptr(self.dY), D, _ptr(self.wt), _ptr(self.rowinfo), _ptr(self.dH), D,
+                    self.Rc, self.cnt(0), D, D, self.drop(self.p_proj, SITE_PROJ, training),
+                    _ptr(G["embedding_vocab_table.glove.linear.bias"]), 0)
         if cw is m:
             conv_w()
         self.kk(m, "proj_bwd_weight", "lego_linear_bwd_weight", _ptr(self.dH), D, _ptr(self.X), E0,
