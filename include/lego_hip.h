@@ -38,7 +38,12 @@ typedef struct {
     float p;             /* drop probability, 0 = off (eval) */
     uint64_t seed;       /* per-run seed */
     uint32_t site;       /* stream id: site index + 16 * step, so every step draws fresh masks */
+    const uint8_t* mask; /* optional (NULL = draw in the kernel): the keep bits of this (seed, site) made ahead of time by
+                          * lego_dropout_mask over the SAME column count: byte [(row / 4) * cols + col], bit i = row % 4 */
 } lego_dropout;
+
+/* keep bits of one dropout site for rows [0, rows) x cols columns (see lego_dropout.mask); drop->mask is ignored */
+int lego_dropout_mask(const lego_dropout* drop, int rows_cap, const int32_t* rows_dyn, int cols, uint8_t* mask, void* stream);
 
 /* ---- a11 / a2: ragged batch plan.  Replaces Resampler.rebuild_clicks padding + the dense
  * [B,C|S,T] stacking (loader/resampler.py:191-193,213-259) and Shaper.transform

@@ -23,7 +23,7 @@ U32 = ctypes.c_uint32
 
 
 class LegoDropout(ctypes.Structure):
-    _fields_ = [("p", ctypes.c_float), ("seed", ctypes.c_uint64), ("site", ctypes.c_uint32)]
+    _fields_ = [("p", ctypes.c_float), ("seed", ctypes.c_uint64), ("site", ctypes.c_uint32), ("mask", ctypes.c_void_p)]
 
 
 # name -> argtypes (all return int; 0 = ok).  Mirrors include/lego_hip.h one to one.
@@ -40,6 +40,7 @@ SIGNATURES = {
     "lego_colsum": [P, I, I, P, P, I, P, P],
     "lego_conv3_pack": [P, P, I, I, P],
     "lego_conv3_unpack_add": [P, P, I, I, P],
+    "lego_dropout_mask": [P, I, P, I, P, P],
     "lego_plan_pairs": [P, I, P, P, P, P],
     "lego_conv3_wino_pack": [P, P, I, I, P],
     "lego_conv3_wino_unpack_add": [P, P, I, I, P],

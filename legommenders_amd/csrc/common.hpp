@@ -34,17 +34,38 @@ struct Dropout {
     float p;            // drop probability; 0 disables
     uint32_t seed_lo, seed_hi;
     uint32_t site;      // dropout site id (distinct streams per site / step)
+    const uint8_t* mask;   // optional: keep bits precomputed by dropout_mask_kernel (same bits the Philox path draws):
+                           // byte [(row / 4) * ncols + col], bit i = row % 4 -- the epilogues then skip the RNG
 };
 
 // keep-scales for the 4 elements (rows r0..r0+3, r0 % 4 == 0, column c) of a [*, ncols] matrix
 __device__ __forceinline__ void dropout_scale4(const Dropout& d, int r0, int c, int ncols, float (&s)[4]) {
     if (d.p <= 0.f) { s[0] = s[1] = s[2] = s[3] = 1.f; return; }
     const uint64_t ctr = (uint64_t)(r0 >> 2) * (uint64_t)ncols + (uint64_t)c;
+    if (d.mask != nullptr) {
+        const uint32_t bits = d.mask[ctr];
+        const float inv = 1.f / (1.f - d.p);
+        s[0] = (bits & 1u) ? inv : 0.f; s[1] = (bits & 2u) ? inv : 0.f;
+        s[2] = (bits & 4u) ? inv : 0.f; s[3] = (bits & 8u) ? inv : 0.f;
+        return;
+    }
     const Philox4 r = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), d.site, 0u, d.seed_lo, d.seed_hi);
     const uint32_t thr = (uint32_t)(d.p * 4294967296.0f);
     const float inv = 1.f / (1.f - d.p);
     s[0] = r.x >= thr ? inv : 0.f; s[1] = r.y >= thr ? inv : 0.f;
     s[2] = r.z >= thr ? inv : 0.f; s[3] = r.w >= thr ? inv : 0.f;
+}
+
+// the same decisions as 4 keep bits (bit i = row r0 + i); with a precomputed mask this is ONE byte load, which the
+// epilogues issue for their whole tile up front (a load placed between the stores of a tile cannot be hoisted by
+// the compiler and would pay a full memory latency per fragment)
+__device__ __forceinline__ uint32_t dropout_bits4(const Dropout& d, int r0, int c, int ncols) {
+    if (d.p <= 0.f) return 15u;
+    const uint64_t ctr = (uint64_t)(r0 >> 2) * (uint64_t)ncols + (uint64_t)c;
+    if (d.mask != nullptr) return d.mask[ctr];
+    const Philox4 r = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), d.site, 0u, d.seed_lo, d.seed_hi);
+    const uint32_t thr = (uint32_t)(d.p * 4294967296.0f);
+    return (r.x >= thr ? 1u : 0u) | (r.y >= thr ? 2u : 0u) | (r.z >= thr ? 4u : 0u) | (r.w >= thr ? 8u : 0u);
 }
 
 __device__ __forceinline__ float dropout_scale1(const Dropout& d, int r, int c, int ncols) {
@@ -66,5 +87,12 @@ extern "C" const char* lego_last_error(void);
 namespace lego {
 int set_error(const char* fmt, ...);
 int check_launch(const char* what);
+}
+#include "../../include/lego_hip.h"
+namespace lego {
+inline Dropout make_dropout(const lego_dropout* d) {
+    if (d != nullptr && d->p > 0.f) return Dropout{d->p, (uint32_t)d->seed, (uint32_t)(d->seed >> 32), d->site, d->mask};
+    return Dropout{0.f, 0u, 0u, 0u, nullptr};
+}
 }
 #define LEGO_REQUIRE(cond, ...) do { if (!(cond)) return ::lego::set_error(__VA_ARGS__); } while (0)

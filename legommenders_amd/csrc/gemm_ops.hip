@@ -121,6 +121,14 @@ struct EpiT : EpiArgs {
             bcol[b] = bias != nullptr ? bias[colc[b]] : 0.f;
             csum[b] = 0.f;
         }
+        // keep bits of the whole tile first (one byte load each when the mask is precomputed)
+        uint32_t kb[NF][2];
+        const float dinv = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+#pragma unroll
+        for (int a = 0; a < NF; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                kb[a][b] = dropout_bits4(drop, min(m_base + a * 16 + 4 * g4, max(m_end - 1, 0) & ~3) + row_off, colc[b], drop_cols);
 #pragma unroll
         for (int a = 0; a < NF; ++a) {
             const int r0 = m_base + a * 16 + 4 * g4;
@@ -141,7 +149,8 @@ struct EpiT : EpiArgs {
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 float ds[4];
-                dropout_scale4(drop, r0 + row_off, col[b], drop_cols, ds);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ds[i] = (kb[a][b] >> i) & 1u ? dinv : 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float x = acc[a][b][i] + bcol[b];
@@ -180,14 +189,14 @@ namespace lego {
 static Epi make_epi(float* C, int ldc) {
     Epi e;
     e.C = C; e.ldc = ldc; e.bias = nullptr; e.act = 0; e.rowinfo = nullptr;
-    e.drop = Dropout{0.f, 0u, 0u, 0u}; e.drop_cols = 1;
+    e.drop = make_dropout(nullptr); e.drop_cols = 1;
     e.relu_ref = nullptr; e.ld_ref = 0; e.relu_scale = 1.f; e.colsum = nullptr;
     e.tap_stride = 0; e.row_off_dyn = nullptr; e.M = e.N = e.row_off = 0;
     return e;
 }
 static void set_drop(Epi& e, const lego_dropout* d, int cols) {
     if (d != nullptr && d->p > 0.f) {
-        e.drop = Dropout{d->p, (uint32_t)d->seed, (uint32_t)(d->seed >> 32), d->site};
+        e.drop = make_dropout(d);
         e.drop_cols = cols;
     }
 }

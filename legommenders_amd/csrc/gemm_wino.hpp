@@ -224,6 +224,8 @@ __global__ __launch_bounds__(STRIP_THREADS) void wino_kernel(WinoArgs w, EpiArgs
             bcol[b] = (e.bias != nullptr && col[b] < N) ? e.bias[col[b]] : 0.f;
             csum[b] = 0.f;
         }
+        const float dinv = e.drop.p > 0.f ? 1.f / (1.f - e.drop.p) : 1.f;
+        const bool dropping = e.drop.p > 0.f && !(w.dbg & 4);
 #pragma unroll
         for (int a = 0; a < NF; ++a) {
             const int pb = p0 + a * 16 + 4 * g4;
@@ -231,6 +233,19 @@ __global__ __launch_bounds__(STRIP_THREADS) void wino_kernel(WinoArgs w, EpiArgs
             int inf[4];
 #pragma unroll
             for (int v = 0; v < 4; ++v) inf[v] = w.pair_info[min(pb + v, P - 1)];
+            // keep bits of the fragment's 8 rows x 2 columns first: rows r and r + 1 of a pair sit in the same 4-row
+            // group unless r % 4 == 3 (then the second group is fetched too)
+            uint32_t k0[4][2], k1[4][2];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int r = inf[v] >> PI_ROW_SHIFT;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int cc = min(col[b], N - 1);
+                    k0[v][b] = dropping ? dropout_bits4(e.drop, r & ~3, cc, e.drop_cols) : 15u;
+                    k1[v][b] = (dropping && (r & 3) == 3) ? dropout_bits4(e.drop, r + 1, cc, e.drop_cols) : k0[v][b];
+                }
+            }
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 if (pb + v >= p_end) continue;
@@ -242,16 +257,8 @@ __global__ __launch_bounds__(STRIP_THREADS) void wino_kernel(WinoArgs w, EpiArgs
                     float y0 = y0a[a][b][v] + bcol[b];
                     float y1 = y1a[a][b][v] + bcol[b];
                     if (e.act == 1) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); }
-                    if (e.drop.p > 0.f) {
-                        float ds[4];
-                        dropout_scale4(e.drop, r & ~3, col[b], e.drop_cols, ds);
-                        const int i0 = r & 3;
-                        y0 *= i0 == 0 ? ds[0] : (i0 == 1 ? ds[1] : (i0 == 2 ? ds[2] : ds[3]));
-                        if (has2) {
-                            if (i0 == 3) dropout_scale4(e.drop, r + 1, col[b], e.drop_cols, ds);
-                            y1 *= i0 == 0 ? ds[1] : (i0 == 1 ? ds[2] : (i0 == 2 ? ds[3] : ds[0]));
-                        }
-                    }
+                    y0 *= (k0[v][b] >> (r & 3)) & 1u ? dinv : 0.f;
+                    y1 *= (k1[v][b] >> ((r + 1) & 3)) & 1u ? dinv : 0.f;
                     float* dst = e.C + (size_t)r * e.ldc + col[b];
                     dst[0] = y0;
                     csum[b] += y0;

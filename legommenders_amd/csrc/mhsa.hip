@@ -179,8 +179,9 @@ __global__ __launch_bounds__(64) void mhsa_bwd_kernel(const float* __restrict__ 
 }
 
 static Dropout to_drop(const lego_dropout* d) {
-    if (d != nullptr && d->p > 0.f) return Dropout{d->p, (uint32_t)d->seed, (uint32_t)(d->seed >> 32), d->site};
-    return Dropout{0.f, 0u, 0u, 0u};
+    Dropout r = make_dropout(d);
+    r.mask = nullptr;                 // the attention-probability site always draws in-kernel
+    return r;
 }
 
 }  // namespace lego

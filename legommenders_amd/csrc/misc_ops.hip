@@ -244,6 +244,22 @@ __global__ void mask_dropout_rows_kernel(float* __restrict__ x, int ld, int R_ca
     }
 }
 
+// keep bits of one dropout site for rows [0, rows): byte [(row / 4) * cols + col], bit i = row % 4 -- exactly the
+// decisions dropout_scale4 draws in the epilogues, generated ahead of time (prefetch stream) so that the GEMM
+// epilogues read one byte instead of running Philox (a wave64 Philox call is ~500 cycles of VALU)
+__global__ void dropout_mask_kernel(Dropout d, int rows_cap, const int* __restrict__ rows_dyn, int cols, uint8_t* __restrict__ mask) {
+    const int rows = rows_dyn != nullptr ? min(rows_cap, *rows_dyn) : rows_cap;
+    const long long total = (long long)((rows + 3) >> 2) * cols;
+    d.mask = nullptr;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(e / cols);
+        const int c = (int)(e - (long long)g * cols);
+        float s[4];
+        dropout_scale4(d, g << 2, c, cols, s);
+        mask[e] = (uint8_t)((s[0] != 0.f ? 1 : 0) | (s[1] != 0.f ? 2 : 0) | (s[2] != 0.f ? 4 : 0) | (s[3] != 0.f ? 8 : 0));
+    }
+}
+
 __global__ void scatter_add_rows_kernel(float* grad_table, int ld_table, int width, const int* __restrict__ idx,
                                         int rows_cap, const int* __restrict__ rows_dyn, const float* __restrict__ g, int ld_g) {
     const int rows = rows_dyn != nullptr ? min(rows_cap, *rows_dyn) : rows_cap;
@@ -824,12 +840,21 @@ extern "C" int lego_nrms_decode_rows(const int32_t* row_tok, int R_cap, const in
 extern "C" int lego_mask_dropout_rows(float* x, int ld, int R_cap, const int32_t* R_dyn, int width, const int32_t* rowinfo,
                                       const lego_dropout* drop, void* stream) {
     if (R_cap <= 0) return 0;
-    Dropout d{0.f, 0u, 0u, 0u};
-    if (drop != nullptr && drop->p > 0.f) d = Dropout{drop->p, (uint32_t)drop->seed, (uint32_t)(drop->seed >> 32), drop->site};
+    Dropout d = make_dropout(drop);
     const long long total = (long long)R_cap * width;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(mask_dropout_rows_kernel, dim3(blocks), dim3(256), 0, ST, x, ld, R_cap, R_dyn, width, rowinfo, d);
     return check_launch("lego_mask_dropout_rows");
+}
+
+extern "C" int lego_dropout_mask(const lego_dropout* drop, int rows_cap, const int32_t* rows_dyn, int cols, uint8_t* mask,
+                                 void* stream) {
+    LEGO_REQUIRE(drop != nullptr && drop->p > 0.f && drop->p < 1.f, "lego_dropout_mask: needs 0 < p < 1");
+    if (rows_cap <= 0) return 0;
+    const long long total = (long long)((rows_cap + 3) / 4) * cols;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks), dim3(256), 0, ST, make_dropout(drop), rows_cap, rows_dyn, cols, mask);
+    return check_launch("lego_dropout_mask");
 }
 
 extern "C" int lego_scatter_add_rows(float* grad_table, int ld_table, int width, int table_rows, const int32_t* idx,

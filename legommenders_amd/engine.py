@@ -211,6 +211,9 @@ class NamlEngine(_Base):
         self.wino = os.environ.get("LEGO_WINO", "1") != "0" and D <= 256 and self.Rc > 0
         self.Pc = self.NIc * ((self.T + 1) // 2)
         self.pair_info = torch.zeros(max(self.Pc, 1), **i32)
+        self.mask_proj = torch.zeros(((self.Rc + 3) // 4) * D + 1, dtype=torch.uint8, device=self.dev)
+        self.mask_conv = torch.zeros(((self.Rc + 3) // 4) * D + 1, dtype=torch.uint8, device=self.dev)
+        self._slot_mask_step, self._mask_step = {}, -1
         self.wino_u = self._f(4, D, D)
         self.wino_du = self._f(4, D, D)
         # backward workspace
@@ -224,7 +227,30 @@ class NamlEngine(_Base):
     # ------------------------------------------------------------------ prefetched token-row gather
     # The GloVe table is frozen, so the gathered rows X of a batch depend on its plan only: with plan slots enabled
     # (TrainStep) the gather of step N+1 runs right after its plan on the prefetch stream, off the critical path.
-    _PLAN_FIELDS = _Base._PLAN_FIELDS + ("X", "pair_info")
+    _PLAN_FIELDS = _Base._PLAN_FIELDS + ("X", "pair_info", "mask_proj", "mask_conv")
+
+    # ---- dropout keep bits made ahead of time (lego_dropout_mask, same bits the epilogues would draw): the GEMM
+    # epilogues of the step then read one byte per 4 rows x column instead of running Philox on the critical path
+    def prefetch_masks(self, stream, slot):
+        b = self._slots[slot]
+        st = ctypes.c_void_p(stream.cuda_stream)
+        for p, site, key in ((self.p_proj, SITE_PROJ, "mask_proj"), (self.p_conv, SITE_CONV, "mask_conv")):
+            if p > 0.0 and self.Rc > 0:
+                call("lego_dropout_mask", ctypes.byref(LegoDropout(p, self.seed, site + 16 * self.step, None)), self.Rc,
+                     _ptr(b["counters"], 0), self.D, _ptr(b[key]), st)
+        self._slot_mask_step[slot] = self.step
+
+    def use_slot(self, s):
+        super().use_slot(s)
+        self._mask_step = self._slot_mask_step.get(s, -1)
+
+    def drop(self, p, site, training):
+        if not training or p <= 0.0:
+            return None
+        d = LegoDropout(p, self.seed, site + 16 * self.step, None)
+        if self._mask_step == self.step and site in (SITE_PROJ, SITE_CONV):
+            d.mask = (self.mask_proj if site == SITE_PROJ else self.mask_conv).data_ptr()
+        return ctypes.byref(d)
 
     def gather_tokens(self, stream=None, into=None):
         """k1: X[r, :] = glove[row_tok[r], :] for the planned token rows (embedding_hub.py:95, frozen table)"""

@@ -82,6 +82,7 @@ class TrainStep:
         frozen = ("embedding_vocab_table.glove.embedding.weight",) if "embedding_vocab_table.glove.embedding.weight" in params else ()
         self.fp = FlatParams(params, frozen, dev)
         pd = 0.1 if dropout else 0.0
+        self.dropout = dropout
         # `micro` > 1: the batch is processed as `micro` equal micro-batches on their own HIP streams.  Their kernel
         # chains are independent, so one chain's prologue / epilogue / last-wave tail overlaps the other's MFMA main
         # loops; gradients of all micro-batches accumulate (atomics) into the same flat buffer == the full-batch mean.
@@ -152,6 +153,8 @@ class TrainStep:
         self.pre.wait_event(go)                    # the slot's previous user (step_idx - 2) is complete by then
         self.sample_batch(step_idx, slot, self.pre)
         self.engine.plan_on(self.pre, slot, self._cand[slot], self._hist[slot], self._hist_len[slot])
+        if self.dropout and hasattr(self.engine, "prefetch_masks"):
+            self.engine.prefetch_masks(self.pre, slot)     # engine.step == step_idx here (one training forward per step)
         with torch.cuda.stream(self.pre):          # row statistics of the planned batch (bench.py), off the main stream
             self.counter_sum += self.engine._slots[slot]["counters"]
         self._ready[slot].record(self.pre)

