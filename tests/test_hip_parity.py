@@ -449,3 +449,64 @@ def test_precomputed_dropout_mask_equals_in_kernel_draw():
         assert torch.equal(y0, y1)
         keep = float((y0 != 0).float().mean())
         assert abs(keep - 0.75) < 0.01
+
+
+@pytest.mark.parametrize("D,n_items", [(64, 40), (256, 700)])
+def test_winograd_conv_matches_direct_and_torch(D, n_items):
+    """Winograd F(2,3) conv over row pairs (lego_conv3_wino_*) against the direct three-tap kernels on the same
+    ragged plan, and against torch conv1d item by item: forward, data gradient, weight gradient.  Lengths include
+    1 (a pair without a second row), odd and even values."""
+    import ctypes
+    from legommenders_amd._lib import call
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+
+    def P(t, off=0):
+        return ctypes.c_void_p(t.data_ptr() + off * t.element_size())
+    lens = torch.randint(1, 31, (n_items,), generator=g).int()
+    lens[:4] = torch.tensor([1, 2, 3, 30], dtype=torch.int32)
+    seg = torch.zeros(n_items + 1, dtype=torch.int32)
+    seg[1:] = torch.cumsum(lens, 0)
+    R = int(seg[-1])
+    pos = torch.arange(R) - torch.repeat_interleave(seg[:-1].long(), lens.long())
+    ln = torch.repeat_interleave(lens.long(), lens.long())
+    inst = torch.repeat_interleave(torch.arange(n_items), lens.long())
+    rowinfo = ((pos > 0).int() | ((pos < ln - 1).int() << 1) | 4 | (inst.int() << 8)).int().contiguous().to(dev)
+    seg_d = seg.to(dev)
+    cnt = torch.tensor([R, n_items, R + n_items, 0, 0, 0, 0, 0], dtype=torch.int32, device=dev)
+    Pcap = n_items * 15
+    pair = torch.zeros(Pcap, dtype=torch.int32, device=dev)
+    call("lego_plan_pairs", P(seg_d), n_items, P(cnt, 1), P(pair), P(cnt, 5), None)
+    assert int(cnt[5]) == int(((lens + 1) // 2).sum())
+    h = torch.randn(R, D, generator=g)
+    w = torch.randn(D, D, 3, generator=g) * 0.05
+    b = torch.randn(D, generator=g) * 0.1
+    gy = torch.randn(R, D, generator=g)
+    hd, wd, bd, gyd = h.to(dev), w.to(dev), b.to(dev), gy.to(dev)
+    wt = torch.zeros(3, D, D, device=dev); u = torch.zeros(4, D, D, device=dev)
+    call("lego_conv3_pack", P(wd), P(wt), D, D, None)
+    call("lego_conv3_wino_pack", P(wd), P(u), D, D, None)
+    y0 = torch.zeros(R, D, device=dev); y1 = torch.zeros(R, D, device=dev)
+    call("lego_conv3_fwd", P(hd), D, P(wt), P(bd), P(rowinfo), P(y0), D, R, P(cnt, 0), D, D, None, 0, None)
+    call("lego_conv3_wino_fwd", P(hd), D, P(u), P(bd), P(pair), Pcap, P(cnt, 5), P(y1), D, D, D, None, None)
+    d0 = torch.zeros(R, D, device=dev); d1 = torch.zeros(R, D, device=dev)
+    c0 = torch.zeros(D, device=dev); c1 = torch.zeros(D, device=dev)
+    call("lego_conv3_bwd_data", P(gyd), D, P(wt), P(rowinfo), P(d0), D, R, P(cnt, 0), D, D, None, P(c0), 0, None)
+    call("lego_conv3_wino_bwd_data", P(gyd), D, P(u), P(pair), Pcap, P(cnt, 5), P(d1), D, D, D, None, P(c1), None)
+    dwt = torch.zeros(3, D, D, device=dev); du = torch.zeros(4, D, D, device=dev)
+    gw0 = torch.zeros(D, D, 3, device=dev); gw1 = torch.zeros(D, D, 3, device=dev)
+    call("lego_conv3_bwd_weight", P(gyd), D, P(hd), D, P(rowinfo), P(dwt), R, P(cnt, 0), D, D, None)
+    call("lego_conv3_unpack_add", P(dwt), P(gw0), D, D, None)
+    call("lego_conv3_wino_bwd_weight", P(gyd), D, P(hd), D, P(pair), Pcap, P(cnt, 5), P(du), D, D, None)
+    call("lego_conv3_wino_unpack_add", P(du), P(gw1), D, D, None)
+    torch.cuda.synchronize()
+    assert float(du.abs().max()) == 0.0                      # the accumulator is handed back clean
+    _close(y1.cpu(), y0.cpu(), rtol=2e-5, what="wino fwd vs direct")
+    _close(d1.cpu(), d0.cpu(), rtol=2e-5, what="wino bwd_data vs direct")
+    _close(c1.cpu(), c0.cpu(), rtol=2e-5, what="wino bwd_data column sums")
+    _close(gw1.cpu(), gw0.cpu(), rtol=2e-5, what="wino bwd_weight vs direct")
+    # torch conv1d on a few items
+    for i in (0, 1, 2, 3, n_items - 1):
+        s, e = int(seg[i]), int(seg[i + 1])
+        ref = torch.relu(torch.nn.functional.conv1d(h[s:e].T[None], w, b, padding="same")[0].T)
+        _close(y1[s:e].cpu(), ref, rtol=2e-5, what=f"wino fwd vs torch, item {i} len {e - s}")
