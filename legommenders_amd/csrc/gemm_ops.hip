@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include "../../include/lego_hip.h"
 #include "gemm_strip.hpp"
+#include "gemm_oneshot.hpp"
 
 namespace lego {
 
@@ -256,10 +257,30 @@ static int launch_strip(const GemmDims& d, const AL& a, const BL& b, const Epi& 
     return check_launch(what);
 }
 
+// small latency-bound products: every load of a 64 x 64 x K block in flight at once (gemm_oneshot.hpp)
+template <bool B_MC, class EK, class AL, class BL>
+static int launch_oneshot(const GemmDims& d, const AL& a, const BL& b, const Epi& e0, hipStream_t st, const char* what) {
+    EK e;
+    static_cast<EpiArgs&>(e) = e0;
+    auto k = oneshot_kernel<B_MC, AL, BL, EK>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)oneshot_lds_bytes<B_MC>(ONE_KMAX));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3((d.M + ONE_BM - 1) / ONE_BM, (d.N + ONE_BN - 1) / ONE_BN), dim3(ONE_THREADS),
+                       oneshot_lds_bytes<B_MC>(d.K), st, d, a, b, e);
+    return check_launch(what);
+}
+
 template <bool B_MC, class EK, class AL, class BL>
 static int launch_rows(const GemmDims& d, const AL& a, const BL& b, const Epi& e, hipStream_t st, const char* what) {
     const int tm = (d.M + 127) / 128;
     if (d.N <= STRIP_BN && d.M >= 32 * num_cus()) return launch_strip<B_MC, EK>(d, a, b, e, st, what);
+    static const bool oneshot_on = !(getenv("LEGO_ONESHOT") && atoi(getenv("LEGO_ONESHOT")) == 0);
+    if constexpr (std::is_same<AL, KcRows>::value)
+        if (oneshot_on && d.K <= ONE_KMAX && d.K % 4 == 0) return launch_oneshot<B_MC, EK>(d, a, b, e, st, what);
     if (tm * ((d.N + 127) / 128) < 128) {         // few row tiles (user / category side): 64-row tiles fill more CUs
         if (d.N > 64) return launch<C64x128, false, B_MC, EK>(d, a, b, e, (d.M + 63) / 64, (d.N + 127) / 128, 1, st, what);
         return launch<C64x64, false, B_MC, EK>(d, a, b, e, (d.M + 63) / 64, (d.N + 63) / 64, 1, st, what);
@@ -285,7 +306,9 @@ static int pick_split(int rows_cap, int M, int N, int taps) {
     const bool big = taps > 1 && M > 64 && N > 64;
     const int t = big ? 128 : 64;
     const int tiles = ((M + t - 1) / t) * ((N + t - 1) / t) * taps;
-    int s = (big ? 512 : 1024) / tiles;
+    static const int big_blocks = getenv("LEGO_TN_BIG") ? atoi(getenv("LEGO_TN_BIG")) : 512;
+    static const int small_blocks = getenv("LEGO_TN_SMALL") ? atoi(getenv("LEGO_TN_SMALL")) : 1024;
+    int s = (big ? big_blocks : small_blocks) / tiles;
     const int max_s = (rows_cap + 127) / 128;
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
