@@ -295,7 +295,8 @@ static int launch_rows(const GemmDims& d, const AL& a, const BL& b, const Epi& e
 template <class AL, class BL>
 static int launch_tn(const GemmDims& d, const AL& a, const BL& b, const Epi& e, int taps, hipStream_t st, const char* what) {
     const int gz = taps * d.split_k;
-    if (taps > 1 && d.M > 64 && d.N > 64)
+    static const bool all_big = getenv("LEGO_TN_TILE") && atoi(getenv("LEGO_TN_TILE")) == 128;
+    if ((taps > 1 || all_big) && d.M > 64 && d.N > 64)
         return launch<C128x128, true, true, EpiAtomic>(d, a, b, e, (d.M + 127) / 128, (d.N + 127) / 128, gz, st, what);
     return launch<C64x64, true, true, EpiAtomic>(d, a, b, e, (d.M + 63) / 64, (d.N + 63) / 64, gz, st, what);
 }
@@ -303,7 +304,8 @@ static int launch_tn(const GemmDims& d, const AL& a, const BL& b, const Epi& e, 
 static int pick_split(int rows_cap, int M, int N, int taps) {
     // plain products: ~1024 blocks of 64 x 64 (4 x 32 KB of LDS per CU); conv: two rounds of 128 x 128 blocks;
     // at least 128 reduction rows per block
-    const bool big = taps > 1 && M > 64 && N > 64;
+    static const bool all_big = getenv("LEGO_TN_TILE") && atoi(getenv("LEGO_TN_TILE")) == 128;
+    const bool big = (taps > 1 || all_big) && M > 64 && N > 64;
     const int t = big ? 128 : 64;
     const int tiles = ((M + t - 1) / t) * ((N + t - 1) / t) * taps;
     static const int big_blocks = getenv("LEGO_TN_BIG") ? atoi(getenv("LEGO_TN_BIG")) : 512;
