@@ -280,7 +280,9 @@ static int launch_rows(const GemmDims& d, const AL& a, const BL& b, const Epi& e
     if (d.N <= STRIP_BN && d.M >= 32 * num_cus()) return launch_strip<B_MC, EK>(d, a, b, e, st, what);
     static const bool oneshot_on = !(getenv("LEGO_ONESHOT") && atoi(getenv("LEGO_ONESHOT")) == 0);
     if constexpr (std::is_same<AL, KcRows>::value)
-        if (oneshot_on && d.K <= ONE_KMAX && d.K % 4 == 0) return launch_oneshot<B_MC, EK>(d, a, b, e, st, what);
+        if (oneshot_on && d.K <= ONE_KMAX && d.K % 4 == 0 &&
+            ((d.M + ONE_BM - 1) / ONE_BM) * ((d.N + ONE_BN - 1) / ONE_BN) <= num_cus())     // one round of whole-CU blocks
+            return launch_oneshot<B_MC, EK>(d, a, b, e, st, what);
     if (tm * ((d.N + 127) / 128) < 128) {         // few row tiles (user / category side): 64-row tiles fill more CUs
         if (d.N > 64) return launch<C64x128, false, B_MC, EK>(d, a, b, e, (d.M + 63) / 64, (d.N + 127) / 128, 1, st, what);
         return launch<C64x64, false, B_MC, EK>(d, a, b, e, (d.M + 63) / 64, (d.N + 63) / 64, 1, st, what);
