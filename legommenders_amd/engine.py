@@ -424,8 +424,11 @@ class NamlEngine(_Base):
                 _ptr(seg_off), None, extra, n_cap, n_dyn, D, A, _ptr(out), D, _ptr(wrow))
 
     # ------------------------------------------------------------------ backward
-    def backward(self, G: Dict[str, torch.Tensor], gloss: float = 1.0):
-        """Accumulates d(loss)/d(param) into G (reference key names); call after forward(training...)."""
+    def backward(self, G: Dict[str, torch.Tensor], gloss: float = 1.0, before_last=None):
+        """Accumulates d(loss)/d(param) into G (reference key names); call after forward(training...).
+        `before_last()`: called on the host right before the LAST gradient kernel (the projection weight gradient) is
+        enqueued, with every other gradient already ordered on the current stream -- TrainStep starts the all-reduce of
+        those there so that it overlaps the last GEMM."""
         P, B, C, S, D, A, E0 = self.P, self.B, self.C, self.S, self.D, self.A, self.E0
         m, sb, sc = self._lanes()
         ev = self._evs
@@ -505,9 +508,15 @@ class NamlEngine(_Base):
                     _ptr(G["embedding_vocab_table.glove.linear.bias"]), 0)
         if cw is m:
             conv_w()
+        joined = False
+        if before_last is not None and cw is m:
+            self._fork(ev[6], sb, m)                 # the side stream's gradients are part of the early all-reduce
+            joined = True
+            before_last()
         self.kk(m, "proj_bwd_weight", "lego_linear_bwd_weight", _ptr(self.dH), D, _ptr(self.X), E0,
                 _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Rc, self.cnt(0), D, E0, None, None)
-        self._fork(ev[6], sb, m)
+        if not joined:
+            self._fork(ev[6], sb, m)
         if cw is not m:
             self._fork(ev[7], sc, m)
         self.step = step_save

@@ -13,6 +13,7 @@ averaged per-rank gradients are the global-batch gradient).
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, Optional
 
 import torch
@@ -24,14 +25,18 @@ from .engine import ItemTables, NamlEngine, NrmsEngine, _ptr, _stream
 class FlatParams:
     """Trainable tensors as views into one flat fp32 buffer (+ matching grad / Adam-moment buffers)."""
 
-    def __init__(self, params: Dict[str, torch.Tensor], frozen=(), device="cuda"):
-        self.names = [k for k in params if k not in frozen]
+    def __init__(self, params: Dict[str, torch.Tensor], frozen=(), device="cuda", last=()):
+        """`last`: names placed at the end of the flat buffers -- the gradients that finish last in backward, so that
+        everything before `self.split` can be all-reduced while they are still being computed (TrainStep)."""
+        self.names = [k for k in params if k not in frozen and k not in last] + [k for k in last if k in params and k not in frozen]
         sizes = [params[k].numel() for k in self.names]
         self.offsets, off = {}, 0
         for k, n in zip(self.names, sizes):
             self.offsets[k] = off
             off += (n + 3) // 4 * 4                 # keep every tensor 16-B aligned inside the buffer
         self.numel = off
+        tail = [k for k in last if k in self.offsets]
+        self.split = min(self.offsets[k] for k in tail) if tail else 0      # grad[:split] is complete before grad[split:]
         self.flat = torch.zeros(off, dtype=torch.float32, device=device)
         self.grad = torch.zeros_like(self.flat)
         self.m = torch.zeros_like(self.flat)
@@ -80,7 +85,11 @@ class TrainStep:
         dev = data.tables.title_tok.device
         self.data, self.B, self.C, self.K = data, B, K + 1, K
         frozen = ("embedding_vocab_table.glove.embedding.weight",) if "embedding_vocab_table.glove.embedding.weight" in params else ()
-        self.fp = FlatParams(params, frozen, dev)
+        # the projection weight gradient is the last kernel of backward: with LEGO_AR_BUCKETS=2 it is all-reduced on its
+        # own after the rest (which then overlaps that GEMM).  Off by default: at world size 1 under torchrun the second
+        # collective's stream hops cost more than the overlap can save (0.851 vs 0.830 ms/step); to be re-measured on 8 GPUs.
+        last = ("embedding_vocab_table.glove.linear.weight",) if (kind == "naml" and micro == 1) else ()
+        self.fp = FlatParams(params, frozen, dev, last=last)
         pd = 0.1 if dropout else 0.0
         self.dropout = dropout
         # `micro` > 1: the batch is processed as `micro` equal micro-batches on their own HIP streams.  Their kernel
@@ -182,7 +191,16 @@ class TrainStep:
                                           fork_ev=go, neck_ev=neck)
             if self.prefetch:
                 self._prefetch(self.step_idx + 1, neck)        # next batch: starts where this step's item tower ends
-            self.engine.backward(self.fp.G)
+            dist_on = self.world > 1 or self.force_allreduce
+            early = None
+            if dist_on and self.fp.split > 0 and os.environ.get("LEGO_AR_BUCKETS", "1") == "2":
+                def early():       # everything but the projection weight gradient: overlaps the last backward GEMM
+                    self._work = torch.distributed.all_reduce(self.fp.grad[:self.fp.split], group=self.pg, async_op=True)
+            self._work = None
+            if early is not None:
+                self.engine.backward(self.fp.G, before_last=early)
+            else:
+                self.engine.backward(self.fp.G)
         else:
             main = torch.cuda.current_stream()
             Bm = self.B // self.micro
@@ -201,7 +219,12 @@ class TrainStep:
             loss = self.loss
             torch.mean(torch.stack([e.loss for e in self.engines]), dim=0, out=self.loss)
         if self.world > 1 or self.force_allreduce:
-            torch.distributed.all_reduce(self.fp.grad, group=self.pg)      # one RCCL all-reduce per step
+            if getattr(self, "_work", None) is not None:
+                torch.distributed.all_reduce(self.fp.grad[self.fp.split:], group=self.pg)   # the late tail (same RCCL stream:
+                self._work.wait()                                                           # ordered after the early part)
+                self._work = None
+            else:
+                torch.distributed.all_reduce(self.fp.grad, group=self.pg)      # one RCCL all-reduce per step
         self.step_idx += 1
         call("lego_adam_step", _ptr(self.fp.flat), _ptr(self.fp.grad), _ptr(self.fp.m), _ptr(self.fp.v),
              self.fp.numel, self.lr_at(self.step_idx - 1), 0.9, 0.999, 1e-8, self.step_idx, 1.0 / self.world, 1, _stream())
