@@ -41,8 +41,19 @@ __global__ __launch_bounds__(64) void mhsa_fwd_kernel(const float* __restrict__ 
     const bool act = i < L;
     const int ic = act ? i : 0;
     const float scale = rsqrtf((float)HD);
-    const float* kbase = qkv + (size_t)beg * ldq + D + h * HD + half * W;
-    const float* vbase = kbase + D;
+    // K and V rows of this (segment, head) are staged in LDS with coalesced 16-B loads; the inner loops then read
+    // one row per step at a wave-uniform address (broadcast) instead of waiting on a global load per key
+    constexpr int LTS = SPLIT ? 32 : kMaxL;
+    __shared__ __attribute__((aligned(16))) float Ks[LTS][HD];
+    __shared__ __attribute__((aligned(16))) float Vs[LTS][HD];
+    {
+        const float* kg = qkv + (size_t)beg * ldq + D + h * HD;
+        for (int e = lane; e < L * (HD / 4); e += 64) {
+            const int j = e / (HD / 4), c4 = e - j * (HD / 4);
+            *reinterpret_cast<f32x4*>(&Ks[j][4 * c4]) = *reinterpret_cast<const f32x4*>(kg + (size_t)j * ldq + 4 * c4);
+            *reinterpret_cast<f32x4*>(&Vs[j][4 * c4]) = *reinterpret_cast<const f32x4*>(kg + D + (size_t)j * ldq + 4 * c4);
+        }
+    }
     float q[W];
     const float* qrow = qkv + (size_t)(beg + ic) * ldq + h * HD + half * W;
 #pragma unroll
@@ -53,9 +64,10 @@ __global__ __launch_bounds__(64) void mhsa_fwd_kernel(const float* __restrict__ 
     constexpr int LT = SPLIT ? 32 : kMaxL;
     __shared__ float Pl[LT][LT + 1];
     float* ptile = probs + ((size_t)beg * heads + (size_t)h * L) * Lmax;
+    __syncthreads();
     float mx = -INFINITY;                              // pass 1: scores and the row max
     for (int j = 0; j < L; ++j) {
-        float s = dotw<W>(q, kbase + (size_t)j * ldq);
+        float s = dotw<W>(q, &Ks[j][half * W]);
         if (SPLIT) s += __shfl_xor(s, 32, 64);
         mx = fmaxf(mx, s);
         if (half == 0) Pl[j][i < LT ? i : 0] = s;
@@ -75,7 +87,7 @@ __global__ __launch_bounds__(64) void mhsa_fwd_kernel(const float* __restrict__ 
         for (int u = 0; u < 4; ++u) {
             const int j = j0 + u;
             if (j < L) {
-                const float* vr = vbase + (size_t)j * ldq;
+                const float* vr = &Vs[j][half * W];
                 const float p = expf(Pl[j][ic] - mx) * inv;
                 const float pd = p * ds[u];
 #pragma unroll
@@ -110,13 +122,23 @@ __global__ __launch_bounds__(64) void mhsa_bwd_kernel(const float* __restrict__ 
     const int ic = act ? i : 0;
     const float scale = rsqrtf((float)HD);
     const float* qbase = qkv + (size_t)beg * ldq + h * HD + half * W;
-    const float* kbase = qbase + D;
     const float* vbase = qbase + 2 * D;
     const float* gbase = gout + (size_t)beg * ldgo + h * HD + half * W;
     constexpr int LT = SPLIT ? 32 : kMaxL;
     __shared__ float Pl[LT][LT + 1];           // signed probabilities [key j][query i], staged with coalesced loads
+    // two row panels in LDS: (K, V) for pass 1, then (Q, dOut) for pass 2 -- rows are read at wave-uniform addresses
+    __shared__ __attribute__((aligned(16))) float Ra[LT][HD];
+    __shared__ __attribute__((aligned(16))) float Rb[LT][HD];
+    auto stage = [&](const float* a, int lda, const float* b, int ldb) {
+        for (int e = lane; e < L * (HD / 4); e += 64) {
+            const int j = e / (HD / 4), c4 = e - j * (HD / 4);
+            *reinterpret_cast<f32x4*>(&Ra[j][4 * c4]) = *reinterpret_cast<const f32x4*>(a + (size_t)j * lda + 4 * c4);
+            *reinterpret_cast<f32x4*>(&Rb[j][4 * c4]) = *reinterpret_cast<const f32x4*>(b + (size_t)j * ldb + 4 * c4);
+        }
+    };
     const float* ptile = probs + ((size_t)beg * heads + (size_t)h * L) * Lmax;
     for (int e = lane; e < L * L; e += 64) Pl[e / L][e % L] = ptile[e];
+    stage(qkv + (size_t)beg * ldq + D + h * HD, ldq, qkv + (size_t)beg * ldq + 2 * D + h * HD, ldq);      // K, V
     __syncthreads();
     {                                          // ---- pass 1, lane = (query row i, half): dot_i and dQ
         float g[W];
@@ -124,7 +146,7 @@ __global__ __launch_bounds__(64) void mhsa_bwd_kernel(const float* __restrict__ 
         for (int c = 0; c < W; ++c) g[c] = gbase[(size_t)ic * ldgo + c];
         float dot = 0.f;
         for (int j = 0; j < L; ++j) {
-            float dpd = dotw<W>(g, vbase + (size_t)j * ldq);
+            float dpd = dotw<W>(g, &Rb[j][half * W]);
             if (SPLIT) dpd += __shfl_xor(dpd, 32, 64);
             const float ps = Pl[j][ic];                                // sign bit = dropped
             dot += (ps > 0.f ? dpd * keep_scale * ps : 0.f);
@@ -134,8 +156,8 @@ __global__ __launch_bounds__(64) void mhsa_bwd_kernel(const float* __restrict__ 
 #pragma unroll
         for (int c = 0; c < W; ++c) dq[c] = 0.f;
         for (int j = 0; j < L; ++j) {
-            const float* kr = kbase + (size_t)j * ldq;
-            float dpd = dotw<W>(g, vbase + (size_t)j * ldq);
+            const float* kr = &Ra[j][half * W];
+            float dpd = dotw<W>(g, &Rb[j][half * W]);
             if (SPLIT) dpd += __shfl_xor(dpd, 32, 64);
             const float ps = Pl[j][ic];
             const float dS = fabsf(ps) * ((ps > 0.f ? dpd * keep_scale : 0.f) - dot);
@@ -149,13 +171,15 @@ __global__ __launch_bounds__(64) void mhsa_bwd_kernel(const float* __restrict__ 
         }
     }
     __syncthreads();
+    stage(qkv + (size_t)beg * ldq + h * HD, ldq, gout + (size_t)beg * ldgo + h * HD, ldgo);                   // Q, dOut
+    __syncthreads();
     {                                          // ---- pass 2, lane = (key row j, half): dK[j], dV[j]; probs read by column
         float own[W], dk[W], dv[W];
 #pragma unroll
         for (int c = 0; c < W; ++c) { own[c] = vbase[(size_t)ic * ldq + c]; dk[c] = 0.f; dv[c] = 0.f; }
         for (int r = 0; r < L; ++r) {
-            const float* qr = qbase + (size_t)r * ldq;
-            const float* gr = gbase + (size_t)r * ldgo;
+            const float* qr = &Ra[r][half * W];
+            const float* gr = &Rb[r][half * W];
             const float ps = Pl[ic][r];
             float dpd = dotw<W>(own, gr);
             if (SPLIT) dpd += __shfl_xor(dpd, 32, 64);
