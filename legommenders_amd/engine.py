@@ -609,32 +609,55 @@ class NrmsEngine(_Base):
              _ptr(P[pre + "additive_attention.encoder.2.weight"]), _ptr(seg_off), None, None, n_cap, n_dyn, D, A,
              _ptr(out), D, _ptr(ws["wrow"]), st)
 
-    def _att_bwd(self, pre, ws, G, x_ptr, dx_ptr, rows_dyn, seg_off, n_cap, n_dyn, gout, site, training, st):
+    def _side(self):
+        """side HIP stream for the weight-gradient products: they overlap the latency-bound attention-core kernels of the
+        data-gradient chain (LEGO_SERIAL=1: everything on the current stream)"""
+        if getattr(self, "_sw", None) is None:
+            self._sw = torch.cuda.Stream(self.dev)
+            self._sev = [torch.cuda.Event() for _ in range(6)]
+        m = torch.cuda.current_stream()
+        return m, (m if os.environ.get("LEGO_SERIAL") == "1" else self._sw)
+
+    def _att_bwd(self, pre, ws, G, x_ptr, dx_ptr, rows_dyn, seg_off, n_cap, n_dyn, gout, site, training, st, ev):
+        """data-gradient chain on the current stream `st`; weight gradients in two groups on the side stream, each behind
+        ONE event (`ev[0]`, `ev[1]`) recorded where its inputs are final (the workspace is not overwritten before the
+        next forward, which the caller orders after the side stream)"""
         P, D, A = self.P, self.D, self.A
         rows = ws["rows"]
+        m, sw = self._side()
+        sp = ctypes.c_void_p(sw.cuda_stream)
         call("lego_additive_pool_bwd", _ptr(ws["t"]), A, _ptr(ws["lin"]), D,
              _ptr(P[pre + "additive_attention.encoder.2.weight"]), _ptr(seg_off), None, n_cap, n_dyn, D, A,
              _ptr(gout), D, _ptr(ws["wrow"]), _ptr(ws["d_lin"]), D,
              _ptr(G[pre + "additive_attention.encoder.2.weight"]), _ptr(G[pre + "additive_attention.encoder.0.bias"]), st)
-        call("lego_linear_bwd_weight", _ptr(ws["t"]), A, _ptr(ws["lin"]), D,
-             _ptr(G[pre + "additive_attention.encoder.0.weight"]), D, rows, rows_dyn, A, D, None, None, st)
         # d_lin += dpre . W1 ; its column sums are the gradient of linear.bias
         call("lego_linear_bwd_data", _ptr(ws["t"]), A, _ptr(P[pre + "additive_attention.encoder.0.weight"]), D,
              _ptr(ws["d_lin"]), D, rows, rows_dyn, A, D, 1, None, 0, 1.0, None, None, _ptr(G[pre + "linear.bias"]), None, None, st)
-        call("lego_linear_bwd_weight", _ptr(ws["d_lin"]), D, _ptr(ws["att"]), D, _ptr(G[pre + "linear.weight"]), D,
-             rows, rows_dyn, D, D, None, None, st)
         call("lego_linear_bwd_data", _ptr(ws["d_lin"]), D, _ptr(P[pre + "linear.weight"]), D, _ptr(ws["d_att"]), D,
              rows, rows_dyn, D, D, 0, None, 0, 1.0, None, None, _ptr(G[pre + "multi_head_attention.out_proj.bias"]), None, None, st)
+        if sw is not m:
+            ev[0].record(m)
+            sw.wait_event(ev[0])
+        # ---- side, group 1: W1, Linear and out-projection weight gradients (inputs: dpre, lin, d_lin, att, d_att, o)
+        call("lego_linear_bwd_weight", _ptr(ws["t"]), A, _ptr(ws["lin"]), D,
+             _ptr(G[pre + "additive_attention.encoder.0.weight"]), D, rows, rows_dyn, A, D, None, None, sp)
+        call("lego_linear_bwd_weight", _ptr(ws["d_lin"]), D, _ptr(ws["att"]), D, _ptr(G[pre + "linear.weight"]), D,
+             rows, rows_dyn, D, D, None, None, sp)
         call("lego_linear_bwd_weight", _ptr(ws["d_att"]), D, _ptr(ws["o"]), D,
-             _ptr(G[pre + "multi_head_attention.out_proj.weight"]), D, rows, rows_dyn, D, D, None, None, st)
+             _ptr(G[pre + "multi_head_attention.out_proj.weight"]), D, rows, rows_dyn, D, D, None, None, sp)
+        # ---- main: out-projection data gradient, attention core
         call("lego_linear_bwd_data", _ptr(ws["d_att"]), D, _ptr(P[pre + "multi_head_attention.out_proj.weight"]), D,
              _ptr(ws["d_o"]), D, rows, rows_dyn, D, D, 0, None, 0, 1.0, None, None, None, None, None, st)
         call("lego_mhsa_core_bwd", _ptr(ws["qkv"]), 3 * D, _ptr(seg_off), n_cap, n_dyn, D, self.heads, _ptr(ws["d_o"]), D,
              _ptr(ws["probs"]), ws["Lmax"], self.drop(self.p_att, site, training), rows, _ptr(ws["d_qkv"]), 3 * D, st)
+        if sw is not m:
+            ev[1].record(m)
+            sw.wait_event(ev[1])
+        # ---- side, group 2: in-projection bias and weight gradients
         call("lego_colsum", _ptr(ws["d_qkv"]), 3 * D, rows, rows_dyn, None, 3 * D,
-             _ptr(G[pre + "multi_head_attention.in_proj_bias"]), st)
+             _ptr(G[pre + "multi_head_attention.in_proj_bias"]), sp)
         call("lego_linear_bwd_weight", _ptr(ws["d_qkv"]), 3 * D, x_ptr, D,
-             _ptr(G[pre + "multi_head_attention.in_proj_weight"]), D, rows, rows_dyn, 3 * D, D, None, None, st)
+             _ptr(G[pre + "multi_head_attention.in_proj_weight"]), D, rows, rows_dyn, 3 * D, D, None, None, sp)
         call("lego_linear_bwd_data", _ptr(ws["d_qkv"]), 3 * D, _ptr(P[pre + "multi_head_attention.in_proj_weight"]), D,
              dx_ptr, D, rows, rows_dyn, 3 * D, D, 0, None, 0, 1.0, None, None, None, None, None, st)
 
@@ -699,10 +722,12 @@ class NrmsEngine(_Base):
             self.step -= 1
         call("lego_dot_ce_bwd", _ptr(self.user), D, _ptr(self.items), D, _ptr(self.scores), B, C, D,
              float(gloss) / B, _ptr(self.d_user), D, _ptr(self.d_items), D, st)
+        m, sw = self._side()
+        sev = self._sev if sw is not m else [None] * 6
         self._att_bwd("user_op.", self.user_ws, G, _ptr(self.items, self.BC * D), _ptr(self.d_items, self.BC * D),
-                      self.cnt(3), self.hist_off, B, None, self.d_user, SITE_USER_ATT, training, st)
+                      self.cnt(3), self.hist_off, B, None, self.d_user, SITE_USER_ATT, training, st, sev[0:2])
         self._att_bwd("item_op.", self.item_ws, G, _ptr(self.E), _ptr(self.dE), self.cnt(0), self.seg_off, self.NIc,
-                      self.cnt(1), self.d_items, SITE_ITEM_ATT, training, st)
+                      self.cnt(1), self.d_items, SITE_ITEM_ATT, training, st, sev[2:4])
         # embedding tables: the three summed look-ups of ConcatInputer.get_embeddings
         call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.__cat_inputer_special_ids.weight"]), D, D, 3,
              _ptr(self.idx_spec), self.Rc, self.cnt(0), _ptr(self.dE), D, st)
@@ -721,4 +746,7 @@ class NrmsEngine(_Base):
             call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.glove.weight"]), D, D,
                  G["embedding_vocab_table.glove.weight"].shape[0], _ptr(self.idx_tok),
                  self.Rc, self.cnt(0), _ptr(self.dE), D, st)
+        if sw is not m:
+            sev[4].record(sw)
+            m.wait_event(sev[4])                     # every gradient is ordered on the caller's stream again
         self.step = step_save
