@@ -157,3 +157,26 @@ class CommandInit:
         for _ in range(4):                           # references may point at references
             root = _resolve(root, root)
         return Obj(root)
+
+
+class ModelInit:
+    """Name -> local checkpoint of a pretrained language model (mirror of the reference's utils/config_init.py:172-185,
+    which keeps `bertbase = bert-base-uncased`-style lines in a `.model` file).  Looked up in `LEGO_MODEL_<NAME>` first,
+    then in `./.model`; returns None when the name is unknown (the operator then explains what to configure)."""
+
+    @classmethod
+    def examples(cls):
+        return "\n".join(["bertbase = bert-base-uncased", "bertlarge = bert-large-uncased"])
+
+    @classmethod
+    def get(cls, name: str):
+        v = os.environ.get("LEGO_MODEL_" + name.upper())
+        if v:
+            return v
+        if os.path.exists(".model"):
+            for line in open(".model"):
+                if "=" in line and not line.lstrip().startswith("#"):
+                    k, val = line.split("=", 1)
+                    if k.strip() == name:
+                        return val.strip()
+        return None

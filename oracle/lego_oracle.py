@@ -221,6 +221,67 @@ def nrms_forward(P, title_tok, title_len, cat, cand, hist, hist_len, heads=8, gl
     return dot_scores(user, cand_v)
 
 
+# --------------------------------------------------------------------------- 8(f)-2: BERT news encoder
+def bert_encoder(x, mask, P, prefix, n_layers, heads, eps=1e-12):
+    """`BertModel(inputs_embeds=x, attention_mask=mask).last_hidden_state` with `word_embeddings = None`
+    (reference call sites: model/operators/once_operator.py:156-170 `_forward`, bert_operator.py:16).
+
+    The arithmetic lives in the third-party `transformers` package (reference pin `transformers~=4.47.1`,
+    requirements.txt:10; the fixtures were generated with the version recorded in their meta).  Published algorithm
+    (Devlin et al. 2019; modeling_bert.py BertEmbeddings / BertSelfAttention / BertSelfOutput / BertIntermediate /
+    BertOutput): h0 = LayerNorm(x + type_emb[0] + pos_emb[:L]); per layer: scores = QK^T/sqrt(dh) + (1-mask)*finfo.min
+    over keys, softmax, context; a = LayerNorm(dense(context) + h); h = LayerNorm(dense(gelu(dense(a))) + a).  x:[n,L,H]."""
+    n, L, H = x.shape
+    dh = H // heads
+    h = x + P[prefix + "embeddings.token_type_embeddings.weight"][0] + P[prefix + "embeddings.position_embeddings.weight"][:L]
+    h = F.layer_norm(h, (H,), P[prefix + "embeddings.LayerNorm.weight"], P[prefix + "embeddings.LayerNorm.bias"], eps)
+    ext = (1.0 - mask.to(x.dtype))[:, None, None, :] * torch.finfo(x.dtype).min
+    for l in range(n_layers):
+        lp = f"{prefix}encoder.layer.{l}."
+
+        def heads_of(name):
+            y = F.linear(h, P[lp + f"attention.self.{name}.weight"], P[lp + f"attention.self.{name}.bias"])
+            return y.view(n, L, heads, dh).permute(0, 2, 1, 3)
+        q, k, v = heads_of("query"), heads_of("key"), heads_of("value")
+        probs = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(dh) + ext, dim=-1)
+        ctx = (probs @ v).permute(0, 2, 1, 3).reshape(n, L, H)
+        a = F.layer_norm(F.linear(ctx, P[lp + "attention.output.dense.weight"], P[lp + "attention.output.dense.bias"]) + h,
+                         (H,), P[lp + "attention.output.LayerNorm.weight"], P[lp + "attention.output.LayerNorm.bias"], eps)
+        i = F.gelu(F.linear(a, P[lp + "intermediate.dense.weight"], P[lp + "intermediate.dense.bias"]))
+        h = F.layer_norm(F.linear(i, P[lp + "output.dense.weight"], P[lp + "output.dense.bias"]) + a,
+                         (H,), P[lp + "output.LayerNorm.weight"], P[lp + "output.LayerNorm.bias"], eps)
+    return h
+
+
+def bert_operator(x, mask, P, prefix, n_layers, heads, eps=1e-12):
+    """OnceOperator.forward, `tune_from` falsy branch (once_operator.py:173-193): transformer -> Linear -> additive pool.
+    `n_layers` = layers KEPT: with the yaml default tune_from = 0 the constructor still slices `encoder.layer[1:]`
+    (once_operator.py:128-134, bert_operator.py:23-24) and forward runs the remaining layers on the input embeddings."""
+    h = bert_encoder(x, mask, P, prefix + "transformer.", n_layers, heads, eps)
+    y = F.linear(h, P[prefix + "linear.weight"], P[prefix + "linear.bias"])
+    return additive_attention(y, mask, P[prefix + "additive_attention.encoder.0.weight"],
+                              P[prefix + "additive_attention.encoder.0.bias"],
+                              P[prefix + "additive_attention.encoder.2.weight"])
+
+
+def bert_naml_forward(P, title_tok, title_len, cat, cand, hist, hist_len, n_layers, heads, eps=1e-12):
+    """Legommender.forward for config/model/bert-naml.yaml (item = BertBase over ConcatInputer without CLS/SEP,
+    user = Ada, predictor = Dot), eval-mode logits [B,C]."""
+    ids, B, C, S = _item_ids(cand, hist)
+    t_ids, c_ids, _, mask = concat_layout(title_tok[ids], title_len[ids], cat[ids], use_sep=False)
+    e_t, _ = table_lookup(t_ids, P["embedding_vocab_table.glove.weight"])
+    e_c, _ = table_lookup(c_ids, P["embedding_vocab_table.category.weight"])
+    items = bert_operator(e_t + e_c, mask, P, "item_op.", n_layers, heads, eps)
+    D = items.shape[-1]
+    cand_v = items[: B * C].view(B, C, D)
+    hist_v = items[B * C:].view(B, S, D)
+    hmask = (torch.arange(S)[None, :] < hist_len[:, None]).long()
+    user = additive_attention(hist_v, hmask, P["user_op.additive_attention.encoder.0.weight"],
+                              P["user_op.additive_attention.encoder.0.bias"],
+                              P["user_op.additive_attention.encoder.2.weight"])
+    return dot_scores(user, cand_v)
+
+
 def eval_scores(kind, P, title_tok, title_len, cat, user_hist, user_hist_len, rows_user, rows_item, heads=8, glove=True):
     """The reference's fast-eval path: all-item cache (loader/cacher/item_cacher.py:51-97), all-user cache from
     `item_repr[history]` (loader/cacher/user_cacher.py:63-97, model/legommender.py:153-157,202-214), then
@@ -246,7 +307,7 @@ def eval_scores(kind, P, title_tok, title_len, cat, user_hist, user_hist_len, ro
     return (user_repr[rows_user] * item_repr[rows_item]).sum(-1), item_repr, user_repr
 
 
-def loss_and_grads(kind, P_np, tables, cand, hist, hist_len, heads=8, glove=True, frozen=()):
+def loss_and_grads(kind, P_np, tables, cand, hist, hist_len, heads=8, glove=True, frozen=(), bert_layers=0, bert_eps=1e-12):
     """Logits, loss and d(loss)/d(param) for every trainable tensor (dropout 0).  numpy in/out."""
     P = {}
     for k, v in P_np.items():
@@ -258,6 +319,8 @@ def loss_and_grads(kind, P_np, tables, cand, hist, hist_len, heads=8, glove=True
     c, h, hl = _t(cand), _t(hist), _t(hist_len)
     if kind == "naml":
         logits = naml_forward(P, tt, ct, c, h, hl)
+    elif kind == "bert_naml":
+        logits = bert_naml_forward(P, tt, tl, ct, c, h, hl, bert_layers, heads, bert_eps)
     else:
         logits = nrms_forward(P, tt, tl, ct, c, h, hl, heads=heads, glove=glove)
     loss = ce_label0(logits)

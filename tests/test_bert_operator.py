@@ -1,0 +1,105 @@
+"""the BERT news encoder plug-in (BertBaseOperator) -- discovery, construction rules and, on the GPU,
+logits / loss / gradients of `Legommender.forward` against the reference's own run (tests/golden/bert_naml_small.npz,
+random-init BertConfig: no pretrained weights exist offline)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import load_model_fixture
+
+
+def _lego_config(meta, tables, P, ops, preds, item_config_extra=None):
+    from legommenders_amd.loader.column_map import ColumnMap
+    from legommenders_amd.loader.embedding_hub import EmbeddingHub
+    from legommenders_amd.loader.tables import Feature, Table, Vocab
+    from legommenders_amd.model.lego_config import LegoConfig
+    D, H, V = meta["D"], meta["item_hidden"], meta["V"]
+    n_items = tables["title_tok"].shape[0]
+    tok_v, cat_v, item_v = Vocab("glove", V), Vocab("category", 18), Vocab("item_id", n_items)
+    user_v = Vocab("user_id", tables["user_hist"].shape[0])
+    item_ut = Table([Feature("item_id", item_v), Feature("title@glove", tok_v, 30), Feature("category", cat_v)],
+                    {"item_id": np.arange(n_items), "title@glove": (tables["title_tok"], tables["title_len"]),
+                     "category": tables["cat"]}, "item_id")
+    user_ut = Table([Feature("user_id", user_v), Feature("history", item_v, 50)],
+                    {"user_id": np.arange(user_v.size), "history": (tables["user_hist"], tables["user_hist_len"])}, "user_id")
+    item_config = {"tune_from": 0, "use_lora": False, "lora_r": None, "lora_alpha": None,
+                   "inputer_config": {"use_cls_token": False, "use_sep_token": False},
+                   "transformer_config": dict(meta["bert"], hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)}
+    item_config.update(item_config_extra or {})
+    lc = LegoConfig(hidden_size=D, item_hidden_size=H, neg_count=4,
+                    user_config={"inputer_config": {"use_cls_token": False, "use_sep_token": False}}, item_config=item_config)
+    lc.set_component_classes(ops["BertBase"], ops["Ada"], preds["Dot"])
+    lc.set_item_ut(item_ut, ["title@glove", "category"])
+    lc.set_user_ut(user_ut, ["history"])
+    lc.set_column_map(ColumnMap(item_col="item_id", user_col="user_id", history_col="history", neg_col="neg",
+                                label_col="click", group_col="user_id"))
+    eh = EmbeddingHub(embedding_dim=H, transformation="auto", transformation_dropout=0.0)
+    eh.load_pretrained_embedding(None, vocab_name="glove", frozen=True, array=P["embedding_vocab_table.glove.weight"])
+    eh.register_ut(item_ut, ["title@glove", "category"])
+    lc.set_embedding_hub(eh)
+    return lc
+
+
+def test_class_hub_registers_the_reference_names():
+    from legommenders_amd.loader.class_hub import ClassHub
+    ops = ClassHub.operators()
+    assert {"bert", "bertbase", "bertlarge"} <= set(ops.list())
+    assert ops["BertBase"].__name__ == "BertBaseOperator"
+    assert ops["BertBase"].config_class.__name__ == "OnceOperatorConfig"
+
+
+@pytest.mark.gpu
+def test_construction_rules_follow_the_reference():
+    from legommenders_amd.loader.class_hub import ClassHub
+    from legommenders_amd.loader.env import Env
+    Env.set_device(torch.device("cuda:0"))
+    meta, P, G, tables, batch, logits, loss = load_model_fixture("bert_naml_small")
+    ops, preds = ClassHub.operators(), ClassHub.predictors()
+    with pytest.raises(ValueError, match="does not match input_dim"):          # bert_operator.py:19-21
+        bad = dict(meta["bert"], hidden_size=32, num_attention_heads=4)
+        _lego_config(meta, tables, P, ops, preds, {"transformer_config": bad}).build_components()
+    with pytest.raises(NotImplementedError, match="peft"):
+        _lego_config(meta, tables, P, ops, preds, {"use_lora": True, "lora_r": 8, "lora_alpha": 16}).build_components()
+    with pytest.raises(NotImplementedError, match="tune_from"):
+        _lego_config(meta, tables, P, ops, preds, {"tune_from": 1}).build_components()
+    with pytest.raises(ValueError, match="no local checkpoint"):                # no network: the checkpoint must be local
+        _lego_config(meta, tables, P, ops, preds, {"transformer_config": None}).build_components()
+
+
+@pytest.mark.gpu
+def test_bert_naml_matches_reference_logits_loss_grads():
+    from legommenders_amd.engine import ItemTables
+    from legommenders_amd.loader.class_hub import ClassHub
+    from legommenders_amd.loader.env import Env
+    from legommenders_amd.model.legommender import Legommender
+    dev = torch.device("cuda:0")
+    Env.set_device(dev)
+    meta, P, G, tables, batch, logits, loss = load_model_fixture("bert_naml_small")
+    lc = _lego_config(meta, tables, P, ClassHub.operators(), ClassHub.predictors())
+    lc.build_components()
+    lc.register_inputer_vocabs()
+    model = Legommender(lc).to(dev)
+    assert len(model.item_op.transformer.encoder.layer) == meta["layers_kept"]   # tune_from = 0 drops block 0, as upstream
+    missing, unexpected = model.load_state_dict({k: torch.tensor(v) for k, v in P.items()}, strict=False)
+    assert not unexpected and all(m.startswith("_") for m in missing), (missing, unexpected)
+    assert set(P) == set(model.state_dict()), set(P) ^ set(model.state_dict())    # identical key set to the reference
+    tb = ItemTables(tables["title_tok"], tables["title_len"], tables["cat"], dev)
+    model.attach_item_table(tb)
+    ids = {"item_id": torch.tensor(batch["cand"]), "history": torch.tensor(batch["hist"]),
+           "__clicks_mask__": (torch.arange(50)[None] < torch.tensor(batch["hist_len"])[:, None]).long()}
+    Env.train()
+    model.train()
+    out = model(batch=dict(ids))
+    assert abs(float(out) - loss) < 2e-5
+    out.backward()
+    gscale = max(float(np.abs(g).max()) for g in G.values())
+    got = dict(model.named_parameters())
+    for k, g in G.items():
+        d = got[k].grad.detach().cpu().numpy().astype(np.float64) - g
+        assert float(np.abs(d).max()) <= 2e-3 * float(np.abs(g).max()) + 2e-6 * gscale, (k, float(np.abs(d).max()))
+    Env.test()
+    model.eval()
+    with torch.no_grad():
+        scores = model(batch=dict(ids))
+    assert float(np.abs(scores.cpu().numpy() - logits).max()) < 1e-3               # the north-star bar on fp32 logits
+    assert float(np.abs(scores.cpu().numpy() - logits).max()) < 1e-4

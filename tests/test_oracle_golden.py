@@ -111,3 +111,19 @@ def test_product_metrics_match_metricpool_and_oracle():
     ref = O.grouped_metrics(z["scores"], z["labels"], z["groups"], names=names)
     for n, v in zip(names, z["values"]):
         assert abs(got[n] - float(v)) < 5e-7 and abs(got[n] - ref[n]) < 1e-9, n
+
+
+def test_bert_news_encoder_full_forward_backward():
+    """the oracle's restatement of the BERT news encoder path (transformers' BertModel arithmetic +
+    once_operator.py's Linear + additive pool, with the tune_from = 0 layer slicing) against the reference run."""
+    meta, P, G, tables, batch, logits, loss = load_model_fixture("bert_naml_small")
+    lg, ls, g = O.loss_and_grads("bert_naml", P, tables, batch["cand"], batch["hist"], batch["hist_len"], heads=meta["heads"],
+                                 frozen=("embedding_vocab_table.glove.weight",), bert_layers=meta["layers_kept"],
+                                 bert_eps=meta["bert"]["layer_norm_eps"])
+    assert meta["layers_kept"] == meta["bert"]["num_hidden_layers"] - 1          # the reference dropped block 0
+    np.testing.assert_allclose(lg, logits, rtol=1e-5, atol=2e-6)
+    assert abs(ls - loss) < 2e-6
+    gscale = max(float(np.abs(v).max()) for v in G.values())
+    assert len(G) == 45
+    for k, v in G.items():
+        assert float(np.abs(g[k] - v).max()) <= 1e-4 * float(np.abs(v).max()) + 1e-6 * gscale, k

@@ -1,0 +1,94 @@
+"""Throughput of the BERT-NAML plug-in route (BERT-base news encoder, item_hidden = 768) on one
+MI355X: `Legommender.forward` + backward + torch Adam on a MIND-small-shaped synthetic world, random-init BERT-base
+(no pretrained weights offline; tune_from = 0 -> 11 of the 12 blocks run, as in the reference).
+
+    python tools/bert_naml_bench.py [--batch 64] [--steps 5] [--layers 12] [--hidden 256]
+The transformer runs through PyTorch-ROCm; the table gather, Linear(768 -> D), additive pools, dot + CE are the path's kernels."""
+import argparse, os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--hidden", type=int, default=256)
+    a = ap.parse_args()
+    from legommenders_amd.engine import ItemTables
+    from legommenders_amd.loader.class_hub import ClassHub
+    from legommenders_amd.loader.column_map import ColumnMap
+    from legommenders_amd.loader.embedding_hub import EmbeddingHub
+    from legommenders_amd.loader.env import Env
+    from legommenders_amd.loader.tables import Feature, Table, Vocab
+    from legommenders_amd.model.lego_config import LegoConfig
+    from legommenders_amd.model.legommender import Legommender
+    from legommenders_amd.synthetic import MIND_SMALL, make_world
+    dev = torch.device("cuda:0")
+    Env.set_device(dev)
+    cfg = dict(MIND_SMALL); cfg.update(n_items=5000, n_users=4000, n_rows=20000, V=30522)
+    w = make_world(seed=2023, **cfg)
+    H, D, V = 768, a.hidden, cfg["V"]
+    n_items = w["title_tok"].shape[0]
+    tok_v, cat_v, item_v = Vocab("bert", V), Vocab("category", cfg["n_cat"]), Vocab("item_id", n_items)
+    user_v = Vocab("user_id", w["user_hist"].shape[0])
+    item_ut = Table([Feature("item_id", item_v), Feature("title@bert", tok_v, 30), Feature("category", cat_v)],
+                    {"item_id": np.arange(n_items), "title@bert": (w["title_tok"], w["title_len"]), "category": w["cat"]}, "item_id")
+    user_ut = Table([Feature("user_id", user_v), Feature("history", item_v, 50)],
+                    {"user_id": np.arange(user_v.size), "history": (w["user_hist"], w["user_hist_len"])}, "user_id")
+    bert = dict(vocab_size=V, hidden_size=H, num_hidden_layers=a.layers, num_attention_heads=12, intermediate_size=3072,
+                max_position_embeddings=512)
+    ops, preds = ClassHub.operators(), ClassHub.predictors()
+    lc = LegoConfig(hidden_size=D, item_hidden_size=H, neg_count=4,
+                    user_config={"inputer_config": {"use_cls_token": False, "use_sep_token": False}},
+                    item_config={"tune_from": 0, "use_lora": False, "lora_r": None, "lora_alpha": None,
+                                 "inputer_config": {"use_cls_token": False, "use_sep_token": False}, "transformer_config": bert})
+    lc.set_component_classes(ops["BertBase"], ops["Ada"], preds["Dot"])
+    lc.set_item_ut(item_ut, ["title@bert", "category"])
+    lc.set_user_ut(user_ut, ["history"])
+    lc.set_column_map(ColumnMap(item_col="item_id", user_col="user_id", history_col="history", neg_col="neg",
+                                label_col="click", group_col="user_id"))
+    eh = EmbeddingHub(embedding_dim=H, transformation="auto", transformation_dropout=0.1)
+    eh.load_pretrained_embedding(None, vocab_name="bert", frozen=True,
+                                 array=(np.random.RandomState(1).standard_normal((V, H)) * 0.02).astype(np.float32))
+    eh.register_ut(item_ut, ["title@bert", "category"])
+    lc.set_embedding_hub(eh)
+    lc.build_components()
+    lc.register_inputer_vocabs()
+    model = Legommender(lc).to(dev)
+    model.attach_item_table(ItemTables(w["title_tok"], w["title_len"], w["cat"], dev))
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
+    B, S = a.batch, 50
+    rs = np.random.RandomState(0)
+    Env.train(); model.train()
+
+    def step():
+        users = rs.randint(0, user_v.size, size=B)
+        cand = rs.randint(0, n_items, size=(B, 5))
+        hist = w["user_hist"][users]
+        hl = w["user_hist_len"][users]
+        ids = {"item_id": torch.tensor(cand), "history": torch.tensor(hist),
+               "__clicks_mask__": (torch.arange(S)[None] < torch.tensor(hl)[:, None]).long()}
+        opt.zero_grad(set_to_none=True)
+        loss = model(batch=ids)
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    n_par = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    print({"model": "BERT-NAML plug-in route", "batch": B, "bert_layers_run": len(model.item_op.transformer.encoder.layer),
+           "trainable_params": n_par, "s_per_step": round(dt, 4), "impressions_per_s": round(B / dt, 1), "loss": float(loss.detach())})
+
+
+if __name__ == "__main__":
+    main()
