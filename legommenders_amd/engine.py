@@ -456,13 +456,6 @@ class NamlEngine(_Base):
         conv_w_main = os.environ.get("LEGO_CONVW", "main") == "main"
         keep = 1.0 / (1.0 - self.p_conv) if (training and self.p_conv > 0) else 1.0
         w1 = _ptr(P["item_op.additive_attention.encoder.0.weight"])
-        # ---- main: token rows: dY = relu'(.)*keep * (dY + dpre.W1); column sums -> conv bias grad
-        # (LEGO_FORK4=late enqueues it BEFORE the fork so that the event completes behind this row-strip GEMM; measured
-        # slower than forking first -- 0.779 vs 0.771 ms/step -- so the default forks first)
-        late_fork = os.environ.get("LEGO_FORK4", "early") == "late"
-        if late_fork:
-            self.kk(m, "additive_bwd_data", "lego_linear_bwd_data", _ptr(self.Tt), A, w1, D, _ptr(self.dY), D, self.Rc, self.cnt(0), A, D, 1,
-                    _ptr(self.Y), D, keep, None, None, _ptr(G["item_op.cnn.bias"]), None, None)
         self._fork(ev[4], m, sb)
         # ---- side stream B: additive weight gradients + the whole category branch
         self.kk(sb, "additive_bwd_weight_user", "lego_linear_bwd_weight", _ptr(self.Tu), self.Au, hist_items, D,
@@ -478,9 +471,9 @@ class NamlEngine(_Base):
         self.kk(sb, None, "lego_scatter_add_rows", _ptr(G["embedding_vocab_table.category.weight"]), D, D,
                 G["embedding_vocab_table.category.weight"].shape[0], _ptr(self.inst_cat),
                 self.NIc, self.cnt(1), _ptr(self.d_cat_emb), D)
-        if not late_fork:
-            self.kk(m, "additive_bwd_data", "lego_linear_bwd_data", _ptr(self.Tt), A, w1, D, _ptr(self.dY), D, self.Rc, self.cnt(0), A, D, 1,
-                    _ptr(self.Y), D, keep, None, None, _ptr(G["item_op.cnn.bias"]), None, None)
+        # ---- main: token rows: dY = relu'(.)*keep * (dY + dpre.W1); column sums -> conv bias grad
+        self.kk(m, "additive_bwd_data", "lego_linear_bwd_data", _ptr(self.Tt), A, w1, D, _ptr(self.dY), D, self.Rc, self.cnt(0), A, D, 1,
+                _ptr(self.Y), D, keep, None, None, _ptr(G["item_op.cnn.bias"]), None, None)
         cw = m if conv_w_main else sc
         if cw is not m:
             self._fork(ev[5], m, sc)
