@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "liblego_hip.so")
+LIB_PATH = os.environ.get("LEGO_HIP_LIB") or os.path.join(CSRC, "liblego_hip.so")   # override: A/B of two builds in one run
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "lego_hip.h")
 
 P = ctypes.c_void_p
@@ -51,7 +51,7 @@ SIGNATURES = {
     "lego_conv3_bwd_data": [P, I, P, P, P, I, I, P, I, I, P, P, I, P],
     "lego_conv3_bwd_weight": [P, I, P, I, P, P, I, P, I, I, P],
     "lego_additive_pool_fwd": [P, I, P, I, P, P, P, P, I, P, I, I, P, I, P, P],
-    "lego_additive_pool_bwd": [P, I, P, I, P, P, P, I, P, I, I, P, I, P, P, I, P, P, P],
+    "lego_additive_pool_bwd": [P, I, P, I, P, P, P, I, P, I, I, P, I, P, P, I, P, P, P, P],
     "lego_dot_ce_fwd": [P, I, P, I, I, I, I, P, P, P],
     "lego_dot_ce_bwd": [P, I, P, I, P, I, I, I, F, P, I, P, I, P],
     "lego_mhsa_core_fwd": [P, I, P, I, P, I, I, P, I, P, I, P, I, P],

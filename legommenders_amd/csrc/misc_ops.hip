@@ -429,11 +429,12 @@ __global__ __launch_bounds__(256) void additive_pool_fwd_kernel(
     if (l < cnt) wrow[l < len ? beg + l : extra] = stash * inv;
 }
 
+constexpr int kPoolReplicas = 32;
 __global__ __launch_bounds__(256) void additive_pool_bwd_kernel(
     float* __restrict__ t, int ldt, const float* __restrict__ x, int ldx, const float* __restrict__ w2,
     const int* __restrict__ seg_off, const int* __restrict__ extra_off_dyn, int n_cap, const int* __restrict__ n_dyn,
     int D, int A, const float* __restrict__ gout, int ldgo, const float* __restrict__ wrow,
-    float* __restrict__ dx, int lddx, float* gw2, float* gb1) {
+    float* __restrict__ dx, int lddx, float* gw2, float* gb1, float* scratch) {
     __shared__ float red[2][4][kMaxChunks * 256];
     __shared__ float red_s[2][4];
     const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
@@ -490,10 +491,29 @@ __global__ __launch_bounds__(256) void additive_pool_bwd_kernel(
         *reinterpret_cast<f32x4*>(&red[1][wave][c]) = ab1[j];
     }
     __syncthreads();
+    // ~1000 workgroups finishing together would serialise their adds on the 2 x A words of gw2 / gb1 (the adds execute
+    // at the memory side, one per address at a time): with a scratch they go to one of kPoolReplicas copies instead
+    // and pool_replica_reduce_kernel folds the copies afterwards
+    if (scratch != nullptr) {
+        gw2 = scratch + (size_t)(blockIdx.x % kPoolReplicas) * 2 * A;
+        gb1 = gw2 + A;
+    }
     for (int c = threadIdx.x; c < A; c += 256) {
         atomicAdd(gw2 + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
         atomicAdd(gb1 + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
     }
+}
+
+__global__ void pool_replica_reduce_kernel(float* __restrict__ scratch, int A, float* gw2, float* gb1) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 2 * A) return;
+    float s = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < kPoolReplicas; ++r) {
+        s += scratch[(size_t)r * 2 * A + c];
+        scratch[(size_t)r * 2 * A + c] = 0.f;                // handed back clean for the next call
+    }
+    atomicAdd((c < A ? gw2 : gb1) + (c < A ? c : c - A), s);
 }
 
 // ------------------------------------------------------------------ dot predictor + cross entropy(label 0)
@@ -595,14 +615,17 @@ __global__ void relu_bwd_kernel(float* __restrict__ g, int ldg, const float* __r
 // C candidates, cross-entropy(label 0) and its gradient, and the backward of the pool (dx direct part, dpre in
 // place of t, parameter-gradient partials).  The tanh GEMM before it and the dpre.W1 / dpre^T.x GEMMs after it
 // stay on the MFMA core.
-__global__ __launch_bounds__(256) void user_tower_train_kernel(
+// 16 waves per user: the row loops below are chains of dependent global loads (one history row per step and wave), so
+// 16 waves make them <= 4 steps long for S = 50 instead of 13 with 4 waves (28 -> ~13 us on the critical path of the step)
+constexpr int kUT_NW = 16;
+__global__ __launch_bounds__(kUT_NW * 64) void user_tower_train_kernel(
     float* __restrict__ t, int ldt, const float* __restrict__ items, int ldi, const float* __restrict__ w2,
     const int* __restrict__ hist_off, int B, int C, int D, int A, float gscale,
     float* __restrict__ user, float* __restrict__ scores, float* loss, float* __restrict__ d_items, int lddi,
     float* gw2, float* gb1) {
-    __shared__ float red[4][kMaxChunks * 256];
+    __shared__ float red[kMaxChunks * 256];             // partial sums of the 16 waves meet here through ds_add_f32
     __shared__ float uvec[kMaxChunks * 256], duvec[kMaxChunks * 256];
-    __shared__ float wl[kMaxSegRows], dwl[kMaxSegRows], sc[kMaxCand], red_s[4];
+    __shared__ float wl[kMaxSegRows], dwl[kMaxSegRows], sc[kMaxCand], red_s[kUT_NW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x;
     const int BC = B * C;
@@ -614,7 +637,7 @@ __global__ __launch_bounds__(256) void user_tower_train_kernel(
 #pragma unroll
     for (int j = 0; j < kMaxChunks; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float s = 0.f;
-    for (int l = wave; l < len; l += 4) {
+    for (int l = wave; l < len; l += kUT_NW) {
         const float e = expf(dot_row(th + (size_t)l * ldt, w2, A, lane));
         s += e;
 #pragma unroll
@@ -624,23 +647,31 @@ __global__ __launch_bounds__(256) void user_tower_train_kernel(
         }
         if (lane == 0) wl[l] = e;
     }
+    for (int c = threadIdx.x; c < kMaxChunks * 256; c += kUT_NW * 64) red[c] = 0.f;
+    if (lane == 0) red_s[wave] = s;
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < kMaxChunks; ++j) {
         const int c = 4 * lane + 256 * j;
-        if (c < D) *reinterpret_cast<f32x4*>(&red[wave][c]) = acc[j];
+        if (c < D) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) atomicAdd(&red[c + i], acc[j][i]);
+        }
     }
-    if (lane == 0) red_s[wave] = s;
     __syncthreads();
-    const float inv = 1.f / ((red_s[0] + red_s[1]) + (red_s[2] + red_s[3]) + kEps);
-    for (int c = threadIdx.x; c < D; c += 256) {
-        const float u = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) * inv;
+    float ssum = 0.f;
+#pragma unroll
+    for (int w_ = 0; w_ < kUT_NW; ++w_) ssum += red_s[w_];
+    const float inv = 1.f / (ssum + kEps);
+    for (int c = threadIdx.x; c < D; c += kUT_NW * 64) {
+        const float u = red[c] * inv;
         uvec[c] = u;
         user[(size_t)b * D + c] = u;
     }
-    for (int l = threadIdx.x; l < len; l += 256) wl[l] *= inv;
+    for (int l = threadIdx.x; l < len; l += kUT_NW * 64) wl[l] *= inv;
     __syncthreads();
     // ---- B: dot scores + cross entropy with label 0 (dot_predictor.py:10, legommender.py:254,263)
-    for (int c = wave; c < C; c += 4) {
+    for (int c = wave; c < C; c += kUT_NW) {
         const float v = dot_row(uvec, items + (size_t)(b * C + c) * ldi, D, lane);
         if (lane == 0) { sc[c] = v; scores[b * C + c] = v; }
     }
@@ -650,7 +681,7 @@ __global__ __launch_bounds__(256) void user_tower_train_kernel(
     for (int c = 0; c < C; ++c) se += expf(sc[c] - mx);
     if (threadIdx.x == 0 && loss != nullptr) atomicAdd(loss, (logf(se) + mx - sc[0]) / (float)B);
     // ---- C: d scores -> d user, d candidates
-    for (int d = threadIdx.x; d < D; d += 256) {
+    for (int d = threadIdx.x; d < D; d += kUT_NW * 64) {
         float du = 0.f;
         const float u = uvec[d];
         for (int c = 0; c < C; ++c) {
@@ -663,18 +694,20 @@ __global__ __launch_bounds__(256) void user_tower_train_kernel(
     __syncthreads();
     // ---- D: additive pool backward
     float sdw = 0.f;
-    for (int l = wave; l < len; l += 4) {
+    for (int l = wave; l < len; l += kUT_NW) {
         const float dw = dot_row(duvec, xh + (size_t)l * ldi, D, lane);
         sdw += wl[l] * dw;
         if (lane == 0) dwl[l] = dw;
     }
     if (lane == 0) red_s[wave] = sdw;
     __syncthreads();
-    sdw = (red_s[0] + red_s[1]) + (red_s[2] + red_s[3]);
+    sdw = 0.f;
+#pragma unroll
+    for (int w_ = 0; w_ < kUT_NW; ++w_) sdw += red_s[w_];
     f32x4 aw2[kMaxChunks], ab1[kMaxChunks];
 #pragma unroll
     for (int j = 0; j < kMaxChunks; ++j) { aw2[j] = f32x4{0.f, 0.f, 0.f, 0.f}; ab1[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    for (int l = wave; l < len; l += 4) {
+    for (int l = wave; l < len; l += kUT_NW) {
         const float w = wl[l];
         const float da = w * (dwl[l] - sdw);
 #pragma unroll
@@ -693,21 +726,142 @@ __global__ __launch_bounds__(256) void user_tower_train_kernel(
         }
     }
     __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {               // 0: d w2, 1: d b1
+        for (int c = threadIdx.x; c < kMaxChunks * 256; c += kUT_NW * 64) red[c] = 0.f;
+        __syncthreads();
 #pragma unroll
-    for (int j = 0; j < kMaxChunks; ++j) {
-        const int c = 4 * lane + 256 * j;
-        if (c < A) *reinterpret_cast<f32x4*>(&red[wave][c]) = aw2[j];
+        for (int j = 0; j < kMaxChunks; ++j) {
+            const int c = 4 * lane + 256 * j;
+            if (c < A) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) atomicAdd(&red[c + i], pass == 0 ? aw2[j][i] : ab1[j][i]);
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < A; c += kUT_NW * 64) atomicAdd((pass == 0 ? gw2 : gb1) + c, red[c]);
+        __syncthreads();
+    }
+}
+
+// Fast path of the fused user tower for D, A <= 256 and S <= 64 (the path's configurations): every history row has
+// ONE owner wave (<= 4 rows per wave) that loads its item vector and tanh row once, all loads in flight together, and
+// keeps them in registers through the forward pool, the loss and the backward pool -- the generic kernel above pays
+// a dependent global load per row in each of its five passes (~30 us of latency for 64 workgroups).
+__global__ __launch_bounds__(kUT_NW * 64) void user_tower_train_fast_kernel(
+    float* __restrict__ t, int ldt, const float* __restrict__ items, int ldi, const float* __restrict__ w2,
+    const int* __restrict__ hist_off, int B, int C, int D, int A, float gscale,
+    float* __restrict__ user, float* __restrict__ scores, float* loss, float* __restrict__ d_items, int lddi,
+    float* gw2, float* gb1) {
+    constexpr int RW = 4;
+    __shared__ float red[256], red2[256];
+    __shared__ float uvec[256], duvec[256];
+    __shared__ float sc[kMaxCand], red_s[kUT_NW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x;
+    const int BC = B * C;
+    const int beg = hist_off[b], len = hist_off[b + 1] - beg;
+    const float* xh = items + (size_t)(BC + beg) * ldi;
+    float* th = t + (size_t)beg * ldt;
+    const int c4 = 4 * lane;
+    const bool inD = c4 < D, inA = c4 < A;
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 w2v = inA ? *reinterpret_cast<const f32x4*>(w2 + c4) : zero4;
+    // candidate rows of this user (for the scores and d user), one per wave
+    f32x4 cv = zero4;
+    if (wave < C && inD) cv = *reinterpret_cast<const f32x4*>(items + (size_t)(b * C + wave) * ldi + c4);
+    f32x4 xr[RW], tr[RW];
+    bool own[RW];
+#pragma unroll
+    for (int u = 0; u < RW; ++u) {
+        const int l = wave + kUT_NW * u;
+        own[u] = l < len;
+        xr[u] = (own[u] && inD) ? *reinterpret_cast<const f32x4*>(xh + (size_t)l * ldi + c4) : zero4;
+        tr[u] = (own[u] && inA) ? *reinterpret_cast<const f32x4*>(th + (size_t)l * ldt + c4) : zero4;
+    }
+    for (int c = threadIdx.x; c < 256; c += kUT_NW * 64) { red[c] = 0.f; red2[c] = 0.f; }
+    // ---- A: additive pool forward
+    float e[RW], s = 0.f;
+    f32x4 acc = zero4;
+#pragma unroll
+    for (int u = 0; u < RW; ++u) {
+        const float a = wave_sum((tr[u][0] * w2v[0] + tr[u][1] * w2v[1]) + (tr[u][2] * w2v[2] + tr[u][3] * w2v[3]));
+        e[u] = own[u] ? expf(a) : 0.f;
+        s += e[u];
+        acc += e[u] * xr[u];
+    }
+    if (lane == 0) red_s[wave] = s;
+    __syncthreads();
+    if (inD) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(&red[c4 + i], acc[i]);
+    }
+    float ssum = 0.f;
+#pragma unroll
+    for (int w_ = 0; w_ < kUT_NW; ++w_) ssum += red_s[w_];
+    const float inv = 1.f / (ssum + kEps);
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += kUT_NW * 64) {
+        const float uu = red[c] * inv;
+        uvec[c] = uu;
+        user[(size_t)b * D + c] = uu;
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < A; c += 256) atomicAdd(gw2 + c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < kMaxChunks; ++j) {
-        const int c = 4 * lane + 256 * j;
-        if (c < A) *reinterpret_cast<f32x4*>(&red[wave][c]) = ab1[j];
+    // ---- B: dot scores + cross entropy with label 0
+    const f32x4 uv = inD ? *reinterpret_cast<const f32x4*>(uvec + c4) : zero4;
+    if (wave < C) {
+        const float v = wave_sum((uv[0] * cv[0] + uv[1] * cv[1]) + (uv[2] * cv[2] + uv[3] * cv[3]));
+        if (lane == 0) { sc[wave] = v; scores[b * C + wave] = v; }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < A; c += 256) atomicAdd(gb1 + c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+    float mx = -INFINITY, se = 0.f;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, sc[c]);
+    for (int c = 0; c < C; ++c) se += expf(sc[c] - mx);
+    if (threadIdx.x == 0 && loss != nullptr) atomicAdd(loss, (logf(se) + mx - sc[0]) / (float)B);
+    // ---- C: d scores -> d candidates (this wave's), d user (sum over the candidate waves, through LDS)
+    if (wave < C) {
+        const float g = (expf(sc[wave] - mx) / se - (wave == 0 ? 1.f : 0.f)) * gscale;
+        if (inD) {
+            *reinterpret_cast<f32x4*>(d_items + (size_t)(b * C + wave) * lddi + c4) = g * uv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) atomicAdd(&red2[c4 + i], g * cv[i]);
+        }
+    }
+    __syncthreads();
+    const f32x4 duv = inD ? *reinterpret_cast<const f32x4*>(red2 + c4) : zero4;
+    // ---- D: additive pool backward on the cached rows
+    float dw[RW], sdw = 0.f;
+#pragma unroll
+    for (int u = 0; u < RW; ++u) {
+        dw[u] = wave_sum((duv[0] * xr[u][0] + duv[1] * xr[u][1]) + (duv[2] * xr[u][2] + duv[3] * xr[u][3]));
+        sdw += e[u] * inv * dw[u];
+    }
+    if (lane == 0) red_s[wave] = sdw;
+    for (int c = threadIdx.x; c < 256; c += kUT_NW * 64) { red[c] = 0.f; uvec[c] = 0.f; }      // reused: d w2 / d b1 partials
+    __syncthreads();
+    sdw = 0.f;
+#pragma unroll
+    for (int w_ = 0; w_ < kUT_NW; ++w_) sdw += red_s[w_];
+    f32x4 aw2 = zero4, ab1 = zero4;
+#pragma unroll
+    for (int u = 0; u < RW; ++u) {
+        if (!own[u]) continue;                           // wave-uniform
+        const int l = wave + kUT_NW * u;
+        const float w = e[u] * inv;
+        const float da = w * (dw[u] - sdw);
+        if (inD) *reinterpret_cast<f32x4*>(d_items + (size_t)(BC + beg + l) * lddi + c4) = w * duv;
+        if (inA) {
+            const f32x4 dpre = da * w2v * (1.f - tr[u] * tr[u]);
+            aw2 += da * tr[u];
+            ab1 += dpre;
+            *reinterpret_cast<f32x4*>(th + (size_t)l * ldt + c4) = dpre;
+        }
+    }
+    if (inA) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { atomicAdd(&red[c4 + i], aw2[i]); atomicAdd(&uvec[c4 + i], ab1[i]); }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < A; c += kUT_NW * 64) { atomicAdd(gw2 + c, red[c]); atomicAdd(gb1 + c, uvec[c]); }
 }
 
 // ------------------------------------------------------------------ Adam
@@ -912,14 +1066,16 @@ extern "C" int lego_additive_pool_fwd(const float* t, int ldt, const float* x, i
 extern "C" int lego_additive_pool_bwd(float* t_dpre, int ldt, const float* x, int ldx, const float* w2,
                                       const int32_t* seg_off, const int32_t* extra_off_dyn, int n_cap, const int32_t* n_dyn,
                                       int D, int A, const float* gout, int ldgo, const float* wrow,
-                                      float* dx, int lddx, float* gw2, float* gb1, void* stream) {
+                                      float* dx, int lddx, float* gw2, float* gb1, float* scratch, void* stream) {
     LEGO_REQUIRE((D & 3) == 0 && (A & 3) == 0 && D <= 256 * kMaxChunks && A <= 256 * kMaxChunks,
                  "lego_additive_pool_bwd: D=%d A=%d must be multiples of 4 and <= %d", D, A, 256 * kMaxChunks);
     if (n_cap <= 0) return 0;
     int blocks = n_cap;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(additive_pool_bwd_kernel, dim3(blocks), dim3(256), 0, ST, t_dpre, ldt, x, ldx, w2, seg_off, extra_off_dyn,
-                       n_cap, n_dyn, D, A, gout, ldgo, wrow, dx, lddx, gw2, gb1);
+                       n_cap, n_dyn, D, A, gout, ldgo, wrow, dx, lddx, gw2, gb1, scratch);
+    if (scratch != nullptr)
+        hipLaunchKernelGGL(pool_replica_reduce_kernel, dim3((2 * A + 255) / 256), dim3(256), 0, ST, scratch, A, gw2, gb1);
     return check_launch("lego_additive_pool_bwd");
 }
 
@@ -946,7 +1102,12 @@ extern "C" int lego_user_tower_train(float* t_dpre, int ldt, const float* items,
     LEGO_REQUIRE((D & 3) == 0 && (A & 3) == 0 && D <= 256 * kMaxChunks && A <= 256 * kMaxChunks && C <= kMaxCand && S < kMaxSegRows,
                  "lego_user_tower_train: D=%d A=%d C=%d S=%d unsupported", D, A, C, S);
     if (B <= 0) return 0;
-    hipLaunchKernelGGL(user_tower_train_kernel, dim3(B), dim3(256), 0, ST, t_dpre, ldt, items, ldi, w2, hist_off, B, C, D, A,
+    if (D <= 256 && A <= 256 && S <= kUT_NW * 4 && C <= kUT_NW) {
+        hipLaunchKernelGGL(user_tower_train_fast_kernel, dim3(B), dim3(kUT_NW * 64), 0, ST, t_dpre, ldt, items, ldi, w2, hist_off, B, C, D, A,
+                           gscale, user, scores, loss, d_items, lddi, gw2, gb1);
+        return check_launch("lego_user_tower_train");
+    }
+    hipLaunchKernelGGL(user_tower_train_kernel, dim3(B), dim3(kUT_NW * 64), 0, ST, t_dpre, ldt, items, ldi, w2, hist_off, B, C, D, A,
                        gscale, user, scores, loss, d_items, lddi, gw2, gb1);
     return check_launch("lego_user_tower_train");
 }

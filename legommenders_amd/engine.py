@@ -518,7 +518,14 @@ class NamlEngine(_Base):
         P, D = self.P, self.D
         self.kk(st, None, "lego_additive_pool_bwd", _ptr(t), A, x_ptr, D, _ptr(P[prefix + "additive_attention.encoder.2.weight"]),
                 _ptr(seg_off), extra, n_cap, n_dyn, D, A, _ptr(gout), D, _ptr(wrow), dx_ptr, D,
-                _ptr(G[prefix + "additive_attention.encoder.2.weight"]), _ptr(G[prefix + "additive_attention.encoder.0.bias"]))
+                _ptr(G[prefix + "additive_attention.encoder.2.weight"]), _ptr(G[prefix + "additive_attention.encoder.0.bias"]),
+                _ptr(self._pool_scratch(A)))
+
+    def _pool_scratch(self, A):
+        """LEGO_POOL_SCRATCH(A) zeroed floats (32 copies of the two A-vectors the pool backward reduces into)"""
+        if getattr(self, "_pscr", None) is None or self._pscr.numel() < 64 * A:
+            self._pscr = torch.zeros(64 * A, dtype=torch.float32, device=self.dev)
+        return self._pscr
 
 
 class NrmsEngine(_Base):
@@ -602,6 +609,11 @@ class NrmsEngine(_Base):
              _ptr(P[pre + "additive_attention.encoder.2.weight"]), _ptr(seg_off), None, None, n_cap, n_dyn, D, A,
              _ptr(out), D, _ptr(ws["wrow"]), st)
 
+    def _pool_scratch(self, A):
+        if getattr(self, "_pscr", None) is None or self._pscr.numel() < 64 * A:
+            self._pscr = torch.zeros(64 * A, dtype=torch.float32, device=self.dev)
+        return self._pscr
+
     def _side(self):
         """side HIP stream for the weight-gradient products: they overlap the latency-bound attention-core kernels of the
         data-gradient chain (LEGO_SERIAL=1: everything on the current stream)"""
@@ -622,7 +634,8 @@ class NrmsEngine(_Base):
         call("lego_additive_pool_bwd", _ptr(ws["t"]), A, _ptr(ws["lin"]), D,
              _ptr(P[pre + "additive_attention.encoder.2.weight"]), _ptr(seg_off), None, n_cap, n_dyn, D, A,
              _ptr(gout), D, _ptr(ws["wrow"]), _ptr(ws["d_lin"]), D,
-             _ptr(G[pre + "additive_attention.encoder.2.weight"]), _ptr(G[pre + "additive_attention.encoder.0.bias"]), st)
+             _ptr(G[pre + "additive_attention.encoder.2.weight"]), _ptr(G[pre + "additive_attention.encoder.0.bias"]),
+             _ptr(self._pool_scratch(A)), st)
         # d_lin += dpre . W1 ; its column sums are the gradient of linear.bias
         call("lego_linear_bwd_data", _ptr(ws["t"]), A, _ptr(P[pre + "additive_attention.encoder.0.weight"]), D,
              _ptr(ws["d_lin"]), D, rows, rows_dyn, A, D, 1, None, 0, 1.0, None, None, _ptr(G[pre + "linear.bias"]), None, None, st)

@@ -165,7 +165,7 @@ def additive_attention_bwd(ctx, gout):
     gb1 = torch.zeros(A, dtype=torch.float32, device=dev)
     gW1 = torch.zeros(A, D, dtype=torch.float32, device=dev)
     call("lego_additive_pool_bwd", _ptr(ctx.t), A, _ptr(ctx.x), D, _ptr(ctx.w2), _ptr(ctx.plan.seg_off), None, n, None,
-         D, A, _ptr(gout), D, _ptr(ctx.wrow), _ptr(dx), D, _ptr(gw2), _ptr(gb1), _stream())
+         D, A, _ptr(gout), D, _ptr(ctx.wrow), _ptr(dx), D, _ptr(gw2), _ptr(gb1), None, _stream())
     linear_bwd_weight(ctx.t, ctx.x, gW1)
     linear_bwd_data(ctx.t, ctx.W1, accumulate_into=dx)
     return dx.view(n, L, D), gW1, gb1, gw2.view(1, A)
