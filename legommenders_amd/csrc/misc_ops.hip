@@ -3,6 +3,7 @@
 // Adam, device-side negative sampling.  Everything here is integer/byte or streaming fp32 work:
 // coalesced 16-B accesses, no MFMA.
 #include "../../include/lego_hip.h"
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace lego {
@@ -1070,8 +1071,9 @@ extern "C" int lego_additive_pool_bwd(float* t_dpre, int ldt, const float* x, in
     LEGO_REQUIRE((D & 3) == 0 && (A & 3) == 0 && D <= 256 * kMaxChunks && A <= 256 * kMaxChunks,
                  "lego_additive_pool_bwd: D=%d A=%d must be multiples of 4 and <= %d", D, A, 256 * kMaxChunks);
     if (n_cap <= 0) return 0;
+    static const int cap = getenv("LEGO_POOLB_BLOCKS") ? atoi(getenv("LEGO_POOLB_BLOCKS")) : 1024;
     int blocks = n_cap;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(additive_pool_bwd_kernel, dim3(blocks), dim3(256), 0, ST, t_dpre, ldt, x, ldx, w2, seg_off, extra_off_dyn,
                        n_cap, n_dyn, D, A, gout, ldgo, wrow, dx, lddx, gw2, gb1, scratch);
     if (scratch != nullptr)

@@ -1,0 +1,127 @@
+"""Training / evaluation through the plug-in route -- `Legommender.forward` operator by operator on id-only batches -- for
+item / user operators that the fused ragged engines (engine.py) do not cover, e.g. the BERT news encoder
+(SURVEY.md section 8f-2).  Same step as the reference's `Trainer.train` (trainer.py:184-204): sample -> forward ->
+backward -> (all-reduce) -> Adam + linear schedule, with the batch sampled on the device by the path's own kernels
+(`lego_sample_negatives`, `lego_gather_history`) instead of the DataLoader workers."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from ._lib import call
+from .engine import _ptr, _stream
+
+
+class PluginStep:
+    def __init__(self, model, data, B: int, K: int = 4, lr: float = 1e-3, total_steps: int = 0, warmup: int = 0,
+                 seed: int = 2023, process_group=None, world_size: int = 1):
+        from legommenders_amd.loader.env import Env
+        self.model, self.data, self.B, self.K, self.C = model, data, B, K, K + 1
+        dev = data.tables.title_tok.device
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.cand = torch.zeros(B, self.C, **i32)
+        self.hist = torch.zeros(B, data.S, **i32)
+        self.hist_len = torch.zeros(B, **i32)
+        self.ar = torch.arange(data.S, device=dev)[None]
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.opt = torch.optim.Adam(self.params, lr=lr)                     # base_lego.py:201-204 (defaults)
+        self.total_steps, self.warmup = total_steps, warmup
+
+        def factor(step):                                                    # HF get_linear_schedule_with_warmup
+            if total_steps <= 0:
+                return 1.0
+            if step < warmup:
+                return step / max(1, warmup)
+            return max(0.0, (total_steps - step) / max(1, total_steps - warmup))
+        self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, factor)
+        self.seed, self.step_idx = seed, 0
+        self.pg, self.world = process_group, world_size
+        self.Env = Env
+
+    def sample_batch(self):
+        d, B = self.data, self.B
+        start = (self.step_idx * B) % max(1, d.n_rows - B + 1)
+        ru, ri = _ptr(d.row_user, start), _ptr(d.row_item, start)
+        call("lego_sample_negatives", ru, ri, _ptr(d.neg_list), _ptr(d.neg_len), d.neg_cap, B, self.K, d.n_items,
+             self.seed, self.step_idx, _ptr(self.cand), _stream())
+        call("lego_gather_history", ru, _ptr(d.user_hist), _ptr(d.user_hist_len), B, d.S, _ptr(self.hist),
+             _ptr(self.hist_len), _stream())
+
+    def step(self):
+        cm = self.model.cm
+        self.sample_batch()
+        batch = {cm.item_col: self.cand.long(), cm.history_col: self.hist.long(),
+                 cm.mask_col: (self.ar < self.hist_len[:, None]).long()}
+        self.Env.train()
+        self.model.train()
+        self.opt.zero_grad(set_to_none=True)
+        loss = self.model(batch=batch)
+        loss.backward()
+        if self.world > 1:                                                   # one all-reduce of the flattened gradients
+            grads = [p.grad for p in self.params if p.grad is not None]
+            flat = torch._utils._flatten_dense_tensors(grads)
+            torch.distributed.all_reduce(flat, group=self.pg)
+            flat.mul_(1.0 / self.world)
+            for g, f in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+                g.copy_(f)
+        self.opt.step()
+        self.sched.step()
+        self.step_idx += 1
+        return loss.detach().reshape(1)
+
+
+class PluginEvaluator:
+    """The reference's fast-eval path on the model itself: item representation cache over all items (pages of
+    `item_page`), user cache from `item_repr[history]`, then score = <user, item> per evaluation row
+    (loader/cacher/*, model/legommender.py:153-157,202-214,282)."""
+
+    def __init__(self, model, data, item_page: int = 512, user_page: int = 512):
+        self.model, self.data, self.item_page, self.user_page = model, data, item_page, user_page
+        self.item_repr = self.user_repr = None
+
+    @torch.no_grad()
+    def build_caches(self):
+        from legommenders_amd.loader.env import Env
+        m, d = self.model, self.data
+        dev = d.tables.title_tok.device
+        cm = m.cm
+        Env.test()
+        m.eval()
+        m.item_repr = m.user_repr = None
+        outs = []
+        for s in range(0, d.n_items, self.item_page):
+            ids = torch.arange(s, min(s + self.item_page, d.n_items), device=dev)[:, None]
+            outs.append(m.get_item_content({cm.item_col: ids}, cm.item_col)[:, 0])
+        self.item_repr = torch.cat(outs, 0).contiguous()
+        m.item_repr = self.item_repr
+        S = d.S
+        ar = torch.arange(S, device=dev)[None]
+        outs = []
+        n_users = d.user_hist.shape[0]
+        for s in range(0, n_users, self.user_page):
+            e = min(s + self.user_page, n_users)
+            batch = {cm.history_col: d.user_hist[s:e].long(), cm.mask_col: (ar < d.user_hist_len[s:e, None]).long()}
+            outs.append(m.get_user_content(batch))
+        self.user_repr = torch.cat(outs, 0).contiguous()
+        m.item_repr = None                                                    # training must not see a stale cache
+        return self.item_repr, self.user_repr
+
+    def evaluate(self, users, items, labels, groups=None, metrics=("GAUC", "MRR", "NDCG@1", "NDCG@5", "NDCG@10")):
+        from legommenders_amd import metrics as M
+        import numpy as np
+        self.build_caches()
+        dev = self.item_repr.device
+        u = torch.as_tensor(users).to(dev, torch.int32).contiguous()
+        it = torch.as_tensor(items).to(dev, torch.int32).contiguous()
+        n, D = u.numel(), self.item_repr.shape[1]
+        gu = torch.empty(n, D, dtype=torch.float32, device=dev)
+        gi = torch.empty(n, D, dtype=torch.float32, device=dev)
+        out = torch.empty(n, dtype=torch.float32, device=dev)
+        st = _stream()
+        call("lego_gather_rows", _ptr(self.user_repr), D, D, _ptr(u), n, None, _ptr(gu), D, 0, st)
+        call("lego_gather_rows", _ptr(self.item_repr), D, D, _ptr(it), n, None, _ptr(gi), D, 0, st)
+        call("lego_rowdot_fwd", _ptr(gu), D, _ptr(gi), D, n, D, _ptr(out), st)
+        s = out.cpu().numpy()
+        g = np.asarray(users if groups is None else groups)
+        return M.calculate(s, np.asarray(labels), g, list(metrics)), s

@@ -104,9 +104,11 @@ def build_model(config: Obj, world: dict, device):
     from legommenders_amd.synthetic import glove_like
 
     model, embed, data = config.model, config.embed, config.data
-    glove_v, cat_v = Vocab("glove", world["V"]), Vocab("category", world["n_cat"])
+    first = (data.item.inputs() or [{"title@glove": world["T"]}])[0]          # data yaml: item.inputs[0] = {col: max_len} | col
+    tcol = next(iter(first)) if isinstance(first, dict) else str(first)
+    tvocab = tcol.split("@", 1)[1] if "@" in tcol else tcol                   # `title@glove` -> vocab `glove` (UniTok naming)
+    glove_v, cat_v = Vocab(tvocab, world["V"]), Vocab("category", world["n_cat"])
     item_v, user_v = Vocab("item_id", world["n_items"]), Vocab("user_id", world["n_users"])
-    tcol = "title@glove"
     item_ut = Table([Feature("item_id", item_v), Feature(tcol, glove_v, world["T"]), Feature("category", cat_v)],
                     {"item_id": np.arange(world["n_items"]), tcol: (world["title_tok"], world["title_len"]),
                      "category": world["cat"]}, "item_id")
@@ -123,8 +125,9 @@ def build_model(config: Obj, world: dict, device):
     for info in (embed.embeddings() or []):
         if os.path.exists(info["path"]):
             arr = np.load(info["path"])
-        elif data.base_dir == "synthetic":
-            arr = glove_like(world["V"], 300, seed=2024, device=device)
+        elif data.base_dir == "synthetic":      # GloVe-like 300-d table, or (other vocabularies, e.g. bert) one of the model's width
+            width = 300 if info.get("vocab_name", "glove") == "glove" else int(lc.item_hidden_size)
+            arr = glove_like(world["V"], width, seed=2024, device=device)
         else:
             raise ValueError(f"pre-trained embedding {info['path']} not found")
         eh.load_pretrained_embedding(info["path"], vocab_name=info.get("vocab_name"), col_name=info.get("col_name"),
@@ -135,8 +138,13 @@ def build_model(config: Obj, world: dict, device):
     lc.register_inputer_vocabs()
     legommender = Legommender(lc).to(device)
     kind = {"CNNOperator": "naml", "AttentionOperator": "nrms"}.get(type(lc.item_operator).__name__)
-    if kind is None or type(lc.predictor).__name__ != "DotPredictor":
-        raise LegoHipError("the MI355X training path covers item operators CNN / Attention with the Dot predictor")
+    if type(lc.predictor).__name__ != "DotPredictor":
+        raise LegoHipError("the MI355X training path covers the Dot predictor")
+    if kind is None or type(lc.user_operator).__name__ not in ("AdaOperator", "AttentionOperator") \
+            or (kind == "naml") != (type(lc.user_operator).__name__ == "AdaOperator"):
+        kind = "plugin"          # e.g. BertBase + Ada: trained operator by operator (plugin_step.py), not by a fused engine
+        from legommenders_amd.engine import ItemTables
+        legommender.attach_item_table(ItemTables(world["title_tok"], world["title_len"], world["cat"], device))
     return legommender, kind
 
 
@@ -173,10 +181,18 @@ class Trainer:
         params = {k: v.detach() for k, v in self.legommender.state_dict().items()}
         glove = any(k.endswith("glove.embedding.weight") for k in params)
         heads = getattr(self.legommender.item_op.config, "num_attention_heads", 8)
-        self.ts = TrainStep(self.kind, params, self.data, self.B, K=self.legommender.neg_count, lr=float(pol.lr),
-                            total_steps=self.steps_per_epoch * int(pol.epoch), warmup=int(pol.n_warmup or 0),
-                            seed=config.seed, heads=heads, glove=glove, process_group=self.pg, world_size=self.world_size)
-        self.evaluator = Evaluator(self.kind, self.ts.fp.P, self.data, heads=heads, glove=glove)
+        if self.kind == "plugin":
+            from legommenders_amd.plugin_step import PluginEvaluator, PluginStep
+            self.ts = PluginStep(self.legommender, self.data, self.B, K=self.legommender.neg_count, lr=float(pol.lr),
+                                 total_steps=self.steps_per_epoch * int(pol.epoch), warmup=int(pol.n_warmup or 0),
+                                 seed=config.seed, process_group=self.pg, world_size=self.world_size)
+            self.evaluator = PluginEvaluator(self.legommender, self.data,
+                                             item_page=int(self.legommender.config.cache_page_size or 512))
+        else:
+            self.ts = TrainStep(self.kind, params, self.data, self.B, K=self.legommender.neg_count, lr=float(pol.lr),
+                                total_steps=self.steps_per_epoch * int(pol.epoch), warmup=int(pol.n_warmup or 0),
+                                seed=config.seed, heads=heads, glove=glove, process_group=self.pg, world_size=self.world_size)
+            self.evaluator = Evaluator(self.kind, self.ts.fp.P, self.data, heads=heads, glove=glove)
         if self.exp.load.sign:
             self.load(str(self.exp.load.sign).replace("@", ""))
 
@@ -188,13 +204,21 @@ class Trainer:
 
     def save(self):
         path = os.path.join(self.ckpt_dir, self.signature + ".pt")
-        torch.save({"model": {k: v.detach().cpu() for k, v in self.ts.fp.P.items()},
-                    "optimizer": {"m": self.ts.fp.m.cpu(), "v": self.ts.fp.v.cpu(), "step": self.ts.step_idx}}, path)
+        if self.kind == "plugin":
+            torch.save({"model": {k: v.detach().cpu() for k, v in self.legommender.state_dict().items()},
+                        "optimizer": self.ts.opt.state_dict()}, path)
+        else:
+            torch.save({"model": {k: v.detach().cpu() for k, v in self.ts.fp.P.items()},
+                        "optimizer": {"m": self.ts.fp.m.cpu(), "v": self.ts.fp.v.cpu(), "step": self.ts.step_idx}}, path)
         self.log("save model to", path)
 
     def load(self, sign):
         path = os.path.join(self.ckpt_dir, sign + ".pt")
         state = torch.load(path, map_location=self.device)
+        if self.kind == "plugin":
+            self.legommender.load_state_dict(state["model"], strict=bool(self.exp.load.strict))
+            self.log("load model from", path)
+            return
         for k, v in state["model"].items():
             if k in self.ts.fp.P:
                 self.ts.fp.P[k].copy_(v)

@@ -87,3 +87,40 @@ def test_short_training_run_end_to_end(model, embed, tmp_path, monkeypatch):
     import torch
     state = torch.load(ck)
     assert set(state["model"]) == set(tr.legommender.state_dict())      # checkpoint carries the reference's keys
+
+
+def test_bert_naml_yaml_resolves():
+    c = get_configurations(dict(data="config/data/synthetic-bert.yaml", model="config/model/bert-naml.yaml",
+                                embed="config/embed/bertbase.yaml", batch_size=8, hidden_size=64))
+    m = c.model.config()
+    assert c.model.meta.item == "BertBase" and c.model.meta.user == "Ada" and c.model.meta.predictor == "Dot"
+    assert m["item_hidden_size"] == 768 and m["hidden_size"] == 64 and m["item_page_size"] == 64
+    assert m["item_config"]["tune_from"] == 0 and m["item_config"]["use_lora"] is False
+    assert c.embed.embeddings()[0]["vocab_name"] == "bert"
+
+
+@pytest.mark.gpu
+def test_bert_naml_cli_trains_through_the_plugin_route(tmp_path, monkeypatch):
+    """`trainer.py --model config/model/bert-naml.yaml` end to end: a tiny LOCAL BERT checkpoint (width 768 as the yaml
+    demands, 2 blocks -> tune_from = 0 keeps 1), the plug-in training step, cached evaluation, checkpoint, test."""
+    import torch
+    from transformers import BertConfig, BertModel
+    from legommenders_amd.trainer import Trainer
+    monkeypatch.chdir(tmp_path)
+    ck = str(tmp_path / "tiny-bert")
+    torch.manual_seed(0)
+    BertModel(BertConfig(vocab_size=5000, hidden_size=768, num_hidden_layers=2, num_attention_heads=12, intermediate_size=128,
+                         max_position_embeddings=64)).save_pretrained(ck)
+    monkeypatch.setenv("LEGO_MODEL_BERTBASE", ck)
+    cfg = get_configurations(dict(data="config/data/synthetic-bert.yaml", model="config/model/bert-naml.yaml",
+                                  embed="config/embed/bertbase.yaml", batch_size=16, hidden_size=64, lr=0.0005, cuda=0,
+                                  world="small", epoch=1, patience=2, interval=0, epoch_batch=6))
+    tr = Trainer(cfg)
+    assert tr.kind == "plugin" and type(tr.legommender.item_op).__name__ == "BertBaseOperator"
+    assert len(tr.legommender.item_op.transformer.encoder.layer) == 1
+    assert "embedding_vocab_table.bert.weight" in tr.legommender.state_dict()      # frozen table, no projection (768 == 768)
+    res = tr.run()
+    assert set(res) == {"GAUC", "MRR", "NDCG@1", "NDCG@5", "NDCG@10"} and all(np.isfinite(v) for v in res.values())
+    assert 0.3 < res["GAUC"] < 0.7
+    state = torch.load(os.path.join("checkpoints", "synthetic", cfg.model.name, tr.signature + ".pt"))
+    assert set(state["model"]) == set(tr.legommender.state_dict())
