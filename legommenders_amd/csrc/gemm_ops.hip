@@ -453,8 +453,7 @@ extern "C" int lego_conv3_wino_fwd(const float* h, int ldh, const float* u, cons
     CHECK4(ldh);
     LEGO_REQUIRE(Din % BK == 0 && Dout % 4 == 0 && Dout <= STRIP_BN, "lego_conv3_wino_fwd: Din=%d must be a multiple of %d, Dout=%d a multiple of 4 and <= %d", Din, BK, Dout, STRIP_BN);
     if (P_cap <= 0) return 0;
-    static const int dbg = getenv("LEGO_WINO_DBG") ? atoi(getenv("LEGO_WINO_DBG")) : 0;
-    WinoArgs w{h, ldh, u, Din, Dout, pair_info, P_cap, P_dyn, 0, dbg};
+    WinoArgs w{h, ldh, u, Din, Dout, pair_info, P_cap, P_dyn, 0};
     Epi e = make_epi(y, ldy);
     e.bias = bias; e.act = 1;
     set_drop(e, drop, Dout);
@@ -467,7 +466,7 @@ extern "C" int lego_conv3_wino_bwd_data(const float* gy, int ldg, const float* u
     CHECK4(ldg);
     LEGO_REQUIRE(Dout % BK == 0 && Din % 4 == 0 && Din <= STRIP_BN, "lego_conv3_wino_bwd_data: Dout=%d must be a multiple of %d, Din=%d a multiple of 4 and <= %d", Dout, BK, Din, STRIP_BN);
     if (P_cap <= 0) return 0;
-    WinoArgs w{gy, ldg, u, Dout, Din, pair_info, P_cap, P_dyn, 1, 0};
+    WinoArgs w{gy, ldg, u, Dout, Din, pair_info, P_cap, P_dyn, 1};
     Epi e = make_epi(dh, lddh);
     e.colsum = colsum;
     set_drop(e, drop_in, Din);

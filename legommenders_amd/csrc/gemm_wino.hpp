@@ -31,7 +31,6 @@ struct WinoArgs {
     int N;                                  // output channels
     const int* pair_info; int P_cap; const int* P_dyn;
     int swap;                               // backward-data: sets 0 and 3 swap weights
-    int dbg;                                // tuning only: 1 = no global loads / LDS stores in the loop, 3 = also no LDS reads
 };
 
 template <bool B_MC>
@@ -163,7 +162,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void wino_kernel(WinoArgs w, EpiArgs
                 const float* B_ = Bs0 + buf * B_FLOATS;
                 float* An = As0 + (buf ^ 1) * A_FLOATS;
                 float* Bn = Bs0 + (buf ^ 1) * B_FLOATS;
-                if (!(w.dbg & 2)) read_frags(A_, B_, 1, fa1, fb1);
+                read_frags(A_, B_, 1, fa1, fb1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -173,10 +172,8 @@ __global__ __launch_bounds__(STRIP_THREADS) void wino_kernel(WinoArgs w, EpiArgs
                         for (int b = 0; b < 2; ++b)
                             ac[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[a][j], fb0[b][j], ac[a][b], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (!(w.dbg & 1)) {
-                    commit(An, Bn);             // tile t+1 (past the end: the unused buffer)
-                    fetch(t + 2);
-                }
+                commit(An, Bn);                 // tile t+1 (past the end: the unused buffer)
+                fetch(t + 2);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
@@ -187,7 +184,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void wino_kernel(WinoArgs w, EpiArgs
                             ac[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[a][j], fb1[b][j], ac[a][b], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();
-                if (!(w.dbg & 2)) read_frags(An, Bn, 0, fa0, fb0);
+                read_frags(An, Bn, 0, fa0, fb0);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int a = 0; a < NF; ++a)
@@ -225,7 +222,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void wino_kernel(WinoArgs w, EpiArgs
             csum[b] = 0.f;
         }
         const float dinv = e.drop.p > 0.f ? 1.f / (1.f - e.drop.p) : 1.f;
-        const bool dropping = e.drop.p > 0.f && !(w.dbg & 4);
+        const bool dropping = e.drop.p > 0.f;
 #pragma unroll
         for (int a = 0; a < NF; ++a) {
             const int pb = p0 + a * 16 + 4 * g4;
