@@ -135,21 +135,16 @@ __device__ __forceinline__ void strip_pass(const ALoad& la0, const BLoad& lb0, E
         float* An = As0 + (buf ^ 1) * A_FLOATS;
         float* Bn = Bs0 + (buf ^ 1) * B_FLOATS;
         if (!(DBG & 2) || k0 == 0) read_frags(A_, B_, 1, fa1, fb1);
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) mfma_j(fa0, fb0, j);
-        __builtin_amdgcn_sched_barrier(0);
         if (!(DBG & 1)) {
             commit(An, Bn);                 // unconditional: past the end this writes the unused buffer
             fetch(k0 + 2 * BK);
         }
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 3; ++j) mfma_j(fa1, fb1, j);
-        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         if (!(DBG & 2)) read_frags(An, Bn, 0, fa0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
         mfma_j(fa1, fb1, 3);
         buf ^= 1;
     }

@@ -163,7 +163,6 @@ __global__ __launch_bounds__(STRIP_THREADS) void wino_kernel(WinoArgs w, EpiArgs
                 float* An = As0 + (buf ^ 1) * A_FLOATS;
                 float* Bn = Bs0 + (buf ^ 1) * B_FLOATS;
                 read_frags(A_, B_, 1, fa1, fb1);
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -171,10 +170,8 @@ __global__ __launch_bounds__(STRIP_THREADS) void wino_kernel(WinoArgs w, EpiArgs
 #pragma unroll
                         for (int b = 0; b < 2; ++b)
                             ac[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[a][j], fb0[b][j], ac[a][b], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
                 commit(An, Bn);                 // tile t+1 (past the end: the unused buffer)
                 fetch(t + 2);
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -182,10 +179,8 @@ __global__ __launch_bounds__(STRIP_THREADS) void wino_kernel(WinoArgs w, EpiArgs
 #pragma unroll
                         for (int b = 0; b < 2; ++b)
                             ac[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[a][j], fb1[b][j], ac[a][b], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();
                 read_frags(An, Bn, 0, fa0, fb0);
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int a = 0; a < NF; ++a)
 #pragma unroll
