@@ -137,13 +137,16 @@ int lego_additive_pool_fwd(const float* t, int ldt, const float* x, int ldx, con
 /* given gout[n,D]: dx rows = w*gout (written, not accumulated); t is overwritten in place with
  * dpre = da*w2*(1-t^2); gw2[A] += sum da*t ; gb1[A] += sum dpre.
  * scratch (nullable): LEGO_POOL_SCRATCH(A) zero-initialised floats owned by the caller, one per stream that calls this:
- * the per-workgroup partials of gw2 / gb1 are spread over 32 copies there and folded afterwards (handed back zeroed),
- * instead of ~1000 workgroups adding to the same 2*A words. */
+ * the per-workgroup partials of gw2 / gb1 are spread over 32 copies there instead of ~1000 workgroups adding to the same
+ * 2*A words; lego_additive_pool_bwd_fold then adds the copies into gw2 / gb1 and hands the scratch back zeroed -- a
+ * separate call so that it can run on another stream, off the critical chain (it must be ordered after the pool
+ * backward and before the scratch is used again). */
 #define LEGO_POOL_SCRATCH(A) (32 * 2 * (A))
 int lego_additive_pool_bwd(float* t_dpre, int ldt, const float* x, int ldx, const float* w2,
                            const int32_t* seg_off, const int32_t* extra_off_dyn, int n_cap, const int32_t* n_dyn,
                            int D, int A, const float* gout, int ldgo, const float* wrow,
                            float* dx, int lddx, float* gw2, float* gb1, float* scratch, void* stream);
+int lego_additive_pool_bwd_fold(float* scratch, int A, float* gw2, float* gb1, void* stream);
 
 /* ---- a9/a10: DotPredictor + CrossEntropy(label 0) (model/predictors/dot_predictor.py:7-10,
  * model/operators/base_operator.py:65-69, model/legommender.py:254,263,268-283). */

@@ -51,6 +51,7 @@ SIGNATURES = {
     "lego_conv3_bwd_data": [P, I, P, P, P, I, I, P, I, I, P, P, I, P],
     "lego_conv3_bwd_weight": [P, I, P, I, P, P, I, P, I, I, P],
     "lego_additive_pool_fwd": [P, I, P, I, P, P, P, P, I, P, I, I, P, I, P, P],
+    "lego_additive_pool_bwd_fold": [P, I, P, P, P],
     "lego_additive_pool_bwd": [P, I, P, I, P, P, P, I, P, I, I, P, I, P, P, I, P, P, P, P],
     "lego_dot_ce_fwd": [P, I, P, I, I, I, I, P, P, P],
     "lego_dot_ce_bwd": [P, I, P, I, P, I, I, I, F, P, I, P, I, P],

@@ -1076,9 +1076,13 @@ extern "C" int lego_additive_pool_bwd(float* t_dpre, int ldt, const float* x, in
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(additive_pool_bwd_kernel, dim3(blocks), dim3(256), 0, ST, t_dpre, ldt, x, ldx, w2, seg_off, extra_off_dyn,
                        n_cap, n_dyn, D, A, gout, ldgo, wrow, dx, lddx, gw2, gb1, scratch);
-    if (scratch != nullptr)
-        hipLaunchKernelGGL(pool_replica_reduce_kernel, dim3((2 * A + 255) / 256), dim3(256), 0, ST, scratch, A, gw2, gb1);
     return check_launch("lego_additive_pool_bwd");
+}
+
+extern "C" int lego_additive_pool_bwd_fold(float* scratch, int A, float* gw2, float* gb1, void* stream) {
+    LEGO_REQUIRE(scratch != nullptr && A > 0, "lego_additive_pool_bwd_fold: needs the scratch of lego_additive_pool_bwd");
+    hipLaunchKernelGGL(pool_replica_reduce_kernel, dim3((2 * A + 255) / 256), dim3(256), 0, ST, scratch, A, gw2, gb1);
+    return check_launch("lego_additive_pool_bwd_fold");
 }
 
 extern "C" int lego_dot_ce_fwd(const float* user, int ldu, const float* items, int ldi, int B, int C, int D,

@@ -446,6 +446,7 @@ class NamlEngine(_Base):
                     float(gloss) / B, _ptr(self.d_user), D, _ptr(self.d_items), D)
             self._pool_bwd(m, "user_op.", G, hist_items, d_hist_items, self.Tu, self.Au, self.hist_off, None, B, None,
                            self.d_user, self.wu)
+            self._pool_fold(m, "user_op.", G, self.Au)
         # main: user-side dx += dpre . W1   (the user dW1 product runs on the side stream after the ONE fork below:
         # every event recorded on the main stream costs it a few microseconds, tools/event_cost.py)
         self.kk(m, None, "lego_linear_bwd_data", _ptr(self.Tu), self.Au, _ptr(P["user_op.additive_attention.encoder.0.weight"]), D,
@@ -457,7 +458,8 @@ class NamlEngine(_Base):
         keep = 1.0 / (1.0 - self.p_conv) if (training and self.p_conv > 0) else 1.0
         w1 = _ptr(P["item_op.additive_attention.encoder.0.weight"])
         self._fork(ev[4], m, sb)
-        # ---- side stream B: additive weight gradients + the whole category branch
+        # ---- side stream B: fold of the pool backward's parameter-gradient copies, additive weight gradients, category branch
+        self._pool_fold(sb, "item_op.", G, A)
         self.kk(sb, "additive_bwd_weight_user", "lego_linear_bwd_weight", _ptr(self.Tu), self.Au, hist_items, D,
                 _ptr(G["user_op.additive_attention.encoder.0.weight"]), D, B * S, self.cnt(3), self.Au, D, None, None)
         self.kk(sb, "additive_bwd_weight_item", "lego_linear_bwd_weight", _ptr(self.Tt), A, _ptr(self.Y), D,
@@ -519,13 +521,20 @@ class NamlEngine(_Base):
         self.kk(st, None, "lego_additive_pool_bwd", _ptr(t), A, x_ptr, D, _ptr(P[prefix + "additive_attention.encoder.2.weight"]),
                 _ptr(seg_off), extra, n_cap, n_dyn, D, A, _ptr(gout), D, _ptr(wrow), dx_ptr, D,
                 _ptr(G[prefix + "additive_attention.encoder.2.weight"]), _ptr(G[prefix + "additive_attention.encoder.0.bias"]),
-                _ptr(self._pool_scratch(A)))
+                _ptr(self._pool_scratch(A, prefix)))
 
-    def _pool_scratch(self, A):
-        """LEGO_POOL_SCRATCH(A) zeroed floats (32 copies of the two A-vectors the pool backward reduces into)"""
-        if getattr(self, "_pscr", None) is None or self._pscr.numel() < 64 * A:
-            self._pscr = torch.zeros(64 * A, dtype=torch.float32, device=self.dev)
-        return self._pscr
+    def _pool_fold(self, st, prefix, G, A):
+        """add the 32 scratch copies of the pool backward's parameter gradients into G (any stream ordered after it)"""
+        self.kk(st, None, "lego_additive_pool_bwd_fold", _ptr(self._pool_scratch(A, prefix)), A,
+                _ptr(G[prefix + "additive_attention.encoder.2.weight"]), _ptr(G[prefix + "additive_attention.encoder.0.bias"]))
+
+    def _pool_scratch(self, A, key):
+        """LEGO_POOL_SCRATCH(A) zeroed floats (32 copies of the two A-vectors the pool backward reduces into), one
+        buffer per pooling site: a site's copies are folded later, possibly on another stream"""
+        d = self.__dict__.setdefault("_pscr", {})
+        if key not in d or d[key].numel() < 64 * A:
+            d[key] = torch.zeros(64 * A, dtype=torch.float32, device=self.dev)
+        return d[key]
 
 
 class NrmsEngine(_Base):
@@ -609,10 +618,11 @@ class NrmsEngine(_Base):
              _ptr(P[pre + "additive_attention.encoder.2.weight"]), _ptr(seg_off), None, None, n_cap, n_dyn, D, A,
              _ptr(out), D, _ptr(ws["wrow"]), st)
 
-    def _pool_scratch(self, A):
-        if getattr(self, "_pscr", None) is None or self._pscr.numel() < 64 * A:
-            self._pscr = torch.zeros(64 * A, dtype=torch.float32, device=self.dev)
-        return self._pscr
+    def _pool_scratch(self, A, key):
+        d = self.__dict__.setdefault("_pscr", {})
+        if key not in d or d[key].numel() < 64 * A:
+            d[key] = torch.zeros(64 * A, dtype=torch.float32, device=self.dev)
+        return d[key]
 
     def _side(self):
         """side HIP stream for the weight-gradient products: they overlap the latency-bound attention-core kernels of the
@@ -635,7 +645,7 @@ class NrmsEngine(_Base):
              _ptr(P[pre + "additive_attention.encoder.2.weight"]), _ptr(seg_off), None, n_cap, n_dyn, D, A,
              _ptr(gout), D, _ptr(ws["wrow"]), _ptr(ws["d_lin"]), D,
              _ptr(G[pre + "additive_attention.encoder.2.weight"]), _ptr(G[pre + "additive_attention.encoder.0.bias"]),
-             _ptr(self._pool_scratch(A)), st)
+             _ptr(self._pool_scratch(A, pre)), st)
         # d_lin += dpre . W1 ; its column sums are the gradient of linear.bias
         call("lego_linear_bwd_data", _ptr(ws["t"]), A, _ptr(P[pre + "additive_attention.encoder.0.weight"]), D,
              _ptr(ws["d_lin"]), D, rows, rows_dyn, A, D, 1, None, 0, 1.0, None, None, _ptr(G[pre + "linear.bias"]), None, None, st)
@@ -644,7 +654,9 @@ class NrmsEngine(_Base):
         if sw is not m:
             ev[0].record(m)
             sw.wait_event(ev[0])
-        # ---- side, group 1: W1, Linear and out-projection weight gradients (inputs: dpre, lin, d_lin, att, d_att, o)
+        # ---- side, group 1: fold of the pool backward's copies; W1, Linear and out-projection weight gradients
+        call("lego_additive_pool_bwd_fold", _ptr(self._pool_scratch(A, pre)), A,
+             _ptr(G[pre + "additive_attention.encoder.2.weight"]), _ptr(G[pre + "additive_attention.encoder.0.bias"]), sp)
         call("lego_linear_bwd_weight", _ptr(ws["t"]), A, _ptr(ws["lin"]), D,
              _ptr(G[pre + "additive_attention.encoder.0.weight"]), D, rows, rows_dyn, A, D, None, None, sp)
         call("lego_linear_bwd_weight", _ptr(ws["d_lin"]), D, _ptr(ws["att"]), D, _ptr(G[pre + "linear.weight"]), D,
