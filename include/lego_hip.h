@@ -104,12 +104,14 @@ int lego_conv3_unpack_add(float* dwt /*[3,Dout,Din], cleared on return*/, float*
  * Every planned row must be live (ragged plans).  Din, Dout multiples of 32, <= 256. */
 int lego_plan_pairs(const int32_t* seg_off, int n_cap, const int32_t* n_dyn, int32_t* pair_info, int32_t* n_pairs_out,
                     void* stream);
-int lego_conv3_wino_pack(const float* w /*[Dout,Din,3]*/, float* u /*[4,Dout,Din]*/, int Dout, int Din, void* stream);
+int lego_conv3_wino_pack(const float* w /*[Dout,Din,3]*/, float* u /*[4,Dout,Din]*/, float* ut /*nullable [4,Din,Dout]: u transposed*/,
+                         int Dout, int Din, void* stream);
 int lego_conv3_wino_unpack_add(float* du /*[4,Dout,Din], cleared*/, float* dw /*[Dout,Din,3], +=*/, int Dout, int Din, void* stream);
 int lego_conv3_wino_fwd(const float* h, int ldh, const float* u, const float* bias, const int32_t* pair_info,
                         int P_cap, const int32_t* P_dyn, float* y, int ldy, int Dout, int Din,
                         const lego_dropout* drop, void* stream);
-int lego_conv3_wino_bwd_data(const float* gy, int ldg, const float* u, const int32_t* pair_info,
+int lego_conv3_wino_bwd_data(const float* gy, int ldg, const float* u, const float* ut /*nullable: reads ut instead of u*/,
+                             const int32_t* pair_info,
                              int P_cap, const int32_t* P_dyn, float* dh, int lddh, int Dout, int Din,
                              const lego_dropout* drop_in, float* colsum, void* stream);
 int lego_conv3_wino_bwd_weight(const float* gy, int ldg, const float* h, int ldh, const int32_t* pair_info,

@@ -42,10 +42,10 @@ SIGNATURES = {
     "lego_conv3_unpack_add": [P, P, I, I, P],
     "lego_dropout_mask": [P, I, P, I, P, P],
     "lego_plan_pairs": [P, I, P, P, P, P],
-    "lego_conv3_wino_pack": [P, P, I, I, P],
+    "lego_conv3_wino_pack": [P, P, P, I, I, P],
     "lego_conv3_wino_unpack_add": [P, P, I, I, P],
     "lego_conv3_wino_fwd": [P, I, P, P, P, I, P, P, I, I, I, P, P],
-    "lego_conv3_wino_bwd_data": [P, I, P, P, I, P, P, I, I, I, P, P, P],
+    "lego_conv3_wino_bwd_data": [P, I, P, P, P, I, P, P, I, I, I, P, P, P],
     "lego_conv3_wino_bwd_weight": [P, I, P, I, P, I, P, P, I, I, P],
     "lego_conv3_fwd": [P, I, P, P, P, P, I, I, P, I, I, P, I, P],
     "lego_conv3_bwd_data": [P, I, P, P, P, I, I, P, I, I, P, P, I, P],

@@ -460,16 +460,20 @@ extern "C" int lego_conv3_wino_fwd(const float* h, int ldh, const float* u, cons
     return launch_wino<false>(w, e, (hipStream_t)stream, "lego_conv3_wino_fwd");
 }
 
-extern "C" int lego_conv3_wino_bwd_data(const float* gy, int ldg, const float* u, const int32_t* pair_info,
+extern "C" int lego_conv3_wino_bwd_data(const float* gy, int ldg, const float* u, const float* ut, const int32_t* pair_info,
                                         int P_cap, const int32_t* P_dyn, float* dh, int lddh, int Dout, int Din,
                                         const lego_dropout* drop_in, float* colsum, void* stream) {
     CHECK4(ldg);
     LEGO_REQUIRE(Dout % BK == 0 && Din % 4 == 0 && Din <= STRIP_BN, "lego_conv3_wino_bwd_data: Dout=%d must be a multiple of %d, Din=%d a multiple of 4 and <= %d", Dout, BK, Din, STRIP_BN);
     if (P_cap <= 0) return 0;
-    WinoArgs w{gy, ldg, u, Dout, Din, pair_info, P_cap, P_dyn, 1};
     Epi e = make_epi(dh, lddh);
     e.colsum = colsum;
     set_drop(e, drop_in, Din);
+    if (ut != nullptr) {         // transposed sets: the weight panel is K-contiguous like the forward's
+        WinoArgs w{gy, ldg, ut, Dout, Din, pair_info, P_cap, P_dyn, 1};
+        return launch_wino<false>(w, e, (hipStream_t)stream, "lego_conv3_wino_bwd_data");
+    }
+    WinoArgs w{gy, ldg, u, Dout, Din, pair_info, P_cap, P_dyn, 1};
     return launch_wino<true>(w, e, (hipStream_t)stream, "lego_conv3_wino_bwd_data");
 }
 

@@ -144,15 +144,21 @@ __global__ __launch_bounds__(1024) void plan_pairs_kernel(const int* __restrict_
 }
 
 // Winograd F(2,3) weight transform: u[0] = g0, u[1] = (g0+g1+g2)/2, u[2] = (g0-g1+g2)/2, u[3] = g2 with g_t = w[:, :, t]
-__global__ void conv3_wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Dout, int Din) {
+// ut (optional): the same four matrices transposed, ut[s][c][o] = u[s][o][c] -- the data gradient then reads its weight
+// panel K-contiguous (one ds_read_b128 per fragment instead of four ds_read_b32 from a [k][n] image)
+__global__ void conv3_wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, float* __restrict__ ut, int Dout, int Din) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;      // over [o][c]
     const int per = Dout * Din;
     if (e >= per) return;
     const float g0 = w[3 * e], g1 = w[3 * e + 1], g2 = w[3 * e + 2];
-    u[e] = g0;
-    u[per + e] = 0.5f * (g0 + g1 + g2);
-    u[2 * per + e] = 0.5f * (g0 - g1 + g2);
-    u[3 * per + e] = g2;
+    const float v[4] = {g0, 0.5f * (g0 + g1 + g2), 0.5f * (g0 - g1 + g2), g2};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) u[(size_t)s * per + e] = v[s];
+    if (ut != nullptr) {
+        const int o = e / Din, c = e - o * Din;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ut[(size_t)s * per + (size_t)c * Dout + o] = v[s];
+    }
 }
 // ... and its transpose for the gradient: dw[:, :, 0] += du0 + (du1+du2)/2, [1] += (du1-du2)/2, [2] += (du1+du2)/2 + du3
 __global__ void conv3_wino_unpack_add_kernel(float* __restrict__ du, float* __restrict__ dw, int Dout, int Din) {
@@ -954,9 +960,9 @@ extern "C" int lego_plan_pairs(const int32_t* seg_off, int n_cap, const int32_t*
     return check_launch("lego_plan_pairs");
 }
 
-extern "C" int lego_conv3_wino_pack(const float* w, float* u, int Dout, int Din, void* stream) {
+extern "C" int lego_conv3_wino_pack(const float* w, float* u, float* ut, int Dout, int Din, void* stream) {
     const int n = Dout * Din;
-    hipLaunchKernelGGL(conv3_wino_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, ST, w, u, Dout, Din);
+    hipLaunchKernelGGL(conv3_wino_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, ST, w, u, ut, Dout, Din);
     return check_launch("lego_conv3_wino_pack");
 }
 extern "C" int lego_conv3_wino_unpack_add(float* du, float* dw, int Dout, int Din, void* stream) {

@@ -215,6 +215,7 @@ class NamlEngine(_Base):
         self.mask_conv = torch.zeros(((self.Rc + 3) // 4) * D + 1, dtype=torch.uint8, device=self.dev)
         self._slot_mask_step, self._mask_step = {}, -1
         self.wino_u = self._f(4, D, D)
+        self.wino_ut = self._f(4, D, D)                   # the same sets transposed (data gradient)
         self.wino_du = self._f(4, D, D)
         # backward workspace
         self.d_user = self._f(B, D)
@@ -370,7 +371,7 @@ class NamlEngine(_Base):
         # the conv must not wait for the category GEMM), then the loss accumulator, then
         # k2/k4 category embedding + Linear on the length-1 column (cnn_operator.py:58-60) -> Y rows R..R+NI
         if self.wino:
-            self.kk(sb, None, "lego_conv3_wino_pack", _ptr(P["item_op.cnn.weight"]), _ptr(self.wino_u), D, D)
+            self.kk(sb, None, "lego_conv3_wino_pack", _ptr(P["item_op.cnn.weight"]), _ptr(self.wino_u), _ptr(self.wino_ut), D, D)
         else:
             self.kk(sb, None, "lego_conv3_pack", _ptr(P["item_op.cnn.weight"]), _ptr(self.wt), D, D)
         if sb is not m:
@@ -494,7 +495,7 @@ class NamlEngine(_Base):
             conv_w()
         # ---- main: conv data gradient -> projection weight gradient
         if self.wino:
-            self.kk(m, "conv3_bwd_data", "lego_conv3_wino_bwd_data", _ptr(self.dY), D, _ptr(self.wino_u), _ptr(self.pair_info),
+            self.kk(m, "conv3_bwd_data", "lego_conv3_wino_bwd_data", _ptr(self.dY), D, _ptr(self.wino_u), _ptr(self.wino_ut), _ptr(self.pair_info),
                     self.Pc, self.cnt(5), _ptr(self.dH), D, D, D, self.drop(self.p_proj, SITE_PROJ, training),
                     _ptr(G["embedding_vocab_table.glove.linear.bias"]))
         else:

@@ -485,14 +485,21 @@ def test_winograd_conv_matches_direct_and_torch(D, n_items):
     hd, wd, bd, gyd = h.to(dev), w.to(dev), b.to(dev), gy.to(dev)
     wt = torch.zeros(3, D, D, device=dev); u = torch.zeros(4, D, D, device=dev)
     call("lego_conv3_pack", P(wd), P(wt), D, D, None)
-    call("lego_conv3_wino_pack", P(wd), P(u), D, D, None)
+    ut = torch.zeros(4, D, D, device=dev)
+    call("lego_conv3_wino_pack", P(wd), P(u), P(ut), D, D, None)
     y0 = torch.zeros(R, D, device=dev); y1 = torch.zeros(R, D, device=dev)
     call("lego_conv3_fwd", P(hd), D, P(wt), P(bd), P(rowinfo), P(y0), D, R, P(cnt, 0), D, D, None, 0, None)
     call("lego_conv3_wino_fwd", P(hd), D, P(u), P(bd), P(pair), Pcap, P(cnt, 5), P(y1), D, D, D, None, None)
     d0 = torch.zeros(R, D, device=dev); d1 = torch.zeros(R, D, device=dev)
     c0 = torch.zeros(D, device=dev); c1 = torch.zeros(D, device=dev)
     call("lego_conv3_bwd_data", P(gyd), D, P(wt), P(rowinfo), P(d0), D, R, P(cnt, 0), D, D, None, P(c0), 0, None)
-    call("lego_conv3_wino_bwd_data", P(gyd), D, P(u), P(pair), Pcap, P(cnt, 5), P(d1), D, D, D, None, P(c1), None)
+    call("lego_conv3_wino_bwd_data", P(gyd), D, P(u), None, P(pair), Pcap, P(cnt, 5), P(d1), D, D, D, None, P(c1), None)
+    d2 = torch.zeros(R, D, device=dev); c2 = torch.zeros(D, device=dev)       # same product from the transposed weight sets
+    call("lego_conv3_wino_bwd_data", P(gyd), D, P(u), P(ut), P(pair), Pcap, P(cnt, 5), P(d2), D, D, D, None, P(c2), None)
+    torch.cuda.synchronize()
+    assert torch.equal(ut, u.transpose(1, 2).contiguous())
+    _close(d2.cpu(), d0.cpu(), rtol=2e-5, what="wino bwd_data (transposed sets) vs direct")
+    _close(c2.cpu(), c0.cpu(), rtol=2e-5, what="wino bwd_data (transposed sets) column sums")
     dwt = torch.zeros(3, D, D, device=dev); du = torch.zeros(4, D, D, device=dev)
     gw0 = torch.zeros(D, D, 3, device=dev); gw1 = torch.zeros(D, D, 3, device=dev)
     call("lego_conv3_bwd_weight", P(gyd), D, P(hd), D, P(rowinfo), P(dwt), R, P(cnt, 0), D, D, None)

@@ -22,7 +22,7 @@ call("lego_plan_pairs", P(seg), NI, P(cnt, 1), P(pair), P(cnt, 5), None)
 Pn = int(cnt[5]); print("rows", R, "pairs", Pn, "expected", int(((lens + 1) // 2).sum()))
 h = torch.randn(R, D, device=dev); w = torch.randn(D, D, 3, device=dev) * 0.05; b = torch.randn(D, device=dev)
 wt = torch.zeros(3, D, D, device=dev); u = torch.zeros(4, D, D, device=dev)
-call("lego_conv3_pack", P(w), P(wt), D, D, None); call("lego_conv3_wino_pack", P(w), P(u), D, D, None)
+call("lego_conv3_pack", P(w), P(wt), D, D, None); ut = torch.zeros(4, D, D, device=dev); call("lego_conv3_wino_pack", P(w), P(u), P(ut), D, D, None)
 def bench(fn, n=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()
@@ -41,7 +41,7 @@ for p in (0.0, 0.1):
     gy = torch.randn(R, D, device=dev)
     d0 = torch.zeros(R, D, device=dev); d1 = torch.zeros(R, D, device=dev); c0 = torch.zeros(D, device=dev); c1 = torch.zeros(D, device=dev)
     g0 = lambda: call("lego_conv3_bwd_data", P(gy), D, P(wt), P(rowinfo), P(d0), D, R, P(cnt, 0), D, D, dr, P(c0), 0, None)
-    g1 = lambda: call("lego_conv3_wino_bwd_data", P(gy), D, P(u), P(pair), pair.numel(), P(cnt, 5), P(d1), D, D, D, dr, P(c1), None)
+    g1 = lambda: call("lego_conv3_wino_bwd_data", P(gy), D, P(u), P(ut) if os.environ.get("WINO_UT") else None, P(pair), pair.numel(), P(cnt, 5), P(d1), D, D, D, dr, P(c1), None)
     t0, t1 = bench(g0), bench(g1)
     print(f"bwd_data p={p}: direct {t0:.1f} us  wino {t1:.1f} us  maxdiff {(d0 - d1).abs().max().item():.2e} (scale {d0.abs().max().item():.2f}) colsum rel {((c0 - c1).abs().max() / c0.abs().max()).item():.2e}")
 dwt = torch.zeros(3, D, D, device=dev); du = torch.zeros(4, D, D, device=dev)
