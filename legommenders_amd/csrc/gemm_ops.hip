@@ -253,7 +253,8 @@ static int launch_strip(const GemmDims& d, const AL& a, const BL& b, const Epi& 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL(k, dim3(num_cus()), dim3(STRIP_THREADS), lds, st, d, a, b, e);
+    const int n_panels = (d.N + STRIP_BN - 1) / STRIP_BN;
+    hipLaunchKernelGGL(k, dim3(num_cus() / n_panels * n_panels), dim3(STRIP_THREADS), lds, st, d, a, b, e);
     return check_launch(what);
 }
 
@@ -277,7 +278,7 @@ static int launch_oneshot(const GemmDims& d, const AL& a, const BL& b, const Epi
 template <bool B_MC, class EK, class AL, class BL>
 static int launch_rows(const GemmDims& d, const AL& a, const BL& b, const Epi& e, hipStream_t st, const char* what) {
     const int tm = (d.M + 127) / 128;
-    if (d.N <= STRIP_BN && d.M >= 32 * num_cus()) return launch_strip<B_MC, EK>(d, a, b, e, st, what);
+    if (d.M >= 32 * num_cus() && d.N <= 4 * STRIP_BN) return launch_strip<B_MC, EK>(d, a, b, e, st, what);
     static const bool oneshot_on = !(getenv("LEGO_ONESHOT") && atoi(getenv("LEGO_ONESHOT")) == 0);
     if constexpr (std::is_same<AL, KcRows>::value)
         if (oneshot_on && d.K <= ONE_KMAX && d.K % 4 == 0 &&

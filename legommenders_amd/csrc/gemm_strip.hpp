@@ -1,5 +1,5 @@
-// Row-strip GEMM for the big ragged products of the item tower (rows x N, N <= 256, N % 16 == 0 handled
-// by guards) on v_mfma_f32_16x16x4_f32.
+// Row-strip GEMM for the big ragged products of the item tower (rows x N; N > 256 runs as ceil(N / 256) column
+// panels, partial fragments are guarded) on v_mfma_f32_16x16x4_f32.
 //
 // Why a second tiling: the token-row count of a batch (~26 k rows at the headline size) cut into
 // 128 x 128 tiles gives ~410 blocks for 256 CUs -- 1.6 rounds, so a fifth of the machine idles in the
@@ -40,7 +40,7 @@ __host__ __device__ inline StripPlan strip_plan(int M, int G) {
 
 template <int NF, bool B_MC, int DBG, class ALoad, class BLoad, class Epi>
 __device__ __forceinline__ void strip_pass(const ALoad& la0, const BLoad& lb0, Epi& epi, float* As0, float* Bs0,
-                                           const typename BLoad::Row (&rb)[4], int m0, int m_end, int N, int K) {
+                                           const typename BLoad::Row (&rb)[4], int m0, int m_end, int n0, int K) {
     constexpr int NT = STRIP_THREADS, BN = STRIP_BN;
     constexpr int A_FLOATS = STRIP_BM * STRIP_KC_LD;
     constexpr int B_FLOATS = B_MC ? BK * STRIP_MC_LD : BN * STRIP_KC_LD;
@@ -65,7 +65,7 @@ __device__ __forceinline__ void strip_pass(const ALoad& la0, const BLoad& lb0, E
         for (int j = 0; j < AN; ++j) { sa[j] = la.load(ra[j], k0 + (tid & 7) * 4); pa[j] = la.keep(ra[j], k0 + (tid & 7) * 4); }
         if constexpr (B_MC) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sb[j] = lb.load(k0 + (tid >> 6) + 8 * j, (tid & 63) * 4, pb[j]);
+            for (int j = 0; j < 4; ++j) sb[j] = lb.load(k0 + (tid >> 6) + 8 * j, n0 + (tid & 63) * 4, pb[j]);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { sb[j] = lb.load(rb[j], k0 + (tid & 7) * 4); pb[j] = lb.keep(rb[j], k0 + (tid & 7) * 4); }
@@ -150,7 +150,7 @@ __device__ __forceinline__ void strip_pass(const ALoad& la0, const BLoad& lb0, E
     }
     __syncthreads();        // the next pass refills both buffers
     // lane holds column l16 x rows 4*g4 + {0..3} of each 16 x 16 fragment
-    epi.template run16<NF>(acc, m0, m_end, wave * 32, l16, g4);
+    epi.template run16<NF>(acc, m0, m_end, n0 + wave * 32, l16, g4);
 }
 
 template <bool B_MC, class ALoad, class BLoad, class Epi, int DBG = 0>
@@ -161,8 +161,12 @@ __global__ __launch_bounds__(STRIP_THREADS) void strip_kernel(GemmDims dims, ALo
     int M = dims.M;
     if (dims.m_dyn != nullptr) M = min(M, *dims.m_dyn);
     const int N = dims.N, K = dims.K;
-    const StripPlan sp = strip_plan(M, gridDim.x);
-    const int strip0 = blockIdx.x * sp.s;
+    // N > 256: the grid is split into ceil(N / 256) column panels, each with its own set of row strips
+    const int n_panels = (N + STRIP_BN - 1) / STRIP_BN;
+    const int panel = blockIdx.x % n_panels;
+    const int n0 = panel * STRIP_BN;
+    const StripPlan sp = strip_plan(M, max((int)gridDim.x / n_panels, 1));
+    const int strip0 = (blockIdx.x / n_panels) * sp.s;
     if (strip0 >= M) return;
     const int strip_end = min(M, strip0 + sp.s);
     epi.setup(M, N, 0);
@@ -174,17 +178,17 @@ __global__ __launch_bounds__(STRIP_THREADS) void strip_kernel(GemmDims dims, ALo
     typename BLoad::Row rb[4];
     if constexpr (!B_MC) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rb[j] = lb.row((threadIdx.x >> 3) + 64 * j);
+        for (int j = 0; j < 4; ++j) rb[j] = lb.row(n0 + (threadIdx.x >> 3) + 64 * j);
     }
     for (int m0 = strip0; m0 < strip_end; m0 += sp.sub) {
         const int m_end = min(strip_end, m0 + sp.sub);
         const int nf = (m_end - m0 + 15) >> 4;              // block-uniform
         switch (nf) {
-            case 1: case 2: strip_pass<2, B_MC, DBG>(la, lb, epi, As0, Bs0, rb, m0, m_end, N, K); break;
-            case 3: case 4: strip_pass<4, B_MC, DBG>(la, lb, epi, As0, Bs0, rb, m0, m_end, N, K); break;
-            case 5: case 6: strip_pass<6, B_MC, DBG>(la, lb, epi, As0, Bs0, rb, m0, m_end, N, K); break;
-            case 7: strip_pass<7, B_MC, DBG>(la, lb, epi, As0, Bs0, rb, m0, m_end, N, K); break;
-            default: strip_pass<8, B_MC, DBG>(la, lb, epi, As0, Bs0, rb, m0, m_end, N, K); break;
+            case 1: case 2: strip_pass<2, B_MC, DBG>(la, lb, epi, As0, Bs0, rb, m0, m_end, n0, K); break;
+            case 3: case 4: strip_pass<4, B_MC, DBG>(la, lb, epi, As0, Bs0, rb, m0, m_end, n0, K); break;
+            case 5: case 6: strip_pass<6, B_MC, DBG>(la, lb, epi, As0, Bs0, rb, m0, m_end, n0, K); break;
+            case 7: strip_pass<7, B_MC, DBG>(la, lb, epi, As0, Bs0, rb, m0, m_end, n0, K); break;
+            default: strip_pass<8, B_MC, DBG>(la, lb, epi, As0, Bs0, rb, m0, m_end, n0, K); break;
         }
     }
 }
