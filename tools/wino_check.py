@@ -41,7 +41,7 @@ for p in (0.0, 0.1):
     gy = torch.randn(R, D, device=dev)
     d0 = torch.zeros(R, D, device=dev); d1 = torch.zeros(R, D, device=dev); c0 = torch.zeros(D, device=dev); c1 = torch.zeros(D, device=dev)
     g0 = lambda: call("lego_conv3_bwd_data", P(gy), D, P(wt), P(rowinfo), P(d0), D, R, P(cnt, 0), D, D, dr, P(c0), 0, None)
-    g1 = lambda: call("lego_conv3_wino_bwd_data", P(gy), D, P(u), P(ut) if os.environ.get("WINO_UT") else None, P(pair), pair.numel(), P(cnt, 5), P(d1), D, D, D, dr, P(c1), None)
+    g1 = lambda: call("lego_conv3_wino_bwd_data", P(gy), D, P(u), P(ut) if os.environ.get("WINO_UT") else None, P(pair), pair.numel(), P(cnt, 5), P(d1), D, D, D, dr, None if os.environ.get("NO_COLSUM") else P(c1), None)
     t0, t1 = bench(g0), bench(g1)
     print(f"bwd_data p={p}: direct {t0:.1f} us  wino {t1:.1f} us  maxdiff {(d0 - d1).abs().max().item():.2e} (scale {d0.abs().max().item():.2f}) colsum rel {((c0 - c1).abs().max() / c0.abs().max()).item():.2e}")
 dwt = torch.zeros(3, D, D, device=dev); du = torch.zeros(4, D, D, device=dev)
