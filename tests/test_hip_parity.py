@@ -518,3 +518,33 @@ def test_winograd_conv_matches_direct_and_torch(D, n_items):
         s, e = int(seg[i]), int(seg[i + 1])
         ref = torch.relu(torch.nn.functional.conv1d(h[s:e].T[None], w, b, padding="same")[0].T)
         _close(y1[s:e].cpu(), ref, rtol=2e-5, what=f"wino fwd vs torch, item {i} len {e - s}")
+
+
+def test_naml_engine_hidden_512_matches_oracle():
+    """Hidden size 512: outside the Winograd kernels' range (N <= 256), so the conv runs as the direct three-tap
+    implicit GEMM and every row product as a row-strip kernel with two column panels; logits and all gradients
+    against the oracle on a seeded synthetic batch."""
+    from oracle import lego_oracle as O
+    from legommenders_amd.engine import ItemTables, NamlEngine
+    from legommenders_amd.synthetic import glove_like, init_naml_params, make_world
+    dev = _dev()
+    D, B, C, S = 512, 64, 5, 50
+    w = make_world(seed=5, n_items=3000, n_users=2000, n_rows=4000, V=5000)
+    P = init_naml_params(D=D, V=5000, n_cat=w["n_cat"], glove=glove_like(5000, 300, seed=6, device=dev))
+    rs = np.random.RandomState(1)
+    cand = rs.randint(0, 3000, size=(B, C))
+    users = rs.randint(0, 2000, size=B)
+    hist, hl = w["user_hist"][users], w["user_hist_len"][users]
+    eng = NamlEngine({k: v.to(dev).contiguous() for k, v in P.items()},
+                     ItemTables(w["title_tok"], w["title_len"], w["cat"], dev), B, C, S, p_proj=0.0, p_conv=0.0)
+    assert not eng.wino
+    ids = [torch.tensor(a).int().to(dev).contiguous() for a in (cand, hist, hl)]
+    scores, loss = eng.forward(*ids, training=False)
+    G = eng.grads_like()
+    eng.backward(G)
+    torch.cuda.synchronize()
+    tables = dict(title_tok=w["title_tok"], title_len=w["title_len"], cat=w["cat"])
+    lg, ls, g = O.loss_and_grads("naml", {k: v.cpu().numpy() for k, v in P.items()}, tables, cand,
+                                 hist * (np.arange(S)[None] < hl[:, None]), hl)
+    assert float(np.abs(scores.cpu().numpy() - lg).max()) < 1e-4 and abs(float(loss) - ls) < 2e-5
+    _grads_close(G, g, "naml_d512")
