@@ -42,7 +42,11 @@ typedef struct {
                           * lego_dropout_mask over the SAME column count: byte [(row / 4) * cols + col], bit i = row % 4 */
 } lego_dropout;
 
-/* keep bits of one dropout site for rows [0, rows) x cols columns (see lego_dropout.mask); drop->mask is ignored */
+/* The reference's nn.Dropout sites on the path -- Transformation.dropout (loader/embedding_hub.py:73-96), CNNOperator.dropout
+ * (model/operators/cnn_operator.py:44,57), MultiheadAttention's attention dropout (model/operators/attention_operator.py:36-41)
+ * -- are epilogues of the producing kernels here (argument `drop`), regenerated from (seed, site) in backward instead of
+ * storing a mask.  lego_dropout_mask: keep bits of one site for rows [0, rows) x cols columns made ahead of time (see
+ * lego_dropout.mask); drop->mask is ignored. */
 int lego_dropout_mask(const lego_dropout* drop, int rows_cap, const int32_t* rows_dyn, int cols, uint8_t* mask, void* stream);
 
 /* ---- a11 / a2: ragged batch plan.  Replaces Resampler.rebuild_clicks padding + the dense
@@ -101,7 +105,9 @@ int lego_conv3_unpack_add(float* dwt /*[3,Dout,Din], cleared on return*/, float*
  * fp32 rounding).  lego_plan_pairs derives the pairs from seg_off: pair_info[p] = first_row << 3 | has_second |
  * has_left << 1 | has_right2 << 2, *n_pairs_out = P.  u / du are the transformed weights [4][Dout][Din]
  * (lego_conv3_wino_pack; lego_conv3_wino_unpack_add adds the transposed transform of du into dw and clears du).
- * Every planned row must be live (ragged plans).  Din, Dout multiples of 32, <= 256. */
+ * Every planned row must be live (ragged plans).  Din, Dout multiples of 32, <= 256.  Same reference lines as
+ * lego_conv3_*: nn.Conv1d(k=3, padding='same') -> ReLU -> Dropout of model/operators/cnn_operator.py:33-38,54-57 and its
+ * autograd backward. */
 int lego_plan_pairs(const int32_t* seg_off, int n_cap, const int32_t* n_dyn, int32_t* pair_info, int32_t* n_pairs_out,
                     void* stream);
 int lego_conv3_wino_pack(const float* w /*[Dout,Din,3]*/, float* u /*[4,Dout,Din]*/, float* ut /*nullable [4,Din,Dout]: u transposed*/,
