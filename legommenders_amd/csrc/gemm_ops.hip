@@ -89,7 +89,7 @@ struct EpiT : EpiArgs {
                     for (int i = 0; i < 4; ++i) {
                         float x = acc[a][b][4 * g + i] + bcol[b];
                         if (act == 1) x = fmaxf(x, 0.f);
-                        else if (act == 2) x = tanhf(x);
+                        else if (act == 2) x = fast_tanh(x);
                         if (ROWINFO && !live[i]) x = 0.f;
                         x *= ds[i];
                         if (ACCUM) x += old[b][i];
@@ -156,7 +156,7 @@ struct EpiT : EpiArgs {
                 for (int i = 0; i < 4; ++i) {
                     float x = acc[a][b][i] + bcol[b];
                     if (act == 1) x = fmaxf(x, 0.f);
-                    else if (act == 2) x = tanhf(x);
+                    else if (act == 2) x = fast_tanh(x);
                     if (ROWINFO && !live[i]) x = 0.f;
                     x *= ds[i];
                     if (ACCUM) x += old[b][i];
