@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64) void mhsa_fwd_kernel(const float* __restrict__ 
     }
     __syncthreads();
     float se = 0.f;
-    for (int j = 0; j < L; ++j) se += expf(Pl[j][ic] - mx);
+    for (int j = 0; j < L; ++j) se += __expf(Pl[j][ic] - mx);
     const float inv = 1.f / se;
     float o[W];
 #pragma unroll
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64) void mhsa_fwd_kernel(const float* __restrict__ 
             const int j = j0 + u;
             if (j < L) {
                 const float* vr = &Vs[j][half * W];
-                const float p = expf(Pl[j][ic] - mx) * inv;
+                const float p = __expf(Pl[j][ic] - mx) * inv;
                 const float pd = p * ds[u];
 #pragma unroll
                 for (int c = 0; c < W; ++c) o[c] += pd * vr[c];
