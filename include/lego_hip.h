@@ -222,6 +222,22 @@ int lego_nrms_decode_rows(const int32_t* row_tok, int R_cap, const int32_t* R_dy
 int lego_mask_dropout_rows(float* x, int ld, int R_cap, const int32_t* R_dyn, int width, const int32_t* rowinfo,
                            const lego_dropout* drop, void* stream);
 
+/* ---- a14: grouped ranking metrics of the evaluation path -- MetricPool.calculate's per-group loop
+ * (utils/metrics.py:313-369; pandas groupby + Pool(5) of Python metric calls) as one launch.
+ * Rows are sorted by group (stable): group g owns rows [group_off[g], group_off[g+1]).  `ks` is a HOST array of n_k
+ * cut-offs (<= LEGO_METRIC_MAX_K).  out is [4 + 3*n_k][n_groups] fp32, per group:
+ *   row 0 GAUC term  roc_auc_score          (utils/metrics.py:95-96,98-107; NaN when one class only -- sklearn raises)
+ *   row 1 MRR        mean over positives of 1/rank   (:147-160; NaN without positives -- the reference divides by 0)
+ *   row 2 MRR0       1/rank of the first positive, 0 without one  (:125-140)
+ *   row 3 LRAP       label_ranking_average_precision_score        (:108-117)
+ *   row 4+3q NDCG@k  sklearn ndcg_score(k), ties averaged          (:216-229)
+ *   row 5+3q HitRatio@k (:183-197)      row 6+3q Recall@k (:199-214; NaN without positives)
+ * rank = position after a stable descending sort of the group's scores (Python `sorted(..., reverse=True)`).
+ * The caller takes the fp32 mean over groups (utils/metrics.py:367). */
+#define LEGO_METRIC_MAX_K 8
+int lego_grouped_metrics(const float* scores, const int32_t* labels, const int32_t* group_off, int n_groups,
+                         const int32_t* ks /*host*/, int n_k, float* out, void* stream);
+
 /* small utilities used by the host side */
 int lego_gather_i32(const int32_t* table, const int32_t* idx, int n_cap, const int32_t* n_dyn, int32_t* out, void* stream);
 

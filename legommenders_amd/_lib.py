@@ -65,6 +65,7 @@ SIGNATURES = {
     "lego_sample_negatives": [P, P, P, P, I, I, I, I, U64, U32, P, P],
     "lego_gather_history": [P, P, P, I, I, P, P, P],
     "lego_gather_i32": [P, P, I, P, P, P],
+    "lego_grouped_metrics": [P, P, P, I, P, I, P, P],
 }
 
 

@@ -62,6 +62,6 @@ class Evaluator:
 
     def evaluate(self, users, items, labels, groups=None, metrics=("GAUC", "MRR", "NDCG@1", "NDCG@5", "NDCG@10")):
         self.build_caches()
-        s = self.scores(torch.as_tensor(users), torch.as_tensor(items)).cpu().numpy()
+        s = self.scores(torch.as_tensor(users), torch.as_tensor(items))
         g = np.asarray(users if groups is None else groups)
-        return M.calculate(s, np.asarray(labels), g, list(metrics)), s
+        return M.calculate_device(s, np.asarray(labels), g, list(metrics)), s.cpu().numpy()

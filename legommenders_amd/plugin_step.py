@@ -107,10 +107,9 @@ class PluginEvaluator:
         m.item_repr = None                                                    # training must not see a stale cache
         return self.item_repr, self.user_repr
 
-    def evaluate(self, users, items, labels, groups=None, metrics=("GAUC", "MRR", "NDCG@1", "NDCG@5", "NDCG@10")):
-        from legommenders_amd import metrics as M
-        import numpy as np
-        self.build_caches()
+    @torch.no_grad()
+    def scores(self, users, items) -> torch.Tensor:
+        """score[r] = <user_repr[users[r]], item_repr[items[r]]> (model/legommender.py:153-157,282 on cached vectors)"""
         dev = self.item_repr.device
         u = torch.as_tensor(users).to(dev, torch.int32).contiguous()
         it = torch.as_tensor(items).to(dev, torch.int32).contiguous()
@@ -122,6 +121,12 @@ class PluginEvaluator:
         call("lego_gather_rows", _ptr(self.user_repr), D, D, _ptr(u), n, None, _ptr(gu), D, 0, st)
         call("lego_gather_rows", _ptr(self.item_repr), D, D, _ptr(it), n, None, _ptr(gi), D, 0, st)
         call("lego_rowdot_fwd", _ptr(gu), D, _ptr(gi), D, n, D, _ptr(out), st)
-        s = out.cpu().numpy()
+        return out
+
+    def evaluate(self, users, items, labels, groups=None, metrics=("GAUC", "MRR", "NDCG@1", "NDCG@5", "NDCG@10")):
+        from legommenders_amd import metrics as M
+        import numpy as np
+        self.build_caches()
+        s = self.scores(users, items)
         g = np.asarray(users if groups is None else groups)
-        return M.calculate(s, np.asarray(labels), g, list(metrics)), s
+        return M.calculate_device(s, np.asarray(labels), g, list(metrics)), s.cpu().numpy()

@@ -452,14 +452,80 @@ def _mrr(labels, scores):
     return float(rr.sum() / y.sum())
 
 
+def _ranked_labels(labels, scores):
+    """labels in the order of Python's `sorted(range(n), key=scores.__getitem__, reverse=True)` (ties keep row order),
+    the ranking MRR / MRR0 / HitRatio / Recall share (utils/metrics.py:131,153,195,212)"""
+    order = sorted(range(len(scores)), key=lambda i: scores[i], reverse=True)
+    return [int(labels[i]) for i in order]
+
+
+def _mrr0(labels, scores):
+    """utils/metrics.py:125-140"""
+    for rank, y in enumerate(_ranked_labels(labels, scores), start=1):
+        if y == 1:
+            return 1.0 / rank
+    return 0.0
+
+
+def _hit_ratio(labels, scores, k):
+    """utils/metrics.py:183-197"""
+    return float(1 in _ranked_labels(labels, scores)[:k])
+
+
+def _recall(labels, scores, k):
+    """utils/metrics.py:199-214"""
+    y = _ranked_labels(labels, scores)
+    return sum(y[:k]) * 1.0 / sum(y)
+
+
+def _lrap(labels, scores):
+    """sklearn.label_ranking_average_precision_score of ONE sample (utils/metrics.py:108-117): mean over the relevant
+    labels of (#relevant ranked at or above it) / (#labels ranked at or above it), ties counted with `>=`;
+    1.0 when no label or every label is relevant."""
+    rel = [i for i in range(len(labels)) if labels[i] == 1]
+    if len(rel) == 0 or len(rel) == len(labels):
+        return 1.0
+    acc = 0.0
+    for i in rel:
+        at_or_above = [j for j in range(len(scores)) if scores[j] >= scores[i]]
+        acc += sum(1 for j in at_or_above if labels[j] == 1) / len(at_or_above)
+    return acc / len(rel)
+
+
+def pointwise_metric(name, scores, labels):
+    """AUC / LogLoss / F1@t over all rows (utils/metrics.py:66-96,162-181; sklearn roc_auc_score, log_loss, f1_score)"""
+    scores = np.asarray(scores, dtype=np.float64)
+    labels = np.asarray(labels)
+    base, _, arg = name.partition("@")
+    if base == "AUC":
+        return float(_auc(labels, scores))
+    if base == "LogLoss":
+        eps = np.finfo(np.float64).eps
+        p = np.clip(scores, eps, 1 - eps)
+        return float(np.mean([-np.log(pi) if y == 1 else -np.log1p(-pi) for pi, y in zip(p, labels)]))
+    if base == "F1":
+        t = float(arg) if arg else 0.5
+        pred = [int(v >= t) for v in scores]
+        tp = sum(1 for q, y in zip(pred, labels) if q == 1 and y == 1)
+        fp = sum(1 for q, y in zip(pred, labels) if q == 1 and y != 1)
+        fn = sum(1 for q, y in zip(pred, labels) if q == 0 and y == 1)
+        return 2.0 * tp / (2.0 * tp + fp + fn) if tp + fp + fn else 0.0
+    raise ValueError(name)
+
+
 def grouped_metrics(scores, labels, groups, names=("GAUC", "MRR", "NDCG@1", "NDCG@5", "NDCG@10")):
-    """MetricPool.calculate (utils/metrics.py:313-369): per-`group` metric, fp32 mean over groups."""
+    """MetricPool.calculate (utils/metrics.py:313-369): per-`group` metric, fp32 mean over groups; point-wise metrics
+    (AUC, LogLoss, F1) over all rows."""
     scores = np.asarray(scores, dtype=np.float64)
     labels = np.asarray(labels)
     groups = np.asarray(groups)
     out = {}
     uniq = np.unique(groups)
     for name in names:
+        base, _, arg = name.partition("@")
+        if base in ("AUC", "LogLoss", "F1"):
+            out[name] = pointwise_metric(name, scores, labels)
+            continue
         vals = []
         for g in uniq:
             sel = groups == g
@@ -468,7 +534,17 @@ def grouped_metrics(scores, labels, groups, names=("GAUC", "MRR", "NDCG@1", "NDC
                 vals.append(_auc(l, s))
             elif name == "MRR":
                 vals.append(_mrr(l, s))
-            elif name.startswith("NDCG@"):
-                vals.append(_ndcg(l, s, int(name.split("@")[1])))
+            elif name == "MRR0":
+                vals.append(_mrr0(l, s))
+            elif name == "LRAP":
+                vals.append(_lrap(l, s))
+            elif base == "NDCG":
+                vals.append(_ndcg(l, s, int(arg)))
+            elif base == "HitRatio":
+                vals.append(_hit_ratio(l, s, int(arg)))
+            elif base == "Recall":
+                vals.append(_recall(l, s, int(arg)))
+            else:
+                raise ValueError(name)
         out[name] = float(np.asarray(vals, dtype=np.float32).mean(dtype=np.float32))
     return out

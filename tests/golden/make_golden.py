@@ -397,12 +397,50 @@ def metric_fixture(seed=11):
     print("metrics", res)
 
 
+FULL_METRICS = ["GAUC", "MRR", "MRR0", "NDCG@1", "NDCG@5", "NDCG@10", "HitRatio@1", "HitRatio@5", "HitRatio@10",
+                "Recall@1", "Recall@5", "Recall@10", "LRAP", "AUC", "LogLoss", "F1"]
+
+
+def metric_fixture_full(seed=12):
+    """every metric of MetricPool.metric_list on probabilities in (0, 1): groups of 2..150 rows, 1..4 positives, ties
+    (including ties between positives and negatives and an all-equal group) -> metrics_full.npz"""
+    from utils.metrics import MetricPool
+    rs = np.random.RandomState(seed)
+    groups, labels, scores = [], [], []
+    for g in range(60):
+        k = int(rs.randint(2, 12)) if g % 6 else int(rs.randint(40, 151))
+        lab = np.zeros(k, dtype=np.int64)
+        lab[rs.choice(k, size=min(int(rs.randint(1, 5)), k - 1), replace=False)] = 1
+        sc = (1.0 / (1.0 + np.exp(-rs.randn(k)))).astype(np.float32)
+        if g % 5 == 0:
+            sc[: k // 2] = sc[0]
+        if g % 7 == 3:
+            sc = np.round(sc, 1)             # many small tie groups
+        if g == 11:
+            sc[:] = 0.5
+        groups += [1000 - g] * k             # group ids are not sorted and not dense
+        labels += lab.tolist()
+        scores += sc.tolist()
+    perm = rs.permutation(len(groups))       # rows of one group are not contiguous
+    groups, labels = np.array(groups)[perm], np.array(labels)[perm]
+    scores = np.array(scores, dtype=np.float32)[perm]
+    pool = MetricPool.parse(FULL_METRICS)
+    res = pool.calculate(scores.tolist(), labels.tolist(), groups.tolist())
+    names = [str(m) for m in pool.metrics]
+    np.savez_compressed(os.path.join(OUT, "metrics_full.npz"), groups=groups, labels=labels, scores=scores,
+                        names=np.array(names), values=np.array([float(res[n]) for n in names]))
+    print("metrics_full", res)
+
+
 def main():
     assert os.path.isdir(REF), "the reference is only present in the build container"
     install_stubs()
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["metrics_full"]:
+        return metric_fixture_full()
     op_fixtures()
     metric_fixture()
+    metric_fixture_full()
     # small full-model pins (tiny shapes)
     model_fixture("naml_glove_d64", "naml", "glove", D=64, V=500, n_items=120, n_users=40, B=8, seed=2023)
     model_fixture("nrms_null_d64", "nrms", "null", D=64, V=500, n_items=120, n_users=40, B=8, seed=2024)

@@ -548,3 +548,72 @@ def test_naml_engine_hidden_512_matches_oracle():
                                  hist * (np.arange(S)[None] < hl[:, None]), hl)
     assert float(np.abs(scores.cpu().numpy() - lg).max()) < 1e-4 and abs(float(loss) - ls) < 2e-5
     _grads_close(G, g, "naml_d512")
+
+
+def test_grouped_metrics_kernel_matches_metricpool_fixtures():
+    """`lego_grouped_metrics` (one launch for every group and metric) against the reference MetricPool values of both
+    fixtures: every metric of MetricPool.metric_list, ties, unsorted non-contiguous groups."""
+    from legommenders_amd import metrics as PM
+    dev = _dev()
+    for fixture in ("metrics.npz", "metrics_full.npz"):
+        z = np.load(os.path.join(GOLDEN, fixture))
+        names = [str(n) for n in z["names"]]
+        got = PM.calculate_device(torch.tensor(z["scores"], device=dev), z["labels"], z["groups"], names)
+        assert list(got) == names
+        for n, v in zip(names, z["values"]):
+            assert abs(got[n] - float(v)) < 5e-7, (fixture, n, got[n], float(v))
+
+
+def test_grouped_metrics_kernel_at_evaluation_size_and_edges():
+    """MIND-dev-sized input (50 k groups, 2..300 rows, quantised scores -> many ties) against the oracle's per-group
+    restatement on a sample of groups and against the host form on all; groups of one class raise as sklearn does;
+    a single-row positive group is defined for the rank metrics."""
+    from legommenders_amd import metrics as PM
+    from legommenders_amd._lib import call
+    from legommenders_amd.engine import _ptr, _stream
+    from oracle import lego_oracle as O
+    dev = _dev()
+    rs = np.random.RandomState(5)
+    G = 50000
+    sizes = np.where(rs.rand(G) < 0.02, rs.randint(100, 301, size=G), rs.randint(2, 40, size=G))
+    groups = np.repeat(rs.permutation(G) * 3 + 7, sizes)
+    n = groups.size
+    scores = np.round(rs.randn(n), 1).astype(np.float32)
+    labels = np.zeros(n, dtype=np.int64)
+    off = np.r_[0, np.cumsum(sizes)]
+    labels[off[:-1]] = 1
+    extra = rs.rand(n) < 0.1
+    extra[off[1:] - 1] = False                                   # the last row of a group stays negative: both classes present
+    labels[extra] = 1
+    perm = rs.permutation(n)
+    groups, scores, labels = groups[perm], scores[perm], labels[perm]
+    names = ["GAUC", "MRR", "MRR0", "LRAP", "NDCG@1", "NDCG@5", "NDCG@10", "HitRatio@5", "Recall@10", "AUC", "F1"]
+    got = PM.calculate_device(torch.tensor(scores, device=dev), labels, groups, names)
+    host = PM.calculate(scores, labels, groups, names)
+    for k in names:
+        assert abs(got[k] - host[k]) < 2e-6, (k, got[k], host[k])
+    # per-group table against the oracle on 300 groups (pure-Python restatement of each metric)
+    order = np.argsort(groups, kind="stable")
+    gs = groups[order]
+    o = np.flatnonzero(np.r_[True, gs[1:] != gs[:-1], True]).astype(np.int32)
+    s_d = torch.tensor(scores[order], device=dev)
+    l_d = torch.tensor(labels[order].astype(np.int32), device=dev)
+    ks = np.array([1, 5, 10], dtype=np.int32)
+    table = torch.empty(4 + 9, o.size - 1, device=dev)
+    call("lego_grouped_metrics", _ptr(s_d), _ptr(l_d), _ptr(torch.tensor(o, device=dev)), o.size - 1, ks.ctypes.data, 3,
+         _ptr(table), _stream())
+    table = table.cpu().numpy()
+    for g in rs.choice(o.size - 1, size=300, replace=False):
+        l, s = labels[order][o[g]:o[g + 1]], scores[order][o[g]:o[g + 1]].astype(np.float64)
+        want = [O._auc(l, s), O._mrr(l, s), O._mrr0(l, s), O._lrap(l, s)]
+        for k in (1, 5, 10):
+            want += [O._ndcg(l, s, k), O._hit_ratio(l, s, k), O._recall(l, s, k)]
+        np.testing.assert_allclose(table[:, g], np.asarray(want, dtype=np.float32), rtol=2e-7, atol=1e-7)
+    # one-class group: roc_auc_score raises in the reference; the rank metrics stay defined
+    with pytest.raises(ValueError):
+        PM.calculate_device(torch.tensor([0.3, 0.1, 0.2], device=dev), np.array([1, 1, 0]), np.array([4, 4, 9]), ["GAUC"])
+    r = PM.calculate_device(torch.tensor([0.3, 0.1, 0.2], device=dev), np.array([1, 0, 1]), np.array([4, 4, 9]),
+                            ["MRR", "MRR0", "HitRatio@1", "NDCG@1", "LRAP"])
+    assert r == {"MRR": 1.0, "MRR0": 1.0, "HitRatio@1": 1.0, "NDCG@1": 1.0, "LRAP": 1.0}
+    with pytest.raises(ValueError):
+        PM.calculate_device(torch.tensor([0.3], device=dev), np.array([1]), np.array([0]), ["Precision@5"])

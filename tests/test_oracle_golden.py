@@ -68,8 +68,9 @@ def test_adam_linear_schedule_trajectory():
         np.testing.assert_allclose(p, z["adam.traj"][step + 1], rtol=1e-6, atol=1e-7)
 
 
-def test_metrics_match_metricpool():
-    z = np.load(os.path.join(GOLDEN, "metrics.npz"))
+@pytest.mark.parametrize("fixture", ["metrics.npz", "metrics_full.npz"])
+def test_metrics_match_metricpool(fixture):
+    z = np.load(os.path.join(GOLDEN, fixture))
     got = O.grouped_metrics(z["scores"], z["labels"], z["groups"], names=[str(n) for n in z["names"]])
     for n, v in zip(z["names"], z["values"]):
         assert abs(got[str(n)] - float(v)) < 5e-7, (n, got[str(n)], v)
@@ -102,15 +103,17 @@ def test_concat_layout_edges():
     assert m[2].tolist() == [1] * 7 and s[2].tolist() == [-1, -1, -1, -1, 2, -1, 2]
 
 
-def test_product_metrics_match_metricpool_and_oracle():
-    """legommenders_amd.metrics (product) against the reference MetricPool fixture and the oracle."""
+@pytest.mark.parametrize("fixture", ["metrics.npz", "metrics_full.npz"])
+def test_product_metrics_match_metricpool_and_oracle(fixture):
+    """legommenders_amd.metrics (host form) against the reference MetricPool fixtures (every metric of
+    MetricPool.metric_list in metrics_full.npz) and the oracle."""
     from legommenders_amd import metrics as PM
-    z = np.load(os.path.join(GOLDEN, "metrics.npz"))
+    z = np.load(os.path.join(GOLDEN, fixture))
     names = [str(n) for n in z["names"]]
     got = PM.calculate(z["scores"], z["labels"], z["groups"], names)
     ref = O.grouped_metrics(z["scores"], z["labels"], z["groups"], names=names)
     for n, v in zip(names, z["values"]):
-        assert abs(got[n] - float(v)) < 5e-7 and abs(got[n] - ref[n]) < 1e-9, n
+        assert abs(got[n] - float(v)) < 5e-7 and abs(got[n] - ref[n]) < 1e-7, n
 
 
 def test_bert_news_encoder_full_forward_backward():

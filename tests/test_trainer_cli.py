@@ -124,3 +124,53 @@ def test_bert_naml_cli_trains_through_the_plugin_route(tmp_path, monkeypatch):
     assert 0.3 < res["GAUC"] < 0.7
     state = torch.load(os.path.join("checkpoints", "synthetic", cfg.model.name, tr.signature + ".pt"))
     assert set(state["model"]) == set(tr.legommender.state_dict())
+
+
+def test_sizer_counts_trainable_parameters_only(capsys):
+    """sizer.py:49-66; SURVEY.md 8a13 pins NAML-GloVe-256 at 476 416 trainable parameters (frozen GloVe not counted)"""
+    from legommenders_amd import sizer
+    cfg = sizer.get_configurations(dict(data="config/data/synthetic.yaml", model="config/model/naml.yaml",
+                                        embed="config/embed/glove.yaml", hidden_size=256, world="small"))
+    sz = sizer.Sizer(cfg)
+    assert sz.run() == 476416
+    out = capsys.readouterr().out
+    assert "item_op.cnn.weight (256, 256, 3)" in out and "Number of parameters: 0.48M" in out
+    assert "glove.embedding.weight" not in out
+    # embed null: the token table becomes a trainable [V, D] parameter
+    cfg = sizer.get_configurations(dict(data="config/data/synthetic.yaml", model="config/model/nrms.yaml", hidden_size=64,
+                                        world="small"))
+    sz = sizer.Sizer(cfg)
+    names = dict(sz.named_trainable())
+    assert tuple(names["embedding_vocab_table.glove.weight"].shape) == (sz.world["V"], 64)
+    assert tuple(names["item_op.multi_head_attention.in_proj_weight"].shape) == (192, 64)
+
+
+def test_status_timer_stops_after_total_count():
+    from legommenders_amd.tester import StatusTimer
+    st = StatusTimer(total_count=3)
+    with pytest.raises(StopIteration):
+        for _ in range(10):
+            st.run()
+            st.run()
+    assert st.count == 3 and st.avgms() >= 0.0 and not st.timing
+
+
+@pytest.mark.gpu
+def test_tester_restores_checkpoint_and_times_scoring(tmp_path, monkeypatch):
+    """tester.py: `--load_sign` restores the trainer's checkpoint, `test` reproduces the trainer's test metrics and writes
+    the result file, `--latency` stops after num_batches timed scoring steps."""
+    from legommenders_amd import tester
+    from legommenders_amd.trainer import Trainer
+    monkeypatch.chdir(tmp_path)
+    common = dict(data="config/data/synthetic.yaml", model="config/model/naml.yaml", embed="config/embed/glove.yaml",
+                  batch_size=32, hidden_size=64, lr=0.001, cuda=0, world="small")
+    tr = Trainer(get_configurations(dict(common, epoch=1, patience=2, interval=0)))
+    ref = tr.run()
+    te = tester.Tester(tester.get_configurations(dict(common, load_sign=tr.signature)))
+    res = te.run()
+    assert res.keys() == ref.keys() and all(abs(res[k] - ref[k]) < 1e-6 for k in ref)
+    lines = open(os.path.join(te.ckpt_dir, te.signature + ".result")).read().splitlines()
+    assert lines[0].startswith("GAUC: ") and len(lines) == len(res)
+    te = tester.Tester(tester.get_configurations(dict(common, load_sign=tr.signature, latency=True, num_batches=20)))
+    st = te.run()
+    assert st.count == 20 and 0.0 < st.avgms() < 50.0

@@ -17,3 +17,11 @@ rs = np.random.RandomState(0)
 u = np.repeat(rs.choice(data.user_hist.shape[0], size=20000, replace=False), 10); n = u.size      # 10 rows per user, one positive
 it = rs.randint(0, data.n_items, n); lab = np.zeros(n, dtype=np.int64); lab[::10] = 1
 t0 = time.perf_counter(); res, _ = ev.evaluate(u, it, lab); print("evaluate 200k rows: %.3f s" % (time.perf_counter() - t0), res)
+from legommenders_amd import metrics as M
+names = ["GAUC", "MRR", "NDCG@1", "NDCG@5", "NDCG@10"]
+s = ev.scores(torch.as_tensor(u), torch.as_tensor(it)); torch.cuda.synchronize()
+for _ in range(2):
+    t0 = time.perf_counter(); r = M.calculate_device(s, lab, u, names); torch.cuda.synchronize()
+    print("grouped metrics on the device (sort + launch + table copy): %.4f s" % (time.perf_counter() - t0))
+t0 = time.perf_counter(); h = M.calculate(s.cpu().numpy(), lab, u, names)
+print("same metrics, host form: %.3f s; max |diff| %.2e" % (time.perf_counter() - t0, max(abs(r[k] - h[k]) for k in names)))
