@@ -617,3 +617,83 @@ def test_grouped_metrics_kernel_at_evaluation_size_and_edges():
     assert r == {"MRR": 1.0, "MRR0": 1.0, "HitRatio@1": 1.0, "NDCG@1": 1.0, "LRAP": 1.0}
     with pytest.raises(ValueError):
         PM.calculate_device(torch.tensor([0.3], device=dev), np.array([1]), np.array([0]), ["Precision@5"])
+
+
+@pytest.mark.parametrize("kind", ["naml", "nrms"])
+def test_headline_size_oracle_and_properties(kind):
+    """BASELINE.json configs 2 / 3 at their full batch shape (D=256, B=64, C=5, S=50, 65 238 items; the token vocabulary is
+    cut to 50 k rows to bound host memory): the engine against the oracle directly, then the size-independent properties
+    of the path -- impressions are independent (permutation equivariance), history slots past `hist_len` are never read,
+    the backward is linear in the incoming loss gradient, and two half batches average to the full batch (the
+    data-parallel contract of SURVEY.md 8e)."""
+    from oracle import lego_oracle as O
+    from legommenders_amd import engine as E
+    from legommenders_amd.synthetic import glove_like, init_naml_params, init_nrms_params, make_world
+    dev = _dev()
+    D, B, C, S, V = 256, 64, 5, 50, 50000
+    w = make_world(seed=2023, n_users=4000, n_rows=4000, V=V)
+    n_items = w["n_items"]
+    assert n_items == 65238
+    if kind == "naml":
+        P = init_naml_params(D=D, V=V, n_cat=w["n_cat"], glove=glove_like(V, 300, seed=2024, device=dev))
+        mk = lambda b: E.NamlEngine(Pd, tb, b, C, S, p_proj=0.0, p_conv=0.0)
+        okw = {}
+    else:
+        P = init_nrms_params(D=D, V=V, n_cat=w["n_cat"], heads=8, glove=None)
+        mk = lambda b: E.NrmsEngine(Pd, tb, b, C, S, heads=8, glove=False, p_proj=0.0, p_att=0.0)
+        okw = dict(heads=8, glove=False)
+    Pd = {k: v.to(dev).contiguous() for k, v in P.items()}
+    tb = E.ItemTables(w["title_tok"], w["title_len"], w["cat"], dev)
+    rs = np.random.RandomState(7)
+    cand = rs.randint(0, n_items, size=(B, C))
+    cand[3, 2] = cand[3, 0]                                   # a negative colliding with the positive (resampler.py:162-171)
+    users = rs.randint(0, 4000, size=B)
+    hist, hl = w["user_hist"][users].copy(), w["user_hist_len"][users].copy()
+    hl[5] = 0 if kind == "naml" else 1                         # empty history (NRMS: nn.MultiheadAttention over an all-masked
+                                                              # row is NaN in the reference, so one click there)
+    hl[6] = S                                                 # full history
+    hist[6] = rs.randint(0, n_items, size=S)
+    hist[7, :hl[7]] = cand[7, 0]                              # the positive already clicked, repeated
+    hist = hist * (np.arange(S)[None] < hl[:, None])
+
+    def run(eng, c, h, l, gloss=1.0):
+        ids = [torch.tensor(np.ascontiguousarray(a)).int().to(dev).contiguous() for a in (c, h, l)]
+        scores, loss = eng.forward(*ids, training=False)
+        G = eng.grads_like()
+        eng.backward(G, gloss)
+        torch.cuda.synchronize()
+        return scores.clone(), float(loss), G
+
+    eng = mk(B)
+    scores, loss, G = run(eng, cand, hist, hl)
+    tables = {k: w[k].astype(np.int64) for k in ("title_tok", "title_len", "cat")}
+    lg, ls, g = O.loss_and_grads(kind, {k: v.cpu().numpy() for k, v in P.items()}, tables, cand, hist, hl, **okw)
+    assert float(np.abs(scores.cpu().numpy() - lg).max()) < 2e-4 and abs(loss - ls) < 2e-5
+    _grads_close(G, g, f"{kind} headline size")
+    Gn = {k: v.cpu().numpy() for k, v in G.items()}
+
+    # impressions are independent: permuting them permutes the logits and leaves loss and gradients alone
+    perm = rs.permutation(B)
+    s2, l2, G2 = run(eng, cand[perm], hist[perm], hl[perm])
+    _close(s2.cpu(), scores.cpu().numpy()[perm], rtol=2e-6, atol=2e-6, what="permuted logits")
+    assert abs(l2 - loss) < 2e-6
+    _grads_close(G2, Gn, "permuted batch")
+
+    # history slots past hist_len are padding: their content is never read
+    junk = np.where(np.arange(S)[None] < hl[:, None], hist, rs.randint(0, n_items, size=(B, S)))
+    s3, l3, _ = run(eng, cand, junk, hl)
+    assert torch.equal(s3, scores) and abs(l3 - loss) < 1e-6      # logits bit-equal; the loss is a sum of B atomics
+
+    # backward is linear in d(loss)
+    _, _, G4 = run(eng, cand, hist, hl, gloss=3.0)
+    _grads_close({k: v / 3.0 for k, v in G4.items()}, Gn, "gloss linearity")
+
+    # two half batches, averaged == the full batch
+    half = mk(B // 2)
+    acc = None
+    for r in range(2):
+        sl = slice(r * B // 2, (r + 1) * B // 2)
+        s5, _, G5 = run(half, cand[sl], hist[sl], hl[sl])
+        _close(s5.cpu(), scores.cpu().numpy()[sl], rtol=2e-6, atol=2e-6, what="half-batch logits")
+        acc = G5 if acc is None else {k: acc[k] + G5[k] for k in acc}
+    _grads_close({k: v * 0.5 for k, v in acc.items()}, Gn, "two half batches")
