@@ -12,6 +12,7 @@ class Env:
     item_cache = False
     user_cache = False
     lm_cache = False
+    data_name = None              # Env.ph.data_name of the reference: names the on-disk layer cache directory
 
     @classmethod
     def train(cls):

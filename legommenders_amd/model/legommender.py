@@ -73,6 +73,8 @@ class Legommender(nn.Module):
         self.user_op = config.user_operator
         self.predictor = config.predictor
         Env.set_lm_cache(False)
+        if config.use_item_content and hasattr(self.item_op, "use_lm_cache"):      # legommender.py:104-107
+            Env.set_lm_cache(bool(self.item_op.use_lm_cache()))
         self.loss_func = nn.CrossEntropyLoss() if self.use_neg_sampling else nn.BCEWithLogitsLoss()
         self.engine = None
         self._anchor = torch.zeros((), requires_grad=True)
@@ -117,6 +119,8 @@ class Legommender(nn.Module):
         """Device-resident item table (engine.ItemTables): lets `forward` accept id-only batches, the layout the
         device Resampler emits (the reference ships stacked per-item tensors instead, resampler.py:191-193)."""
         self.item_table = tables
+        if Env.lm_cache and hasattr(self.item_op, "build_layer_cache"):
+            self.item_op.build_layer_cache(self)          # cached-layer LM operators (once_operator.py:99-134)
 
     def expand_item_ids(self, ids: torch.Tensor):
         """ids [B,C] -> the nested `{input_ids, attention_mask}` batch the item inputer expects (index
@@ -162,6 +166,12 @@ class Legommender(nn.Module):
             indices = batch[col].to(Env.device)
             return self.item_repr[indices.reshape(-1)].reshape(*indices.shape, -1)
         content = batch[col]
+        if Env.lm_cache:                                             # legommender.py:166-169,187-188: ids go to the operator
+            ids = content.to(Env.device)
+            flat = ids.reshape(-1)
+            page = self.config.item_page_size or flat.numel()
+            outs = [self.item_op(flat[s:s + page], mask=None) for s in range(0, flat.numel(), page)]
+            return (outs[0] if len(outs) == 1 else torch.cat(outs, 0)).view(*ids.shape, -1)
         if isinstance(content, torch.Tensor):                        # id-only batch: expand through the item table
             content = self.expand_item_ids(content)
         item_content, B, C = _flatten(content)

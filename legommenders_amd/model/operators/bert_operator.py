@@ -8,11 +8,21 @@ loader/embedding_hub.py:269-271) is the path's HIP row gather; the transformer b
 
 Reproduced quirk: with the yaml default `tune_from: 0` the reference still slices `encoder.layer[1:]` (and pre-caches the
 layer-0 states on disk, which nothing reads) while `forward` takes the whole-transformer branch because `not 0` is true
-(once_operator.py:128-134,173-180) -- so the model that trains is BERT without its first block.  `tune_from > 0` (cached
-hidden states gathered on the CPU per batch, once_operator.py:182-188) and LoRA (needs `peft`) are not built and say so."""
+(once_operator.py:128-134,173-180) -- so the model that trains is BERT without its first block.
+
+`tune_from = k > 0` (cached-layer mode, once_operator.py:99-134,182-188): hidden_states[k] of the checkpoint transformer
+is computed once for every item (`build_layer_cache`, pages of `item_page_size`), the blocks `[k + 1:]` stay (block k is
+skipped, as upstream) and training batches index the cache by item id (`Env.lm_cache`).  The reference keeps that cache as
+a CPU tensor and copies the batch's rows to the device every step; here it lives in HBM ([n_items, L, H] fp32: 6.6 GB for
+MIND-small at BERT-base width, of 288 GB) and the per-batch look-up is a device gather.  The on-disk layout
+`cache/<data>/<operator>/layer_k.npy` + `mask.npy` is read when present and written after a build
+(`LEGO_LAYER_CACHE_SAVE=0` skips the write), so caches made by the reference's splitter.py are usable.
+LoRA (needs `peft`) is not built and says so."""
 import abc
 import os
 
+import numpy as np
+import torch
 from torch import nn
 
 from legommenders_amd import functional as F_hip
@@ -67,6 +77,8 @@ class BertOperator(LMOperator, abc.ABC):
         self.additive_attention = AdditiveAttention(embed_dim=self.config.hidden_size,
                                                     hidden_size=self.config.additive_hidden_size)
         self.transformer.embeddings.word_embeddings = None            # bert_operator.py:16: inputs_embeds only
+        self.hidden_weights = None                                    # [n_items, L, H] layer cache (device)
+        self.attention_mask = None                                    # [n_items, L]
         self._prepare_network()
         if self.transformer.config.hidden_size != self.config.input_dim:
             raise ValueError(f"In {self.classname}, hidden_size of transformer ({self.transformer.config.hidden_size}) "
@@ -98,10 +110,9 @@ class BertOperator(LMOperator, abc.ABC):
         if self.config.tune_from is not None:
             if self.config.tune_from > self.num_hidden_layers:
                 raise ValueError(f"tune_from should be less than {self.num_hidden_layers}")
-            if self.config.tune_from:
-                raise NotImplementedError("tune_from > 0 trains on hidden states cached in cache/<data>/<name>/layer_k.npy "
-                                          "(once_operator.py:99-126,182-188); only the whole-transformer branch is built")
-            self._slice_transformer_layers()                          # also for tune_from == 0: see the module docstring
+            if not self.config.tune_from:
+                self._slice_transformer_layers()                      # also for tune_from == 0: see the module docstring
+            # tune_from > 0: the cache needs every block and the item table -- `build_layer_cache` slices afterwards
         if (self.config.tune_from is None or self.config.tune_from < self.num_hidden_layers - 1) and self.config.use_lora:
             raise NotImplementedError("use_lora needs `peft`, which this build does not ship; set item_config.use_lora: false "
                                       "(the bert-naml.yaml default)")
@@ -109,11 +120,81 @@ class BertOperator(LMOperator, abc.ABC):
     def get_pretrained_parameter_names(self):
         return ["transformer"]
 
+    # ---- cached-layer mode (once_operator.py:72-126)
+    @property
+    def _cache_base_dir(self):
+        return os.path.join("cache", str(getattr(Env, "data_name", None) or "data"), self.operator_name)
+
+    def _get_cache_path(self, layer):
+        return os.path.join(self._cache_base_dir, f"layer_{layer}.npy")
+
+    def _get_mask_path(self):
+        return os.path.join(self._cache_base_dir, "mask.npy")
+
+    @torch.no_grad()
+    def build_layer_cache(self, legommender):
+        """hidden_states[tune_from] of every item, then `encoder.layer = layer[tune_from + 1:]` (once_operator.py:99-134).
+        Called by `Legommender.attach_item_table`, i.e. before any optimiser collects the parameters."""
+        k = int(self.config.tune_from)
+        if not k or self.hidden_weights is not None:
+            return
+        dev = Env.device
+        n_items = int(legommender.item_table.title_tok.shape[0])
+        if os.path.exists(self._get_cache_path(k)) and os.path.exists(self._get_mask_path()):
+            mask = torch.from_numpy(np.load(self._get_mask_path())).to(dev)
+            hidden = torch.from_numpy(np.load(self._get_cache_path(k))).to(dev).float()
+            hidden = hidden.view(*mask.shape[:2], hidden.shape[-1])
+            if mask.shape[0] != n_items:
+                raise ValueError(f"{self._get_cache_path(k)} holds {mask.shape[0]} items, the item table {n_items}")
+        else:
+            from legommenders_amd.model.legommender import _flatten
+            was_training = self.transformer.training
+            self.transformer.eval()                                   # from_pretrained hands the reference an eval-mode module
+            page = int(self.lego_config.item_page_size or 512)
+            hs, ms = [], []
+            for s in range(0, n_items, page):
+                ids = torch.arange(s, min(s + page, n_items), device=dev)[:, None]
+                content, _, _ = _flatten(legommender.expand_item_ids(ids))
+                m = self.inputer.get_mask(content).to(dev)
+                e = self.inputer.get_embeddings(content)
+                out = self.transformer(inputs_embeds=e.float(), attention_mask=m.float(), output_hidden_states=True,
+                                       return_dict=True)
+                hs.append(out.hidden_states[k].float())
+                ms.append(m.long())
+            hidden, mask = torch.cat(hs, 0).contiguous(), torch.cat(ms, 0).contiguous()
+            self.transformer.train(was_training)
+            if os.environ.get("LEGO_LAYER_CACHE_SAVE", "1") != "0":
+                os.makedirs(self._cache_base_dir, exist_ok=True)
+                np.save(self._get_cache_path(k), hidden.cpu().numpy())
+                np.save(self._get_mask_path(), mask.cpu().numpy())
+        nan_rows = torch.isnan(hidden).any(-1)                        # once_operator.py:116-124
+        if bool(nan_rows.any()):
+            hidden[nan_rows] = torch.rand_like(hidden[nan_rows])
+            bad = nan_rows.any(-1)
+            template = torch.zeros_like(mask[0])
+            template[0] = 1
+            mask[bad] = template
+        self.hidden_weights, self.attention_mask = hidden, mask
+        self._slice_transformer_layers()
+
+    def _loop_forward(self, hidden_states, attention_mask):
+        """bert_operator.py:30-45: the kept blocks on cached states"""
+        ext = (1.0 - attention_mask[:, None, None, :].to(hidden_states.dtype)) * torch.finfo(hidden_states.dtype).min
+        return self.transformer.encoder(hidden_states=hidden_states, attention_mask=ext, return_dict=True).last_hidden_state
+
     # ---- forward (once_operator.py:173-193, tune_from falsy)
     def forward(self, embeddings, mask=None, **kwargs):
-        mask = mask.to(Env.device)
-        outputs = self.transformer(inputs_embeds=embeddings.float(), attention_mask=mask.float(),
-                                   return_dict=True).last_hidden_state
+        if self.config.tune_from:                                     # once_operator.py:182-188: `embeddings` are item ids
+            if self.hidden_weights is None:
+                raise RuntimeError(f"{self.classname}: tune_from = {self.config.tune_from} needs the layer cache -- "
+                                   f"call Legommender.attach_item_table(...) first")
+            indices = embeddings.to(Env.device).long().reshape(-1)
+            mask = self.attention_mask[indices]
+            outputs = self._loop_forward(self.hidden_weights[indices], mask.float())
+        else:
+            mask = mask.to(Env.device)
+            outputs = self.transformer(inputs_embeds=embeddings.float(), attention_mask=mask.float(),
+                                       return_dict=True).last_hidden_state
         outputs = F_hip.linear(outputs.float().contiguous(), self.linear.weight, self.linear.bias)
         return self.additive_attention(outputs, mask)
 

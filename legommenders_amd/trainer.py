@@ -104,6 +104,7 @@ def build_model(config: Obj, world: dict, device):
     from legommenders_amd.synthetic import glove_like
 
     model, embed, data = config.model, config.embed, config.data
+    Env.data_name = data.name
     first = (data.item.inputs() or [{"title@glove": world["T"]}])[0]          # data yaml: item.inputs[0] = {col: max_len} | col
     tcol = next(iter(first)) if isinstance(first, dict) else str(first)
     tvocab = tcol.split("@", 1)[1] if "@" in tcol else tcol                   # `title@glove` -> vocab `glove` (UniTok naming)

@@ -231,26 +231,75 @@ def bert_encoder(x, mask, P, prefix, n_layers, heads, eps=1e-12):
     (Devlin et al. 2019; modeling_bert.py BertEmbeddings / BertSelfAttention / BertSelfOutput / BertIntermediate /
     BertOutput): h0 = LayerNorm(x + type_emb[0] + pos_emb[:L]); per layer: scores = QK^T/sqrt(dh) + (1-mask)*finfo.min
     over keys, softmax, context; a = LayerNorm(dense(context) + h); h = LayerNorm(dense(gelu(dense(a))) + a).  x:[n,L,H]."""
-    n, L, H = x.shape
+    return bert_hidden_states(x, mask, P, prefix, n_layers, heads, eps)[-1]
+
+
+def _bert_layer(h, ext, P, lp, heads, eps):
+    n, L, H = h.shape
     dh = H // heads
+
+    def heads_of(name):
+        y = F.linear(h, P[lp + f"attention.self.{name}.weight"], P[lp + f"attention.self.{name}.bias"])
+        return y.view(n, L, heads, dh).permute(0, 2, 1, 3)
+    q, k, v = heads_of("query"), heads_of("key"), heads_of("value")
+    probs = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(dh) + ext, dim=-1)
+    ctx = (probs @ v).permute(0, 2, 1, 3).reshape(n, L, H)
+    a = F.layer_norm(F.linear(ctx, P[lp + "attention.output.dense.weight"], P[lp + "attention.output.dense.bias"]) + h,
+                     (H,), P[lp + "attention.output.LayerNorm.weight"], P[lp + "attention.output.LayerNorm.bias"], eps)
+    i = F.gelu(F.linear(a, P[lp + "intermediate.dense.weight"], P[lp + "intermediate.dense.bias"]))
+    return F.layer_norm(F.linear(i, P[lp + "output.dense.weight"], P[lp + "output.dense.bias"]) + a,
+                        (H,), P[lp + "output.LayerNorm.weight"], P[lp + "output.LayerNorm.bias"], eps)
+
+
+def bert_hidden_states(x, mask, P, prefix, n_layers, heads, eps=1e-12):
+    """`BertModel(..., output_hidden_states=True).hidden_states`: [embeddings output, block 1 output, ..., block n output]
+    -- entry k is what `OnceOperator.cache([k])` stores per item (once_operator.py:99-126, lm_layer_pager.py `combine`)."""
+    n, L, H = x.shape
     h = x + P[prefix + "embeddings.token_type_embeddings.weight"][0] + P[prefix + "embeddings.position_embeddings.weight"][:L]
     h = F.layer_norm(h, (H,), P[prefix + "embeddings.LayerNorm.weight"], P[prefix + "embeddings.LayerNorm.bias"], eps)
     ext = (1.0 - mask.to(x.dtype))[:, None, None, :] * torch.finfo(x.dtype).min
+    states = [h]
     for l in range(n_layers):
-        lp = f"{prefix}encoder.layer.{l}."
+        h = _bert_layer(h, ext, P, f"{prefix}encoder.layer.{l}.", heads, eps)
+        states.append(h)
+    return states
 
-        def heads_of(name):
-            y = F.linear(h, P[lp + f"attention.self.{name}.weight"], P[lp + f"attention.self.{name}.bias"])
-            return y.view(n, L, heads, dh).permute(0, 2, 1, 3)
-        q, k, v = heads_of("query"), heads_of("key"), heads_of("value")
-        probs = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(dh) + ext, dim=-1)
-        ctx = (probs @ v).permute(0, 2, 1, 3).reshape(n, L, H)
-        a = F.layer_norm(F.linear(ctx, P[lp + "attention.output.dense.weight"], P[lp + "attention.output.dense.bias"]) + h,
-                         (H,), P[lp + "attention.output.LayerNorm.weight"], P[lp + "attention.output.LayerNorm.bias"], eps)
-        i = F.gelu(F.linear(a, P[lp + "intermediate.dense.weight"], P[lp + "intermediate.dense.bias"]))
-        h = F.layer_norm(F.linear(i, P[lp + "output.dense.weight"], P[lp + "output.dense.bias"]) + a,
-                         (H,), P[lp + "output.LayerNorm.weight"], P[lp + "output.LayerNorm.bias"], eps)
-    return h
+
+def bert_operator_cached(hidden, mask, P, prefix, n_layers, heads, eps=1e-12):
+    """OnceOperator.forward, `tune_from = k > 0` branch (once_operator.py:182-193, bert_operator.py:30-45): the cached
+    layer-k states of the batch's items run through the blocks KEPT after `encoder.layer[k + 1:]` (renumbered from 0 in
+    the state_dict; block k itself is skipped -- the reference's off-by-one), then Linear and the additive pool."""
+    ext = (1.0 - mask.to(hidden.dtype))[:, None, None, :] * torch.finfo(hidden.dtype).min
+    h = hidden
+    for l in range(n_layers):
+        h = _bert_layer(h, ext, P, f"{prefix}transformer.encoder.layer.{l}.", heads, eps)
+    y = F.linear(h, P[prefix + "linear.weight"], P[prefix + "linear.bias"])
+    return additive_attention(y, mask, P[prefix + "additive_attention.encoder.0.weight"],
+                              P[prefix + "additive_attention.encoder.0.bias"],
+                              P[prefix + "additive_attention.encoder.2.weight"])
+
+
+def bert_layer_cache(P_ckpt, word_table, cat_table, title_tok, title_len, cat, layer, n_layers, heads, eps=1e-12):
+    """The per-item cache of `OnceOperator.cache([layer])`: hidden_states[layer] of the CHECKPOINT transformer (all blocks,
+    before slicing) for every item, and the ConcatInputer mask.  P_ckpt: BertModel state_dict keys (no prefix)."""
+    t_ids, c_ids, _, mask = concat_layout(title_tok, title_len, cat, use_sep=False)
+    e_t, _ = table_lookup(t_ids, word_table)
+    e_c, _ = table_lookup(c_ids, cat_table)
+    return bert_hidden_states(e_t + e_c, mask, P_ckpt, "", n_layers, heads, eps)[layer], mask
+
+
+def bert_naml_cached_forward(P, hidden_cache, mask_cache, cand, hist, hist_len, n_layers, heads, eps=1e-12):
+    """Legommender.forward with `Env.lm_cache` (legommender.py:166-189): item ids index the layer cache directly."""
+    ids, B, C, S = _item_ids(cand, hist)
+    items = bert_operator_cached(hidden_cache[ids], mask_cache[ids], P, "item_op.", n_layers, heads, eps)
+    D = items.shape[-1]
+    cand_v = items[: B * C].view(B, C, D)
+    hist_v = items[B * C:].view(B, S, D)
+    hmask = (torch.arange(S)[None, :] < hist_len[:, None]).long()
+    user = additive_attention(hist_v, hmask, P["user_op.additive_attention.encoder.0.weight"],
+                              P["user_op.additive_attention.encoder.0.bias"],
+                              P["user_op.additive_attention.encoder.2.weight"])
+    return dot_scores(user, cand_v)
 
 
 def bert_operator(x, mask, P, prefix, n_layers, heads, eps=1e-12):
@@ -307,7 +356,8 @@ def eval_scores(kind, P, title_tok, title_len, cat, user_hist, user_hist_len, ro
     return (user_repr[rows_user] * item_repr[rows_item]).sum(-1), item_repr, user_repr
 
 
-def loss_and_grads(kind, P_np, tables, cand, hist, hist_len, heads=8, glove=True, frozen=(), bert_layers=0, bert_eps=1e-12):
+def loss_and_grads(kind, P_np, tables, cand, hist, hist_len, heads=8, glove=True, frozen=(), bert_layers=0, bert_eps=1e-12,
+                   layer_cache=None):
     """Logits, loss and d(loss)/d(param) for every trainable tensor (dropout 0).  numpy in/out."""
     P = {}
     for k, v in P_np.items():
@@ -319,6 +369,8 @@ def loss_and_grads(kind, P_np, tables, cand, hist, hist_len, heads=8, glove=True
     c, h, hl = _t(cand), _t(hist), _t(hist_len)
     if kind == "naml":
         logits = naml_forward(P, tt, ct, c, h, hl)
+    elif kind == "bert_naml" and layer_cache is not None:
+        logits = bert_naml_cached_forward(P, _t(layer_cache[0]), _t(layer_cache[1]), c, h, hl, bert_layers, heads, bert_eps)
     elif kind == "bert_naml":
         logits = bert_naml_forward(P, tt, tl, ct, c, h, hl, bert_layers, heads, bert_eps)
     else:
@@ -327,7 +379,7 @@ def loss_and_grads(kind, P_np, tables, cand, hist, hist_len, heads=8, glove=True
     names = [k for k, v in P.items() if v.requires_grad]
     grads = torch.autograd.grad(loss, [P[k] for k in names], allow_unused=True)
     g = {k: (gv.numpy() if gv is not None else np.zeros_like(P_np[k])) for k, gv in zip(names, grads)}
-    return logits.detach().numpy(), float(loss), g
+    return logits.detach().numpy(), float(loss.detach()), g
 
 
 def naml_train_step_cpu(P, opt, title_tok, cat, cand, hist, hist_len, p_drop=0.1):

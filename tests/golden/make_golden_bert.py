@@ -5,6 +5,7 @@ weights exist offline).  Container-only, like make_golden.py: imports the refere
 (`unitok`, `pigmento`, plus `peft` and `utils.config_init`, which this operator pulls in) and stores data only.
 
     python tests/golden/make_golden_bert.py       # rewrites tests/golden/bert_naml_small.npz
+    python tests/golden/make_golden_bert.py tune1 # rewrites tests/golden/bert_naml_tune1.npz (tune_from = 1)
 """
 from __future__ import annotations
 
@@ -42,9 +43,9 @@ def install_bert_stubs(bert_dir):
     sys.modules["utils.config_init"] = ci
 
 
-def main():
+def main(tune_from=0, name="bert_naml_small"):
     from transformers import BertConfig, BertModel
-    seed, D, H, V, n_items, n_users, B = 31, 32, 64, 300, 60, 30, 6
+    seed, D, H, V, n_items, n_users, B = 31 + tune_from, 32, 64, 300, 60, 30, 6
     torch.manual_seed(seed); random.seed(seed); np.random.seed(seed)
     shutil.rmtree(TMP, ignore_errors=True)
     os.makedirs(TMP)
@@ -88,7 +89,7 @@ def main():
     # config/model/bert-naml.yaml: item_hidden_size = transformer width, tune_from 0, no LoRA, no CLS/SEP tokens
     lc = LegoConfig(hidden_size=D, item_hidden_size=H, neg_count=4, item_page_size=0,
                     user_config={"inputer_config": {"use_cls_token": False, "use_sep_token": False}},
-                    item_config={"tune_from": 0, "use_lora": False, "lora_r": None, "lora_alpha": None,
+                    item_config={"tune_from": tune_from, "use_lora": False, "lora_r": None, "lora_alpha": None,
                                  "inputer_config": {"use_cls_token": False, "use_sep_token": False}})
     lc.set_component_classes(BertBaseOperator, AdaOperator, DotPredictor)
     lc.set_item_ut(item_ut, ["title@glove", "category"])
@@ -105,7 +106,8 @@ def main():
     lc.register_inputer_vocabs()
     model = Legommender(lc)
     kept = len(model.item_op.transformer.encoder.layer)
-    assert kept == cfg.num_hidden_layers - 1          # tune_from = 0 still slices layer[1:] (once_operator.py:128-134)
+    assert kept == cfg.num_hidden_layers - 1 - tune_from   # tune_from = 0 still slices layer[1:] (once_operator.py:128-134)
+    assert Env.lm_cache == bool(tune_from)
     with torch.no_grad():                             # non-trivial biases / LayerNorm gains so they are pinned too
         for n, p_ in model.named_parameters():
             if p_.requires_grad and (n.endswith("bias") or "LayerNorm.weight" in n):
@@ -113,7 +115,12 @@ def main():
     resampler = Resampler(lc)
     Env.train(); model.train()
     batch = MG.reference_batch(resampler, inter_ut, list(range(B)))
-    cand, hist, hist_len = MG.flat_batch("concat", batch, w)
+    if tune_from:                                     # Env.lm_cache: the resampler hands over bare ids (resampler.py:181-188,244-246)
+        cand = batch["item_id"].numpy().copy()
+        hist = batch["history"].numpy().copy()
+        hist_len = batch["__clicks_mask__"].sum(-1).numpy().copy()
+    else:
+        cand, hist, hist_len = MG.flat_batch("concat", batch, w)
     assert (cand[:, 0] == w["row_item"][:B]).all()
     batch2 = MG.clone_batch(batch)
     model.zero_grad()
@@ -129,18 +136,27 @@ def main():
     out.update(grads)
     out.update(MG.world_np(w))
     out.update({"cand": cand, "hist": hist, "hist_len": hist_len, "logits": logits, "loss": np.float32(loss.item())})
+    if tune_from:
+        # the layer cache the operator trained on (once_operator.py:99-126) and the checkpoint it was computed from
+        out["cache::hidden"] = model.item_op.hidden_weights.numpy().copy()
+        out["cache::mask"] = model.item_op.attention_mask.numpy().copy()
+        for k_, v_ in BertModel.from_pretrained(TMP).state_dict().items():
+            out["ckpt::" + k_] = v_.numpy().copy()
     bert_cfg = dict(hidden_size=H, num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
                     intermediate_size=cfg.intermediate_size, max_position_embeddings=cfg.max_position_embeddings,
                     layer_norm_eps=cfg.layer_norm_eps, hidden_act=cfg.hidden_act, vocab_size=V)
     meta = dict(kind="bert_naml", embed="wordpiece", D=D, item_hidden=H, V=V, n_items=n_items, n_users=n_users, B=B, seed=seed,
-                heads=cfg.num_attention_heads, tune_from=0, layers_kept=kept, bert=bert_cfg, torch=torch.__version__,
+                heads=cfg.num_attention_heads, tune_from=tune_from, layers_kept=kept, bert=bert_cfg, torch=torch.__version__,
                 transformers=__import__("transformers").__version__,
                 note="random-init BertConfig (no pretrained weights offline); the frozen word-piece table is stored")
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
-    np.savez_compressed(os.path.join(HERE, "bert_naml_small.npz"), **out)
-    print("bert_naml_small: loss", float(loss.detach()), "logits[0]", logits[0], "grads", len(grads))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, ": loss", float(loss.detach()), "logits[0]", logits[0], "grads", len(grads))
     shutil.rmtree(TMP, ignore_errors=True)
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["tune1"]:
+        main(1, "bert_naml_tune1")        # cached-layer mode: hidden states of layer 1 cached, blocks [2:] train
+    else:
+        main()

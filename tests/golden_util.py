@@ -25,4 +25,4 @@ def load_model_fixture(name):
 
 
 MODEL_FIXTURES = ["naml_glove_d64", "nrms_null_d64", "nrms_glove_d64", "naml_glove_cfg1", "naml_glove_d256"]
-BERT_FIXTURES = ["bert_naml_small"]          # SURVEY.md 8(f)-2, tests/golden/make_golden_bert.py
+BERT_FIXTURES = ["bert_naml_small", "bert_naml_tune1"]          # SURVEY.md 8(f)-2, tests/golden/make_golden_bert.py

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.golden_util import load_model_fixture
+from tests.golden_util import GOLDEN, load_model_fixture
 
 
 def _lego_config(meta, tables, P, ops, preds, item_config_extra=None):
@@ -60,8 +60,8 @@ def test_construction_rules_follow_the_reference():
         _lego_config(meta, tables, P, ops, preds, {"transformer_config": bad}).build_components()
     with pytest.raises(NotImplementedError, match="peft"):
         _lego_config(meta, tables, P, ops, preds, {"use_lora": True, "lora_r": 8, "lora_alpha": 16}).build_components()
-    with pytest.raises(NotImplementedError, match="tune_from"):
-        _lego_config(meta, tables, P, ops, preds, {"tune_from": 1}).build_components()
+    with pytest.raises(ValueError, match="tune_from should be less than"):      # once_operator.py:103-104
+        _lego_config(meta, tables, P, ops, preds, {"tune_from": 7}).build_components()
     with pytest.raises(ValueError, match="no local checkpoint"):                # no network: the checkpoint must be local
         _lego_config(meta, tables, P, ops, preds, {"transformer_config": None}).build_components()
 
@@ -103,3 +103,70 @@ def test_bert_naml_matches_reference_logits_loss_grads():
         scores = model(batch=dict(ids))
     assert float(np.abs(scores.cpu().numpy() - logits).max()) < 1e-3               # the north-star bar on fp32 logits
     assert float(np.abs(scores.cpu().numpy() - logits).max()) < 1e-4
+
+
+@pytest.mark.gpu
+def test_bert_cached_layer_mode_matches_reference(tmp_path, monkeypatch):
+    """`tune_from = 1` (once_operator.py:99-134,182-188): the operator builds the layer-1 cache of every item from the
+    checkpoint (device-resident), slices the transformer to the blocks after it, and training / scoring batches index the
+    cache by item id (`Env.lm_cache`).  Cache, loss, gradients and logits against the reference's own run
+    (tests/golden/bert_naml_tune1.npz); the on-disk cache layout is written and read back."""
+    import os
+    from legommenders_amd.engine import ItemTables
+    from legommenders_amd.loader.class_hub import ClassHub
+    from legommenders_amd.loader.env import Env
+    from legommenders_amd.model.legommender import Legommender
+    monkeypatch.chdir(tmp_path)
+    dev = torch.device("cuda:0")
+    Env.set_device(dev)
+    Env.data_name = "golden"
+    z = np.load(os.path.join(GOLDEN, "bert_naml_tune1.npz"))
+    meta, P, G, tables, batch, logits, loss = load_model_fixture("bert_naml_tune1")
+
+    def build():
+        lc = _lego_config(meta, tables, P, ClassHub.operators(), ClassHub.predictors(), {"tune_from": 1})
+        lc.build_components()
+        lc.register_inputer_vocabs()
+        m = Legommender(lc).to(dev)
+        assert Env.lm_cache and m.item_op.use_lm_cache()
+        assert len(m.item_op.transformer.encoder.layer) == meta["bert"]["num_hidden_layers"]      # not sliced yet
+        ckpt = {k[len("ckpt::"):]: torch.tensor(z[k]) for k in z.files if k.startswith("ckpt::")}
+        missing, unexpected = m.item_op.transformer.load_state_dict(ckpt, strict=False)
+        assert set(unexpected) <= {"embeddings.word_embeddings.weight"} and not missing, (missing, unexpected)
+        with torch.no_grad():                                     # frozen tables the cache is computed from
+            m.embedding_vocab_table["category"].weight.copy_(torch.tensor(P["embedding_vocab_table.category.weight"]))
+        m.attach_item_table(ItemTables(tables["title_tok"], tables["title_len"], tables["cat"], dev))
+        return m
+
+    model = build()
+    op = model.item_op
+    assert len(op.transformer.encoder.layer) == meta["layers_kept"]                                   # blocks [2:] of 3
+    assert np.array_equal(op.attention_mask.cpu().numpy(), z["cache::mask"])
+    np.testing.assert_allclose(op.hidden_weights.cpu().numpy(), z["cache::hidden"], rtol=1e-4, atol=1e-5)
+    assert os.path.exists("cache/golden/bertbase/layer_1.npy") and os.path.exists("cache/golden/bertbase/mask.npy")
+    missing, unexpected = model.load_state_dict({k: torch.tensor(v) for k, v in P.items()}, strict=False)
+    assert not unexpected and all(m.startswith("_") for m in missing), (missing, unexpected)
+    assert set(P) == set(model.state_dict())
+    ids = {"item_id": torch.tensor(batch["cand"]), "history": torch.tensor(batch["hist"]),
+           "__clicks_mask__": (torch.arange(50)[None] < torch.tensor(batch["hist_len"])[:, None]).long()}
+    Env.train()
+    model.train()
+    out = model(batch=dict(ids))
+    assert abs(float(out) - loss) < 2e-5
+    out.backward()
+    gscale = max(float(np.abs(g).max()) for g in G.values())
+    got = dict(model.named_parameters())
+    for k, g in G.items():
+        d = got[k].grad.detach().cpu().numpy().astype(np.float64) - g
+        assert float(np.abs(d).max()) <= 2e-3 * float(np.abs(g).max()) + 2e-6 * gscale, (k, float(np.abs(d).max()))
+    Env.test()
+    model.eval()
+    with torch.no_grad():
+        scores = model(batch=dict(ids))
+    assert float(np.abs(scores.cpu().numpy() - logits).max()) < 1e-4
+    # a second construction finds the cache on disk (the layout the reference's splitter.py writes) and reads it
+    before = os.path.getmtime("cache/golden/bertbase/layer_1.npy")
+    again = build()
+    assert os.path.getmtime("cache/golden/bertbase/layer_1.npy") == before
+    assert torch.equal(again.item_op.hidden_weights, op.hidden_weights)
+    Env.set_lm_cache(False)

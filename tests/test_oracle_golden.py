@@ -130,3 +130,29 @@ def test_bert_news_encoder_full_forward_backward():
     assert len(G) == 45
     for k, v in G.items():
         assert float(np.abs(g[k] - v).max()) <= 1e-4 * float(np.abs(v).max()) + 1e-6 * gscale, k
+
+
+def test_bert_cached_layer_mode_full_forward_backward():
+    """`tune_from = 1` (cached-layer mode, once_operator.py:99-134,182-188): the oracle rebuilds the reference's layer-1
+    cache from the checkpoint the reference loaded, then reproduces its logits / loss / gradients from that cache."""
+    import json
+    z = np.load(os.path.join(GOLDEN, "bert_naml_tune1.npz"))
+    meta, P, G, tables, batch, logits, loss = load_model_fixture("bert_naml_tune1")
+    assert meta["tune_from"] == 1 and meta["layers_kept"] == meta["bert"]["num_hidden_layers"] - 2    # block 1 is skipped too
+    ckpt = {k[len("ckpt::"):]: torch.tensor(z[k]) for k in z.files if k.startswith("ckpt::")}
+    hidden, mask = O.bert_layer_cache(ckpt, torch.tensor(P["embedding_vocab_table.glove.weight"]),
+                                      torch.tensor(P["embedding_vocab_table.category.weight"]), torch.tensor(tables["title_tok"]),
+                                      torch.tensor(tables["title_len"]), torch.tensor(tables["cat"]), layer=1,
+                                      n_layers=meta["bert"]["num_hidden_layers"], heads=meta["heads"],
+                                      eps=meta["bert"]["layer_norm_eps"])
+    assert np.array_equal(mask.numpy(), z["cache::mask"])
+    np.testing.assert_allclose(hidden.numpy(), z["cache::hidden"], rtol=1e-5, atol=2e-6)
+    lg, ls, g = O.loss_and_grads("bert_naml", P, tables, batch["cand"], batch["hist"], batch["hist_len"], heads=meta["heads"],
+                                 frozen=("embedding_vocab_table.glove.weight", "embedding_vocab_table.category.weight"),
+                                 bert_layers=meta["layers_kept"], bert_eps=meta["bert"]["layer_norm_eps"],
+                                 layer_cache=(z["cache::hidden"], z["cache::mask"]))
+    np.testing.assert_allclose(lg, logits, rtol=1e-5, atol=2e-6)
+    assert abs(ls - loss) < 2e-6
+    assert set(G) <= set(g)
+    for k, v in G.items():
+        assert float(np.abs(g[k] - v).max()) <= 2e-4 * max(1e-8, float(np.abs(v).max())) + 1e-9, k

@@ -100,24 +100,30 @@ def test_bert_naml_yaml_resolves():
 
 
 @pytest.mark.gpu
-def test_bert_naml_cli_trains_through_the_plugin_route(tmp_path, monkeypatch):
-    """`trainer.py --model config/model/bert-naml.yaml` end to end: a tiny LOCAL BERT checkpoint (width 768 as the yaml
-    demands, 2 blocks -> tune_from = 0 keeps 1), the plug-in training step, cached evaluation, checkpoint, test."""
+@pytest.mark.parametrize("tune_from", [0, 1])
+def test_bert_naml_cli_trains_through_the_plugin_route(tune_from, tmp_path, monkeypatch):
+    """`trainer.py --model config/model/bert-naml.yaml [--tune_from 1]` end to end: a tiny LOCAL BERT checkpoint (width 768
+    as the yaml demands, 3 blocks -> tune_from = 0 keeps 2; tune_from = 1 caches layer 1 of every item in HBM and keeps 1),
+    the plug-in training step, cached evaluation, checkpoint, test."""
     import torch
     from transformers import BertConfig, BertModel
     from legommenders_amd.trainer import Trainer
     monkeypatch.chdir(tmp_path)
     ck = str(tmp_path / "tiny-bert")
     torch.manual_seed(0)
-    BertModel(BertConfig(vocab_size=5000, hidden_size=768, num_hidden_layers=2, num_attention_heads=12, intermediate_size=128,
+    monkeypatch.setenv("LEGO_LAYER_CACHE_SAVE", "0")
+    BertModel(BertConfig(vocab_size=5000, hidden_size=768, num_hidden_layers=3, num_attention_heads=12, intermediate_size=128,
                          max_position_embeddings=64)).save_pretrained(ck)
     monkeypatch.setenv("LEGO_MODEL_BERTBASE", ck)
     cfg = get_configurations(dict(data="config/data/synthetic-bert.yaml", model="config/model/bert-naml.yaml",
                                   embed="config/embed/bertbase.yaml", batch_size=16, hidden_size=64, lr=0.0005, cuda=0,
-                                  world="small", epoch=1, patience=2, interval=0, epoch_batch=6))
+                                  world="small", epoch=1, patience=2, interval=0, epoch_batch=6, tune_from=tune_from))
     tr = Trainer(cfg)
     assert tr.kind == "plugin" and type(tr.legommender.item_op).__name__ == "BertBaseOperator"
-    assert len(tr.legommender.item_op.transformer.encoder.layer) == 1
+    assert len(tr.legommender.item_op.transformer.encoder.layer) == 3 - 1 - tune_from
+    if tune_from:
+        assert tuple(tr.legommender.item_op.hidden_weights.shape) == (3000, 31, 768)
+        assert tr.legommender.item_op.hidden_weights.is_cuda
     assert "embedding_vocab_table.bert.weight" in tr.legommender.state_dict()      # frozen table, no projection (768 == 768)
     res = tr.run()
     assert set(res) == {"GAUC", "MRR", "NDCG@1", "NDCG@5", "NDCG@10"} and all(np.isfinite(v) for v in res.values())
