@@ -76,8 +76,9 @@ class PluginEvaluator:
     `item_page`), user cache from `item_repr[history]`, then score = <user, item> per evaluation row
     (loader/cacher/*, model/legommender.py:153-157,202-214,282)."""
 
-    def __init__(self, model, data, item_page: int = 512, user_page: int = 512):
+    def __init__(self, model, data, item_page: int = 512, user_page: int = 512, process_group=None, rank=0, world_size=1):
         self.model, self.data, self.item_page, self.user_page = model, data, item_page, user_page
+        self.pg, self.rank, self.world = process_group, rank, world_size
         self.item_repr = self.user_repr = None
 
     @torch.no_grad()
@@ -89,21 +90,25 @@ class PluginEvaluator:
         Env.test()
         m.eval()
         m.item_repr = m.user_repr = None
-        outs = []
-        for s in range(0, d.n_items, self.item_page):
-            ids = torch.arange(s, min(s + self.item_page, d.n_items), device=dev)[:, None]
-            outs.append(m.get_item_content({cm.item_col: ids}, cm.item_col)[:, 0])
-        self.item_repr = torch.cat(outs, 0).contiguous()
+        from legommenders_amd.evaluate import gather_shards, shard_bounds
+
+        def sharded(n, page, encode):                               # this rank's contiguous shard, then one all_gather
+            lo, hi, per = shard_bounds(n, self.rank, self.world)
+            outs = [encode(s, min(s + page, hi)) for s in range(lo, hi, page)]
+            local = torch.cat(outs, 0) if outs else None
+            pad = torch.zeros(per, int(m.config.hidden_size), dtype=torch.float32, device=dev)
+            if local is not None:
+                pad[:hi - lo] = local
+            return gather_shards(pad, n, self.pg, self.world).contiguous()
+
+        self.item_repr = sharded(d.n_items, self.item_page, lambda s, e: m.get_item_content(
+            {cm.item_col: torch.arange(s, e, device=dev)[:, None]}, cm.item_col)[:, 0])
         m.item_repr = self.item_repr
         S = d.S
         ar = torch.arange(S, device=dev)[None]
-        outs = []
         n_users = d.user_hist.shape[0]
-        for s in range(0, n_users, self.user_page):
-            e = min(s + self.user_page, n_users)
-            batch = {cm.history_col: d.user_hist[s:e].long(), cm.mask_col: (ar < d.user_hist_len[s:e, None]).long()}
-            outs.append(m.get_user_content(batch))
-        self.user_repr = torch.cat(outs, 0).contiguous()
+        self.user_repr = sharded(n_users, self.user_page, lambda s, e: m.get_user_content(
+            {cm.history_col: d.user_hist[s:e].long(), cm.mask_col: (ar < d.user_hist_len[s:e, None]).long()}))
         m.item_repr = None                                                    # training must not see a stale cache
         return self.item_repr, self.user_repr
 
@@ -127,6 +132,8 @@ class PluginEvaluator:
         from legommenders_amd import metrics as M
         import numpy as np
         self.build_caches()
+        if self.rank != 0:
+            return {}, None
         s = self.scores(users, items)
         g = np.asarray(users if groups is None else groups)
         return M.calculate_device(s, np.asarray(labels), g, list(metrics)), s.cpu().numpy()

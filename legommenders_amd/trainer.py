@@ -188,12 +188,14 @@ class Trainer:
                                  total_steps=self.steps_per_epoch * int(pol.epoch), warmup=int(pol.n_warmup or 0),
                                  seed=config.seed, process_group=self.pg, world_size=self.world_size)
             self.evaluator = PluginEvaluator(self.legommender, self.data,
-                                             item_page=int(self.legommender.config.cache_page_size or 512))
+                                             item_page=int(self.legommender.config.cache_page_size or 512),
+                                             process_group=self.pg, rank=self.rank, world_size=self.world_size)
         else:
             self.ts = TrainStep(self.kind, params, self.data, self.B, K=self.legommender.neg_count, lr=float(pol.lr),
                                 total_steps=self.steps_per_epoch * int(pol.epoch), warmup=int(pol.n_warmup or 0),
                                 seed=config.seed, heads=heads, glove=glove, process_group=self.pg, world_size=self.world_size)
-            self.evaluator = Evaluator(self.kind, self.ts.fp.P, self.data, heads=heads, glove=glove)
+            self.evaluator = Evaluator(self.kind, self.ts.fp.P, self.data, heads=heads, glove=glove,
+                                       process_group=self.pg, rank=self.rank, world_size=self.world_size)
         if self.exp.load.sign:
             self.load(str(self.exp.load.sign).replace("@", ""))
 
@@ -256,8 +258,8 @@ class Trainer:
             self.log(f"[epoch {epoch}] train loss {float(run) / max(n, 1):.4f}  "
                      f"{n * self.B * self.world_size / dt:.0f} impressions/s ({self.world_size} GPU)")
             action = "skip"
+            res = self.evaluate("valid", [store.metric])       # every rank: the cache build is sharded (evaluate.py)
             if self.rank == 0:
-                res = self.evaluate("valid", [store.metric])
                 self.log(f"[epoch {epoch}] " + " ".join(f"{k} {v:.4f}" for k, v in res.items()))
                 action = monitor.push(res[store.metric])
                 if action == "best":
@@ -272,9 +274,9 @@ class Trainer:
         self.log("Training Ended")
 
     def test(self):
+        res = self.evaluate("test", list(self.exp.metrics() or ["GAUC"]))
         if self.rank != 0:
             return {}
-        res = self.evaluate("test", list(self.exp.metrics() or ["GAUC"]))
         self.log("[test] " + " ".join(f"{k} {v:.4f}" for k, v in res.items()))
         with open(os.path.join(self.ckpt_dir, self.signature + ".csv"), "w") as f:
             f.write(",".join(res.keys()) + "\n" + ",".join(f"{v:.6f}" for v in res.values()) + "\n")
@@ -282,8 +284,10 @@ class Trainer:
 
     def run(self):
         self.train()
-        if self.rank == 0 and os.path.exists(os.path.join(self.ckpt_dir, self.signature + ".pt")):
-            self.load(self.signature)
+        if self.world_size > 1:
+            torch.distributed.barrier()                        # rank 0 may still be writing the best checkpoint
+        if os.path.exists(os.path.join(self.ckpt_dir, self.signature + ".pt")):
+            self.load(self.signature)                          # every rank: the test caches are built from all shards
         out = self.test()
         if self.world_size > 1:
             torch.distributed.barrier()

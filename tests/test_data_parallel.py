@@ -78,3 +78,28 @@ def test_linear_schedule_matches_oracle():
     ts.total_steps, ts.warmup = 20, 5
     for step in range(22):
         assert abs(ts.lr_at(step) - 1e-3 * O.linear_schedule_factor(step, 20, 5)) < 1e-12
+
+
+def _eval_shard_worker(rank, world, port, out_dir):
+    from legommenders_amd.evaluate import gather_shards, shard_bounds
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    n, D = 11, 3                                                          # 11 rows over 2 ranks: shards of 6 and 5
+    full = torch.arange(n * D, dtype=torch.float32).view(n, D)
+    lo, hi, per = shard_bounds(n, rank, world)
+    local = torch.zeros(per, D)
+    local[:hi - lo] = full[lo:hi]                                         # what this rank "encoded"
+    got = gather_shards(local, n, dist.group.WORLD, world)
+    assert torch.equal(got, full), (rank, got)
+    dist.destroy_process_group()
+
+
+def test_eval_cache_shards_gather_to_the_whole_table():
+    """evaluation caches: contiguous per-rank shards + one all_gather == the whole table on every rank"""
+    from legommenders_amd.evaluate import shard_bounds
+    for n in (0, 1, 7, 64, 65238, 91935):
+        for world in (1, 2, 3, 8):
+            b = [shard_bounds(n, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            assert all(hi - lo <= per for lo, hi, per in b) and len({per for _, _, per in b}) == 1
+    world, port = 2, _free_port()
+    mp.spawn(_eval_shard_worker, args=(world, port, ""), nprocs=world, join=True)

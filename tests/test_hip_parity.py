@@ -697,3 +697,31 @@ def test_headline_size_oracle_and_properties(kind):
         _close(s5.cpu(), scores.cpu().numpy()[sl], rtol=2e-6, atol=2e-6, what="half-batch logits")
         acc = G5 if acc is None else {k: acc[k] + G5[k] for k in acc}
     _grads_close({k: v * 0.5 for k, v in acc.items()}, Gn, "two half batches")
+
+
+def test_eval_caches_through_the_collective_path():
+    """The sharded cache build with its all_gather (RCCL, a one-rank group here: one GPU per box) gives the same caches
+    as the plain build (the two-rank tiling of the shards is covered on gloo in tests/test_data_parallel.py)."""
+    import socket
+    import torch.distributed as dist
+    from legommenders_amd.evaluate import Evaluator
+    from legommenders_amd.train_step import DeviceData
+    dev = _dev()
+    meta, P, G, tables, batch, _, _ = load_model_fixture("naml_glove_d64")
+    n_items, n_users = tables["title_tok"].shape[0], tables["user_hist"].shape[0]
+    world = dict(title_tok=tables["title_tok"], title_len=tables["title_len"], cat=tables["cat"],
+                 user_hist=tables["user_hist"], user_hist_len=tables["user_hist_len"],
+                 neg_list=np.zeros((n_users, 4), dtype=np.int64), neg_len=np.zeros(n_users, dtype=np.int64),
+                 row_user=np.zeros(4, dtype=np.int64), row_item=np.zeros(4, dtype=np.int64))
+    data = DeviceData(world, dev)
+    Pd = {k: torch.tensor(v).to(dev).contiguous() for k, v in P.items()}
+    plain = Evaluator("naml", Pd, data, item_page=50, user_page=16)
+    item_ref, user_ref = [t.clone() for t in plain.build_caches()]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        ev = Evaluator("naml", Pd, data, item_page=50, user_page=16, process_group=dist.group.WORLD, rank=0, world_size=1)
+        item, user = ev.build_caches()
+        assert torch.equal(item, item_ref) and torch.equal(user, user_ref)
+    finally:
+        dist.destroy_process_group()
