@@ -15,9 +15,10 @@ from .engine import _ptr, _stream
 
 class PluginStep:
     def __init__(self, model, data, B: int, K: int = 4, lr: float = 1e-3, total_steps: int = 0, warmup: int = 0,
-                 seed: int = 2023, process_group=None, world_size: int = 1):
+                 seed: int = 2023, process_group=None, world_size: int = 1, accumulate: int = 1):
         from legommenders_amd.loader.env import Env
         self.model, self.data, self.B, self.K, self.C = model, data, B, K, K + 1
+        self.accumulate, self._acc, self.batch_idx = max(1, int(accumulate)), 0, 0     # trainer.py:171,197-203
         dev = data.tables.title_tok.device
         i32 = dict(dtype=torch.int32, device=dev)
         self.cand = torch.zeros(B, self.C, **i32)
@@ -41,10 +42,10 @@ class PluginStep:
 
     def sample_batch(self):
         d, B = self.data, self.B
-        start = (self.step_idx * B) % max(1, d.n_rows - B + 1)
+        start = (self.batch_idx * B) % max(1, d.n_rows - B + 1)
         ru, ri = _ptr(d.row_user, start), _ptr(d.row_item, start)
         call("lego_sample_negatives", ru, ri, _ptr(d.neg_list), _ptr(d.neg_len), d.neg_cap, B, self.K, d.n_items,
-             self.seed, self.step_idx, _ptr(self.cand), _stream())
+             self.seed, self.batch_idx, _ptr(self.cand), _stream())
         call("lego_gather_history", ru, _ptr(d.user_hist), _ptr(d.user_hist_len), B, d.S, _ptr(self.hist),
              _ptr(self.hist_len), _stream())
 
@@ -55,9 +56,15 @@ class PluginStep:
                  cm.mask_col: (self.ar < self.hist_len[:, None]).long()}
         self.Env.train()
         self.model.train()
-        self.opt.zero_grad(set_to_none=True)
+        if self._acc == 0:
+            self.opt.zero_grad(set_to_none=True)
         loss = self.model(batch=batch)
         loss.backward()
+        self.batch_idx += 1
+        self._acc += 1
+        if self._acc < self.accumulate:                                      # gradients add up over the cycle
+            return loss.detach().reshape(1)
+        self._acc = 0
         if self.world > 1:                                                   # one all-reduce of the flattened gradients
             grads = [p.grad for p in self.params if p.grad is not None]
             flat = torch._utils._flatten_dense_tensors(grads)

@@ -81,7 +81,7 @@ class TrainStep:
     def __init__(self, kind: str, params: Dict[str, torch.Tensor], data: DeviceData, B: int, K: int = 4,
                  lr: float = 1e-3, total_steps: int = 0, warmup: int = 0, seed: int = 2023, heads: int = 8,
                  glove: bool = True, process_group=None, world_size: int = 1, dropout: bool = True, micro: int = 1,
-                 force_allreduce: bool = False):
+                 force_allreduce: bool = False, accumulate: int = 1):
         dev = data.tables.title_tok.device
         self.data, self.B, self.C, self.K = data, B, K + 1, K
         frozen = ("embedding_vocab_table.glove.embedding.weight",) if "embedding_vocab_table.glove.embedding.weight" in params else ()
@@ -128,6 +128,10 @@ class TrainStep:
             self._planned_step = -1
         self.lr, self.total_steps, self.warmup = lr, total_steps, warmup
         self.seed, self.step_idx = seed, 0
+        # `accumulate` batches per optimiser step (exp.policy.accumulate_batch, trainer.py:171,197-203): gradients of the
+        # batch-mean losses ADD UP over the cycle (no 1/accumulate), then one all-reduce + Adam + scheduler step.
+        # batch_idx counts batches (sampling, plan slots, dropout streams), step_idx optimiser steps (Adam bias, lr).
+        self.accumulate, self._acc, self.batch_idx = max(1, int(accumulate)), 0, 0
         self.pg, self.world = process_group, world_size
         self.force_allreduce = force_allreduce
         self.counter_sum = torch.zeros(8, dtype=torch.int64, device=dev)
@@ -144,7 +148,7 @@ class TrainStep:
     def sample_batch(self, step_idx=None, slot=0, stream=None):
         """Resampler.rebuild on device for training step `step_idx` into batch slot `slot`"""
         d, B = self.data, self.B
-        step_idx = self.step_idx if step_idx is None else step_idx
+        step_idx = self.batch_idx if step_idx is None else step_idx
         start = (step_idx * B) % max(1, d.n_rows - B + 1)
         st = _stream() if stream is None else ctypes.c_void_p(stream.cuda_stream)
         ru, ri = _ptr(d.row_user, start), _ptr(d.row_item, start)
@@ -171,16 +175,17 @@ class TrainStep:
 
     def step(self):
         """sample -> forward -> backward -> all-reduce -> Adam.  Returns the device loss tensor (no sync)."""
-        slot = self.step_idx % 2 if self.prefetch else 0
+        slot = self.batch_idx % 2 if self.prefetch else 0
         self.cand, self.hist, self.hist_len = self._cand[slot], self._hist[slot], self._hist_len[slot]
+        last_of_cycle = self._acc + 1 == self.accumulate
         if self.prefetch:
-            if self._planned_step != self.step_idx:
-                self._prefetch(self.step_idx)
+            if self._planned_step != self.batch_idx:
+                self._prefetch(self.batch_idx)
             torch.cuda.current_stream().wait_event(self._ready[slot])
             self.engine.use_slot(slot)
         else:
             self.sample_batch()
-        if not self._grad_clean:
+        if self._acc == 0 and not self._grad_clean:
             self.fp.grad.zero_()
         if self.micro == 1:
             go = neck = None
@@ -190,8 +195,8 @@ class TrainStep:
             _, loss = self.engine.forward(self.cand, self.hist, self.hist_len, training=True, planned=self.prefetch,
                                           fork_ev=go, neck_ev=neck)
             if self.prefetch:
-                self._prefetch(self.step_idx + 1, neck)        # next batch: starts where this step's item tower ends
-            dist_on = self.world > 1 or self.force_allreduce
+                self._prefetch(self.batch_idx + 1, neck)       # next batch: starts where this step's item tower ends
+            dist_on = (self.world > 1 or self.force_allreduce) and last_of_cycle
             early = None
             if dist_on and self.fp.split > 0 and os.environ.get("LEGO_AR_BUCKETS", "1") == "2":
                 def early():       # everything but the projection weight gradient: overlaps the last backward GEMM
@@ -218,6 +223,14 @@ class TrainStep:
                 main.wait_stream(st)
             loss = self.loss
             torch.mean(torch.stack([e.loss for e in self.engines]), dim=0, out=self.loss)
+        self.batch_idx += 1
+        if not self.prefetch:
+            for e in self.engines:
+                self.counter_sum += e.counters
+        if not last_of_cycle:                          # gradients stay in the flat buffer for the next batch of the cycle
+            self._acc += 1
+            return loss
+        self._acc = 0
         if self.world > 1 or self.force_allreduce:
             if getattr(self, "_work", None) is not None:
                 torch.distributed.all_reduce(self.fp.grad[self.fp.split:], group=self.pg)   # the late tail (same RCCL stream:
@@ -229,7 +242,4 @@ class TrainStep:
         call("lego_adam_step", _ptr(self.fp.flat), _ptr(self.fp.grad), _ptr(self.fp.m), _ptr(self.fp.v),
              self.fp.numel, self.lr_at(self.step_idx - 1), 0.9, 0.999, 1e-8, self.step_idx, 1.0 / self.world, 1, _stream())
         self._grad_clean = True                    # Adam cleared the gradient buffer as it consumed it
-        if not self.prefetch:
-            for e in self.engines:
-                self.counter_sum += e.counters
         return loss

@@ -179,6 +179,8 @@ class Trainer:
         pol = self.exp.policy
         self.B = int(pol.batch_size)
         self.steps_per_epoch = self.data.n_rows // self.B
+        accumulate = int(pol.accumulate_batch or 1)                       # trainer.py:171
+        Env.simple_dev = bool(pol.simple_dev)                            # base_lego.py:121
         params = {k: v.detach() for k, v in self.legommender.state_dict().items()}
         glove = any(k.endswith("glove.embedding.weight") for k in params)
         heads = getattr(self.legommender.item_op.config, "num_attention_heads", 8)
@@ -186,14 +188,16 @@ class Trainer:
             from legommenders_amd.plugin_step import PluginEvaluator, PluginStep
             self.ts = PluginStep(self.legommender, self.data, self.B, K=self.legommender.neg_count, lr=float(pol.lr),
                                  total_steps=self.steps_per_epoch * int(pol.epoch), warmup=int(pol.n_warmup or 0),
-                                 seed=config.seed, process_group=self.pg, world_size=self.world_size)
+                                 seed=config.seed, process_group=self.pg, world_size=self.world_size, accumulate=accumulate)
             self.evaluator = PluginEvaluator(self.legommender, self.data,
                                              item_page=int(self.legommender.config.cache_page_size or 512),
                                              process_group=self.pg, rank=self.rank, world_size=self.world_size)
         else:
             self.ts = TrainStep(self.kind, params, self.data, self.B, K=self.legommender.neg_count, lr=float(pol.lr),
                                 total_steps=self.steps_per_epoch * int(pol.epoch), warmup=int(pol.n_warmup or 0),
-                                seed=config.seed, heads=heads, glove=glove, process_group=self.pg, world_size=self.world_size)
+                                seed=config.seed, heads=heads, glove=glove, process_group=self.pg, world_size=self.world_size,
+                                accumulate=accumulate)
+            self._heads, self._glove = heads, glove
             self.evaluator = Evaluator(self.kind, self.ts.fp.P, self.data, heads=heads, glove=glove,
                                        process_group=self.pg, rank=self.rank, world_size=self.world_size)
         if self.exp.load.sign:
@@ -234,10 +238,56 @@ class Trainer:
         res, _ = self.evaluator.evaluate(rows["user"], rows["item"], rows["label"], metrics=metrics)
         return res
 
+    def simple_evaluate(self):
+        """`--simple_dev true` (trainer.py:126-140, manager.py:331-346, resampler.py:159-171): the dev rows with label 1,
+        K sampled negatives each, the training loss in eval mode (no dropout); mean of the batch means, a short last
+        batch included.  Runs on rank 0 (no collective inside)."""
+        import ctypes
+        from legommenders_amd._lib import call
+        from legommenders_amd.engine import NamlEngine, NrmsEngine, _ptr, _stream
+        from legommenders_amd.loader.env import Env
+        rows = self.world["valid"]
+        pos = np.asarray(rows["label"]) == 1
+        dev, d = self.device, self.data
+        users = torch.as_tensor(np.asarray(rows["user"])[pos]).to(dev, torch.int32).contiguous()
+        items = torch.as_tensor(np.asarray(rows["item"])[pos]).to(dev, torch.int32).contiguous()
+        K, C, S = self.legommender.neg_count, self.legommender.neg_count + 1, d.S
+        if not hasattr(self, "_dev_engines"):
+            self._dev_engines = {}
+        total = torch.zeros((), dtype=torch.float32, device=dev)
+        n_batches = 0
+        for bi, s in enumerate(range(0, users.numel(), self.B)):
+            b = min(self.B, users.numel() - s)
+            cand = torch.empty(b, C, dtype=torch.int32, device=dev)
+            hist = torch.empty(b, S, dtype=torch.int32, device=dev)
+            hist_len = torch.empty(b, dtype=torch.int32, device=dev)
+            call("lego_sample_negatives", _ptr(users, s), _ptr(items, s), _ptr(d.neg_list), _ptr(d.neg_len), d.neg_cap, b, K,
+                 d.n_items, int(self.config.seed) + 1, bi, _ptr(cand), _stream())
+            call("lego_gather_history", _ptr(users, s), _ptr(d.user_hist), _ptr(d.user_hist_len), b, S, _ptr(hist),
+                 _ptr(hist_len), _stream())
+            if self.kind == "plugin":
+                cm = self.legommender.cm
+                Env.dev()
+                self.legommender.eval()
+                with torch.no_grad():
+                    loss = self.legommender(batch={cm.item_col: cand.long(), cm.history_col: hist.long(),
+                                                   cm.mask_col: (torch.arange(S, device=dev)[None] < hist_len[:, None]).long()})
+            else:
+                if b not in self._dev_engines:
+                    P = self.ts.fp.P
+                    self._dev_engines[b] = NamlEngine(P, d.tables, b, C, S, p_proj=0.0, p_conv=0.0) if self.kind == "naml" else \
+                        NrmsEngine(P, d.tables, b, C, S, heads=self._heads, glove=self._glove, p_proj=0.0, p_att=0.0)
+                _, loss = self._dev_engines[b].forward(cand, hist, hist_len, training=False)
+            total += loss.reshape(())
+            n_batches += 1
+        return {"loss": float(total) / max(n_batches, 1)}
+
     def train(self):
         from legommenders_amd import metrics as M
+        from legommenders_amd.loader.env import Env
         pol, store = self.exp.policy, self.exp.store
-        monitor = Monitor(patience=int(store.patience), minimize=M.is_minimize(store.metric))
+        simple = bool(Env.simple_dev)
+        monitor = Monitor(patience=int(store.patience), minimize=simple or M.is_minimize(store.metric))
         interval = int(pol.check_interval or 0)
         if interval < 0:
             interval = max(self.steps_per_epoch // (-interval), 1)
@@ -258,10 +308,13 @@ class Trainer:
             self.log(f"[epoch {epoch}] train loss {float(run) / max(n, 1):.4f}  "
                      f"{n * self.B * self.world_size / dt:.0f} impressions/s ({self.world_size} GPU)")
             action = "skip"
-            res = self.evaluate("valid", [store.metric])       # every rank: the cache build is sharded (evaluate.py)
+            if simple:
+                res = self.simple_evaluate() if self.rank == 0 else {}
+            else:
+                res = self.evaluate("valid", [store.metric])   # every rank: the cache build is sharded (evaluate.py)
             if self.rank == 0:
                 self.log(f"[epoch {epoch}] " + " ".join(f"{k} {v:.4f}" for k, v in res.items()))
-                action = monitor.push(res[store.metric])
+                action = monitor.push(res["loss" if simple else store.metric])
                 if action == "best":
                     self.save()
             if self.world_size > 1:

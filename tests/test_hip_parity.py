@@ -725,3 +725,44 @@ def test_eval_caches_through_the_collective_path():
         assert torch.equal(item, item_ref) and torch.equal(user, user_ref)
     finally:
         dist.destroy_process_group()
+
+
+def test_gradient_accumulation_cycle(monkeypatch):
+    """`exp.policy.accumulate_batch = 2` (trainer.py:171,197-203): the first batch of a cycle leaves the parameters alone,
+    the second triggers ONE Adam step on the SUM of the two batch gradients (no 1/accumulate), batches keep advancing."""
+    from legommenders_amd import train_step as TS
+    from legommenders_amd.engine import NamlEngine
+    from legommenders_amd.synthetic import glove_like, init_naml_params, make_world
+    dev = _dev()
+    w = make_world(seed=11, n_items=800, n_users=300, n_rows=600, V=2000)
+    P0 = init_naml_params(D=64, V=2000, n_cat=w["n_cat"], glove=glove_like(2000, 300, seed=12, device=dev))
+    data = TS.DeviceData(w, dev)
+    ts = TS.TrainStep("naml", {k: v.clone() for k, v in P0.items()}, data, 16, dropout=False, accumulate=2)
+    seen = []
+    orig = TS.call
+
+    def spy(name, *a):
+        if name == "lego_adam_step":
+            seen.append(ts.fp.grad.clone())
+        return orig(name, *a)
+    monkeypatch.setattr(TS, "call", spy)
+    before = ts.fp.flat.clone()
+    ts.step()
+    torch.cuda.synchronize()
+    assert not seen and torch.equal(ts.fp.flat, before) and (ts.step_idx, ts.batch_idx) == (0, 1)
+    ts.step()
+    torch.cuda.synchronize()
+    assert len(seen) == 1 and not torch.equal(ts.fp.flat, before) and (ts.step_idx, ts.batch_idx) == (1, 2)
+    assert float(ts.fp.grad.abs().max()) == 0.0                       # Adam cleared the buffer for the next cycle
+    # the same two batches, one after the other, through a plain engine: gradients add up
+    ref = TS.TrainStep("naml", {k: v.clone() for k, v in P0.items()}, data, 16, dropout=False)
+    eng = NamlEngine(ref.fp.P, data.tables, 16, 5, data.S, p_proj=0.0, p_conv=0.0)
+    G = eng.grads_like()
+    for b in range(2):
+        ref.sample_batch(b, 0)
+        torch.cuda.synchronize()
+        eng.forward(ref._cand[0], ref._hist[0], ref._hist_len[0], training=False)
+        eng.backward(G)
+    torch.cuda.synchronize()
+    got = {k: seen[0][ts.fp.offsets[k]:ts.fp.offsets[k] + g.numel()].view_as(g) for k, g in ts.fp.G.items()}
+    _grads_close({k: got[k] for k in G}, {k: v.cpu().numpy() for k, v in G.items()}, "accumulated gradient")

@@ -180,3 +180,24 @@ def test_tester_restores_checkpoint_and_times_scoring(tmp_path, monkeypatch):
     te = tester.Tester(tester.get_configurations(dict(common, load_sign=tr.signature, latency=True, num_batches=20)))
     st = te.run()
     assert st.count == 20 and 0.0 < st.avgms() < 50.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,embed", [("naml", "glove"), ("nrms", "null")])
+def test_simple_dev_and_accumulate_batch_flags(model, embed, tmp_path, monkeypatch):
+    """`--simple_dev true` monitors the eval-mode training loss of the positive dev rows (minimised) instead of a ranking
+    metric; `accumulate_batch 2` takes one optimiser step per two batches (trainer.py:126-140,164-171,197-203)."""
+    from legommenders_amd.trainer import Trainer
+    monkeypatch.chdir(tmp_path)
+    cfg = get_configurations(dict(data="config/data/synthetic.yaml", model=f"config/model/{model}.yaml",
+                                  embed=f"config/embed/{embed}.yaml", batch_size=32, hidden_size=64, lr=0.001, cuda=0,
+                                  world="small", epoch=2, patience=2, interval=0, simple_dev=True, accumulate_batch=2))
+    tr = Trainer(cfg)
+    assert tr.ts.accumulate == 2
+    first = tr.simple_evaluate()["loss"]
+    assert 1.2 < first < 2.2                                     # ~log(5) for an untrained model
+    res = tr.run()
+    assert tr.ts.batch_idx == 2 * tr.steps_per_epoch and tr.ts.step_idx == tr.steps_per_epoch
+    log = open(os.path.join("checkpoints", "synthetic", cfg.model.name, tr.signature + ".log")).read()
+    assert "[epoch 0] loss " in log and any(l.startswith("[test] GAUC") for l in log.splitlines())
+    assert set(res) == {"GAUC", "MRR", "NDCG@1", "NDCG@5", "NDCG@10"}
