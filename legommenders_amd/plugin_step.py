@@ -15,7 +15,7 @@ from .engine import _ptr, _stream
 
 class PluginStep:
     def __init__(self, model, data, B: int, K: int = 4, lr: float = 1e-3, total_steps: int = 0, warmup: int = 0,
-                 seed: int = 2023, process_group=None, world_size: int = 1, accumulate: int = 1):
+                 seed: int = 2023, process_group=None, world_size: int = 1, accumulate: int = 1, item_lr=None):
         from legommenders_amd.loader.env import Env
         self.model, self.data, self.B, self.K, self.C = model, data, B, K, K + 1
         self.accumulate, self._acc, self.batch_idx = max(1, int(accumulate)), 0, 0     # trainer.py:171,197-203
@@ -26,7 +26,11 @@ class PluginStep:
         self.hist_len = torch.zeros(B, **i32)
         self.ar = torch.arange(data.S, device=dev)[None]
         self.params = [p for p in model.parameters() if p.requires_grad]
-        self.opt = torch.optim.Adam(self.params, lr=lr)                     # base_lego.py:201-204 (defaults)
+        if model.config.use_item_content and item_lr:                        # base_lego.py:183-197: pretrained encoder vs the rest
+            pretrained, other = model.get_parameters()
+            self.opt = torch.optim.Adam([{"params": pretrained, "lr": float(item_lr)}, {"params": other, "lr": lr}])
+        else:
+            self.opt = torch.optim.Adam(self.params, lr=lr)                 # base_lego.py:201-204 (defaults)
         self.total_steps, self.warmup = total_steps, warmup
 
         def factor(step):                                                    # HF get_linear_schedule_with_warmup

@@ -188,7 +188,8 @@ class Trainer:
             from legommenders_amd.plugin_step import PluginEvaluator, PluginStep
             self.ts = PluginStep(self.legommender, self.data, self.B, K=self.legommender.neg_count, lr=float(pol.lr),
                                  total_steps=self.steps_per_epoch * int(pol.epoch), warmup=int(pol.n_warmup or 0),
-                                 seed=config.seed, process_group=self.pg, world_size=self.world_size, accumulate=accumulate)
+                                 seed=config.seed, process_group=self.pg, world_size=self.world_size, accumulate=accumulate,
+                                 item_lr=pol.item_lr)
             self.evaluator = PluginEvaluator(self.legommender, self.data,
                                              item_page=int(self.legommender.config.cache_page_size or 512),
                                              process_group=self.pg, rank=self.rank, world_size=self.world_size)

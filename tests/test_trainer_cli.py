@@ -117,8 +117,12 @@ def test_bert_naml_cli_trains_through_the_plugin_route(tune_from, tmp_path, monk
     monkeypatch.setenv("LEGO_MODEL_BERTBASE", ck)
     cfg = get_configurations(dict(data="config/data/synthetic-bert.yaml", model="config/model/bert-naml.yaml",
                                   embed="config/embed/bertbase.yaml", batch_size=16, hidden_size=64, lr=0.0005, cuda=0,
-                                  world="small", epoch=1, patience=2, interval=0, epoch_batch=6, tune_from=tune_from))
+                                  world="small", epoch=1, patience=2, interval=0, epoch_batch=6, tune_from=tune_from,
+                                  item_lr=0.00001))
     tr = Trainer(cfg)
+    groups = tr.ts.opt.param_groups                                  # base_lego.py:183-197: transformer at item_lr, rest at lr
+    assert [g["initial_lr"] for g in groups] == [0.00001, 0.0005]
+    assert sum(p.numel() for p in groups[0]["params"]) == sum(p.numel() for p in tr.legommender.item_op.transformer.parameters())
     assert tr.kind == "plugin" and type(tr.legommender.item_op).__name__ == "BertBaseOperator"
     assert len(tr.legommender.item_op.transformer.encoder.layer) == 3 - 1 - tune_from
     if tune_from:
