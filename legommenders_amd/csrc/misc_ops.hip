@@ -354,6 +354,40 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     if (ry == 0 && c < N) atomicAdd(out + c, (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
 }
 
+// the same sums with 16-B loads: block = 64 float4 columns (256 columns) x 4 row lanes, 256 rows per block, four rows in
+// flight per lane (the dword version above moved 1.7 TB/s on the 30 k x 768 QKV gradient of NRMS)
+__global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ x, int ldx, int M_cap,
+                                                      const int* __restrict__ M_dyn, const int* __restrict__ off_dyn,
+                                                      int N, float* out) {
+    __shared__ f32x4 part[4][64];
+    const int M = M_dyn != nullptr ? min(M_cap, *M_dyn) : M_cap;
+    const int off = off_dyn != nullptr ? *off_dyn : 0;
+    const int lane = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 4;
+    const int r0 = blockIdx.y * 256;
+    if (r0 >= M) return;
+    const int r_end = min(M, r0 + 256);
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (c < N) {
+        const float* p = x + (size_t)off * ldx + c;
+        int r = r0 + ry;
+        for (; r + 12 < r_end; r += 16) {
+            s0 += *reinterpret_cast<const f32x4*>(p + (size_t)r * ldx);
+            s1 += *reinterpret_cast<const f32x4*>(p + (size_t)(r + 4) * ldx);
+            s2 += *reinterpret_cast<const f32x4*>(p + (size_t)(r + 8) * ldx);
+            s3 += *reinterpret_cast<const f32x4*>(p + (size_t)(r + 12) * ldx);
+        }
+        for (; r < r_end; r += 4) s0 += *reinterpret_cast<const f32x4*>(p + (size_t)r * ldx);
+    }
+    part[ry][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ry == 0 && c < N) {
+        const f32x4 t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(out + c + i, t[i]);
+    }
+}
+
 __global__ void conv3_pack_kernel(const float* __restrict__ w, float* __restrict__ wt, int Dout, int Din) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;      // over [tap][o][c]
     const int per = Dout * Din;
@@ -1042,6 +1076,11 @@ extern "C" int lego_gather_i32(const int32_t* table, const int32_t* idx, int n_c
 extern "C" int lego_colsum(const float* x, int ldx, int M_cap, const int32_t* M_dyn, const int32_t* row_off_dyn,
                            int N, float* out, void* stream) {
     if (M_cap <= 0) return 0;
+    if ((N & 3) == 0 && (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        hipLaunchKernelGGL(colsum4_kernel, dim3((N + 255) / 256, (M_cap + 255) / 256), dim3(256), 0, ST, x, ldx, M_cap, M_dyn,
+                           row_off_dyn, N, out);
+        return check_launch("lego_colsum");
+    }
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, (M_cap + 255) / 256), dim3(256), 0, ST, x, ldx, M_cap, M_dyn, row_off_dyn, N, out);
     return check_launch("lego_colsum");
 }

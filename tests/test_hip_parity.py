@@ -766,3 +766,21 @@ def test_gradient_accumulation_cycle(monkeypatch):
     torch.cuda.synchronize()
     got = {k: seen[0][ts.fp.offsets[k]:ts.fp.offsets[k] + g.numel()].view_as(g) for k, g in ts.fp.G.items()}
     _grads_close({k: got[k] for k in G}, {k: v.cpu().numpy() for k, v in G.items()}, "accumulated gradient")
+
+
+@pytest.mark.parametrize("N,ld", [(768, 768), (256, 260), (100, 100), (30, 31)])
+def test_colsum_matches_torch(N, ld):
+    """`lego_colsum` (bias gradients): 16-B-load kernel for aligned shapes, dword kernel otherwise; device row count and
+    row offset, accumulation into the destination."""
+    from legommenders_amd._lib import call
+    from legommenders_amd.engine import _ptr, _stream
+    dev = _dev()
+    torch.manual_seed(N)
+    M_cap, M, off = 3000, 2345, 17
+    x = torch.randn(M_cap + off, ld, device=dev)
+    out = torch.full((N,), 0.5, device=dev)
+    m_dyn = torch.tensor([M], dtype=torch.int32, device=dev)
+    off_dyn = torch.tensor([off], dtype=torch.int32, device=dev)
+    call("lego_colsum", _ptr(x), ld, M_cap, _ptr(m_dyn), _ptr(off_dyn), N, _ptr(out), _stream())
+    ref = 0.5 + x[off:off + M, :N].double().sum(0)
+    _close(out.cpu(), ref.cpu().numpy(), rtol=2e-6, atol=1e-4, what=f"colsum N={N}")
