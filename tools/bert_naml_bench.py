@@ -2,7 +2,7 @@
 MI355X: `Legommender.forward` + backward + torch Adam on a MIND-small-shaped synthetic world, random-init BERT-base
 (no pretrained weights offline; tune_from = 0 -> 11 of the 12 blocks run, as in the reference).
 
-    python tools/bert_naml_bench.py [--batch 64] [--steps 5] [--layers 12] [--hidden 256]
+    python tools/bert_naml_bench.py [--batch 64] [--steps 5] [--layers 12] [--hidden 256] [--tune_from 9]
 The transformer runs through PyTorch-ROCm; the table gather, Linear(768 -> D), additive pools, dot + CE are the path's kernels."""
 import argparse, os, sys, time
 import numpy as np
@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--tune_from", type=int, default=0, help="k > 0: cached-layer mode, blocks [k+1:] train on the HBM-resident layer-k cache")
     a = ap.parse_args()
     from legommenders_amd.engine import ItemTables
     from legommenders_amd.loader.class_hub import ClassHub
@@ -44,7 +45,7 @@ def main():
     ops, preds = ClassHub.operators(), ClassHub.predictors()
     lc = LegoConfig(hidden_size=D, item_hidden_size=H, neg_count=4,
                     user_config={"inputer_config": {"use_cls_token": False, "use_sep_token": False}},
-                    item_config={"tune_from": 0, "use_lora": False, "lora_r": None, "lora_alpha": None,
+                    item_config={"tune_from": a.tune_from, "use_lora": False, "lora_r": None, "lora_alpha": None,
                                  "inputer_config": {"use_cls_token": False, "use_sep_token": False}, "transformer_config": bert})
     lc.set_component_classes(ops["BertBase"], ops["Ada"], preds["Dot"])
     lc.set_item_ut(item_ut, ["title@bert", "category"])
@@ -58,8 +59,12 @@ def main():
     lc.set_embedding_hub(eh)
     lc.build_components()
     lc.register_inputer_vocabs()
+    os.environ.setdefault("LEGO_LAYER_CACHE_SAVE", "0")
     model = Legommender(lc).to(dev)
+    t_cache = time.perf_counter()
     model.attach_item_table(ItemTables(w["title_tok"], w["title_len"], w["cat"], dev))
+    torch.cuda.synchronize()
+    t_cache = time.perf_counter() - t_cache
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
     B, S = a.batch, 50
     rs = np.random.RandomState(0)
@@ -87,7 +92,9 @@ def main():
     dt = (time.perf_counter() - t0) / a.steps
     n_par = sum(p.numel() for p in model.parameters() if p.requires_grad)
     print({"model": "BERT-NAML plug-in route", "batch": B, "bert_layers_run": len(model.item_op.transformer.encoder.layer),
-           "trainable_params": n_par, "s_per_step": round(dt, 4), "impressions_per_s": round(B / dt, 1), "loss": float(loss.detach())})
+           "trainable_params": n_par, "s_per_step": round(dt, 4), "impressions_per_s": round(B / dt, 1), "loss": float(loss.detach()),
+           "tune_from": a.tune_from, "layer_cache_s": round(t_cache, 3) if a.tune_from else None,
+           "layer_cache_GB": round(model.item_op.hidden_weights.numel() * 4 / 1e9, 3) if a.tune_from else None})
 
 
 if __name__ == "__main__":
