@@ -289,36 +289,43 @@ constexpr int kSmallChunk = 16;
 __global__ __launch_bounds__(256) void scatter_add_small_kernel(float* grad_table, int ld_table, int width, int table_rows,
                                                                 const int* __restrict__ idx, int rows_cap,
                                                                 const int* __restrict__ rows_dyn,
-                                                                const float* __restrict__ g, int ld_g) {
+                                                                const float* __restrict__ g, int ld_g, int iters) {
     __shared__ float tab[kSmallTableRows][256];
     __shared__ int touched[kSmallTableRows];
     const int rows = rows_dyn != nullptr ? min(rows_cap, *rows_dyn) : rows_cap;
-    const int r0 = blockIdx.x * kSmallChunk;
-    if (r0 >= rows) return;
+    // a workgroup folds `iters` chunks of 16 rows into its LDS image before it touches memory (the host picks `iters`
+    // so that a long row range -- NRMS's ~50 k token rows, most of them not in this table -- still gives ~500 workgroups:
+    // one LDS clear, one barrier pair and one round of global atomics per 16 rows was most of the kernel there)
+    const int first = blockIdx.x * iters * kSmallChunk;
+    if (first >= rows) return;
     const int c0 = blockIdx.y * 256;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int t[4];
-    float v[4][4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {                      // all 16 loads of the wave are in flight before the first use
-        const int r = r0 + wave * 4 + u;
-        t[u] = r < rows ? idx[r] : -1;
-        if (t[u] >= table_rows) t[u] = -1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = c0 + lane + 64 * i;
-            v[u][i] = (t[u] >= 0 && c < width) ? g[(size_t)r * ld_g + c] : 0.f;
-        }
-    }
     for (int e = threadIdx.x; e < table_rows * 256; e += 256) (&tab[0][0])[e] = 0.f;
     if (threadIdx.x < kSmallTableRows) touched[threadIdx.x] = 0;
     __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+        const int r0 = first + it * kSmallChunk;
+        if (r0 >= rows) break;
+        int t[4];
+        float v[4][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        if (t[u] < 0) continue;                        // wave-uniform
-        if (lane == 0) touched[t[u]] = 1;
+        for (int u = 0; u < 4; ++u) {                  // all 16 loads of the wave are in flight before the first use
+            const int r = r0 + wave * 4 + u;
+            t[u] = r < rows ? idx[r] : -1;
+            if (t[u] >= table_rows) t[u] = -1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) atomicAdd(&tab[t[u]][lane + 64 * i], v[u][i]);
+            for (int i = 0; i < 4; ++i) {
+                const int c = c0 + lane + 64 * i;
+                v[u][i] = (t[u] >= 0 && c < width) ? g[(size_t)r * ld_g + c] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (t[u] < 0) continue;                    // wave-uniform
+            if (lane == 0) touched[t[u]] = 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) atomicAdd(&tab[t[u]][lane + 64 * i], v[u][i]);
+        }
     }
     __syncthreads();
     for (int tr = 0; tr < table_rows; ++tr) {
@@ -1057,8 +1064,11 @@ extern "C" int lego_scatter_add_rows(float* grad_table, int ld_table, int width,
     if (rows_cap <= 0) return 0;
     if (table_rows > 0 && table_rows <= kSmallTableRows) {
         LEGO_REQUIRE((width & 3) == 0 && (ld_g & 3) == 0, "lego_scatter_add_rows: width=%d and ld_g=%d must be multiples of 4", width, ld_g);
-        hipLaunchKernelGGL(scatter_add_small_kernel, dim3((rows_cap + kSmallChunk - 1) / kSmallChunk, (width + 255) / 256), dim3(256), 0, ST,
-                           grad_table, ld_table, width, table_rows, idx, rows_cap, rows_dyn, g, ld_g);
+        const int chunks = (rows_cap + kSmallChunk - 1) / kSmallChunk;
+        int iters = chunks / 512;                      // ~512 workgroups for long row ranges, one chunk each for short ones
+        iters = iters < 1 ? 1 : (iters > 16 ? 16 : iters);
+        hipLaunchKernelGGL(scatter_add_small_kernel, dim3((chunks + iters - 1) / iters, (width + 255) / 256), dim3(256), 0, ST,
+                           grad_table, ld_table, width, table_rows, idx, rows_cap, rows_dyn, g, ld_g, iters);
         return check_launch("lego_scatter_add_rows");
     }
     const long long total = (long long)rows_cap * width;
