@@ -122,10 +122,10 @@ __global__ __launch_bounds__(64) void mhsa_bwd_kernel(const float* __restrict__ 
     const int ic = act ? i : 0;
     const float scale = rsqrtf((float)HD);
     const float* qbase = qkv + (size_t)beg * ldq + h * HD + half * W;
-    const float* vbase = qbase + 2 * D;
     const float* gbase = gout + (size_t)beg * ldgo + h * HD + half * W;
     constexpr int LT = SPLIT ? 32 : kMaxL;
     __shared__ float Pl[LT][LT + 1];           // signed probabilities [key j][query i], staged with coalesced loads
+    __shared__ float dPl[LT][LT + 1];          // dP[i][j] = dOut_i . V_j, same layout: formed once, used by both passes
     // two row panels in LDS: (K, V) for pass 1, then (Q, dOut) for pass 2 -- rows are read at wave-uniform addresses
     __shared__ __attribute__((aligned(16))) float Ra[LT][HD];
     __shared__ __attribute__((aligned(16))) float Rb[LT][HD];
@@ -150,6 +150,7 @@ __global__ __launch_bounds__(64) void mhsa_bwd_kernel(const float* __restrict__ 
             if (SPLIT) dpd += __shfl_xor(dpd, 32, 64);
             const float ps = Pl[j][ic];                                // sign bit = dropped
             dot += (ps > 0.f ? dpd * keep_scale * ps : 0.f);
+            if (half == 0) dPl[j][i] = dpd;                            // rows i >= L are never read back
         }
         if (act && half == 0) dotS[i] = dot;
         float dq[W];
@@ -157,8 +158,7 @@ __global__ __launch_bounds__(64) void mhsa_bwd_kernel(const float* __restrict__ 
         for (int c = 0; c < W; ++c) dq[c] = 0.f;
         for (int j = 0; j < L; ++j) {
             const float* kr = &Ra[j][half * W];
-            float dpd = dotw<W>(g, &Rb[j][half * W]);
-            if (SPLIT) dpd += __shfl_xor(dpd, 32, 64);
+            const float dpd = dPl[j][i];                               // own write of the loop above (both halves: lane i)
             const float ps = Pl[j][ic];
             const float dS = fabsf(ps) * ((ps > 0.f ? dpd * keep_scale : 0.f) - dot);
 #pragma unroll
@@ -174,15 +174,14 @@ __global__ __launch_bounds__(64) void mhsa_bwd_kernel(const float* __restrict__ 
     stage(qkv + (size_t)beg * ldq + h * HD, ldq, gout + (size_t)beg * ldgo + h * HD, ldgo);                   // Q, dOut
     __syncthreads();
     {                                          // ---- pass 2, lane = (key row j, half): dK[j], dV[j]; probs read by column
-        float own[W], dk[W], dv[W];
+        float dk[W], dv[W];
 #pragma unroll
-        for (int c = 0; c < W; ++c) { own[c] = vbase[(size_t)ic * ldq + c]; dk[c] = 0.f; dv[c] = 0.f; }
+        for (int c = 0; c < W; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
         for (int r = 0; r < L; ++r) {
             const float* qr = &Ra[r][half * W];
             const float* gr = &Rb[r][half * W];
             const float ps = Pl[ic][r];
-            float dpd = dotw<W>(own, gr);
-            if (SPLIT) dpd += __shfl_xor(dpd, 32, 64);
+            const float dpd = dPl[ic][r];                              // dOut_r . V_j from pass 1 (other lanes' writes: barriers above)
             const float keep = ps > 0.f ? keep_scale : 0.f;
             const float p = fabsf(ps);
             const float dS = p * (dpd * keep - dotS[r]);
