@@ -41,7 +41,6 @@ def parse():
     ap.add_argument("--model", default="naml", choices=["naml", "nrms"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=12)
-    ap.add_argument("--micro", type=int, default=1, help="micro-batches per step on separate HIP streams")
     ap.add_argument("--time-every", type=int, default=8, help="bracket the tagged kernels with HIP events every N-th timed step")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even at world size 1 (path check)")
     ap.add_argument("--small", action="store_true", help="shrunken world for quick checks (NOT the metric config)")
@@ -129,7 +128,7 @@ def main():
         params = init_nrms_params(D=args.hidden, V=cfg["V"], n_cat=cfg["n_cat"], glove=glove)
     B = args.batch
     ts = TrainStep(args.model, params, data, B, K=4, lr=1e-3, total_steps=0, seed=2023,
-                   process_group=pg, world_size=world_size, dropout=True, micro=args.micro, force_allreduce=args.force_dist)
+                   process_group=pg, world_size=world_size, dropout=True, force_allreduce=args.force_dist, tail="drop")
 
     def barrier():
         if dist_on:
@@ -188,7 +187,7 @@ def main():
         kern[tag] = {"avg_ms": ms, "launches": len(evs)}
     for e in ts.engines:
         e.timers = None
-    launches = max(1, args.steps * args.micro)         # one launch of each tagged kernel per micro-batch
+    launches = max(1, args.steps)                      # one launch of each tagged kernel per step
     rows_per_launch = rows_tok / launches
     yrows_per_launch = (rows_tok + n_inst) / launches
     flops = {                                          # algorithmic flops per launch
@@ -229,7 +228,7 @@ def main():
                            "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic.get("gather_rows"),
                            "avg_launch_ms": round(kern["gather_rows"]["avg_ms"], 5),
                            "algorithmic_bytes_per_launch": gbytes,
-                           "dense_reference_bytes_per_launch": B // args.micro * 55 * 30 * 1200}
+                           "dense_reference_bytes_per_launch": B * 55 * 30 * 1200}
 
     if rank != 0:
         if dist_on:
@@ -245,7 +244,6 @@ def main():
                                f"K=4 negatives S=50 T=30, full train step (sample+fwd+bwd+allreduce+Adam), dropout 0.1"
                                + (" [SMALL WORLD - not the metric config]" if args.small else ""),
                    "global_batch": B * world_size, "parallelism": f"dp{world_size}",
-                   "micro_batches": args.micro,
                    "live_token_rows_per_step": round(rows_tok / max(1, args.steps), 1),
                    "item_instances_per_step": round(n_inst / max(1, args.steps), 1)},
         "final_loss": round(final_loss, 5),

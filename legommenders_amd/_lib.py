@@ -62,7 +62,7 @@ SIGNATURES = {
     "lego_rowdot_bwd": [P, I, P, I, P, I, I, P, I, P, I, P],
     "lego_relu_bwd": [P, I, P, I, I, I, F, P],
     "lego_adam_step": [P, P, P, P, I64, F, F, F, F, I, F, I, P],
-    "lego_sample_negatives": [P, P, P, P, I, I, I, I, U64, U32, P, P],
+    "lego_sample_negatives": [P, P, P, P, I, I, I, I, U64, U32, U32, U32, P, P],
     "lego_gather_history": [P, P, P, I, I, P, P, P],
     "lego_gather_i32": [P, P, I, P, P, P],
     "lego_grouped_metrics": [P, P, P, I, P, I, P, P],

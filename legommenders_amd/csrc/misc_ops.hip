@@ -930,21 +930,25 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float*
 // ------------------------------------------------------------------ negative sampling / history fetch
 __global__ void sample_negatives_kernel(const int* __restrict__ row_user, const int* __restrict__ row_item,
                                         const int* __restrict__ neg_list, const int* __restrict__ neg_len, int neg_cap,
-                                        int B, int K, int n_items, uint32_t seed_lo, uint32_t seed_hi, uint32_t step, int* cand) {
+                                        int B, int K, int n_items, uint32_t seed_lo, uint32_t seed_hi, uint32_t step,
+                                        uint32_t row_base, uint32_t row_stride, int* cand) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    // the Philox stream of a row is keyed on its position in the GLOBAL batch of the step (rank r of W: r + b * W), so that
+    // W ranks x B rows draw exactly what one device with batch W * B draws for the same rows
+    const uint32_t gb = row_base + (uint32_t)b * row_stride;
     const int u = row_user[b];
     const int L = min(max(neg_len[u], 0), neg_cap);
     const int n_true = min(K, L);
     int* out = cand + (size_t)b * (K + 1);
     out[0] = row_item[b];
     uint32_t ctr = 0;
-    Philox4 r = philox4x32_10((uint32_t)b, step, ctr++, 0x6e656773u, seed_lo, seed_hi);
+    Philox4 r = philox4x32_10(gb, step, ctr++, 0x6e656773u, seed_lo, seed_hi);
     int have = 0;
     uint32_t pool[4] = {r.x, r.y, r.z, r.w};
     auto next = [&]() -> uint32_t {
         if (have == 4) {
-            r = philox4x32_10((uint32_t)b, step, ctr++, 0x6e656773u, seed_lo, seed_hi);
+            r = philox4x32_10(gb, step, ctr++, 0x6e656773u, seed_lo, seed_hi);
             pool[0] = r.x; pool[1] = r.y; pool[2] = r.z; pool[3] = r.w; have = 0;
         }
         return pool[have++];
@@ -1211,11 +1215,11 @@ extern "C" int lego_adam_step(float* p, float* g, float* m, float* v, int64_t n,
 
 extern "C" int lego_sample_negatives(const int32_t* row_user, const int32_t* row_item, const int32_t* neg_list,
                                      const int32_t* neg_len, int neg_cap, int B, int K, int n_items, uint64_t seed,
-                                     uint32_t step, int32_t* cand, void* stream) {
+                                     uint32_t step, uint32_t row_base, uint32_t row_stride, int32_t* cand, void* stream) {
     LEGO_REQUIRE(K < kMaxCand && n_items > 0, "lego_sample_negatives: K=%d n_items=%d unsupported", K, n_items);
     if (B <= 0) return 0;
     hipLaunchKernelGGL(sample_negatives_kernel, dim3((B + 127) / 128), dim3(128), 0, ST, row_user, row_item, neg_list, neg_len,
-                       neg_cap, B, K, n_items, (uint32_t)seed, (uint32_t)(seed >> 32), step, cand);
+                       neg_cap, B, K, n_items, (uint32_t)seed, (uint32_t)(seed >> 32), step, row_base, row_stride, cand);
     return check_launch("lego_sample_negatives");
 }
 

@@ -67,7 +67,7 @@ class _Base:
         self.seed = seed
         self.step = 0
         self.NIc = B * (C + S)
-        self.BC = B * C
+        self.nb = B               # rows of the batch being processed (<= B: the short last batch of an epoch)
         i32 = dict(dtype=torch.int32, device=self.dev)
         self.counters = torch.zeros(8, **i32)
         self.inst_item = torch.zeros(self.NIc, **i32)
@@ -78,6 +78,18 @@ class _Base:
 
     def _f(self, *shape):
         return torch.zeros(*shape, dtype=torch.float32, device=self.dev)
+
+    @property
+    def BC(self):
+        """candidate instances come first in the plan's instance order; the clicked items start here"""
+        return self.nb * self.C
+
+    def set_batch(self, nb: int):
+        """process batches of `nb` <= B rows from now on (workspaces stay sized for B; every launch takes its row count as
+        an argument, so this is host state only)"""
+        if not 0 < nb <= self.B:
+            raise _lib.LegoHipError(f"batch of {nb} rows does not fit an engine built for B={self.B}")
+        self.nb = int(nb)
 
     # ---- double-buffered plans: the (tiny, latency-bound) plan kernels of step N+1 run on a side stream while
     # step N computes, so they leave the critical path (TrainStep._prefetch)
@@ -93,11 +105,11 @@ class _Base:
         for k, v in self._slots[s].items():
             setattr(self, k, v)
 
-    def plan_on(self, stream, slot: int, cand, hist, hist_len):
-        """enqueue the ragged plan of (cand, hist, hist_len) into plan slot `slot` on `stream`"""
+    def plan_on(self, stream, slot: int, cand, hist, hist_len, nb=None):
+        """enqueue the ragged plan of the first `nb` rows of (cand, hist, hist_len) into plan slot `slot` on `stream`"""
         b = self._slots[slot]
         tok, tlen, width = self._plan_tables()
-        call("lego_plan_batch", _ptr(cand), _ptr(hist), _ptr(hist_len), self.B, self.C, self.S, _ptr(tok), _ptr(tlen), width,
+        call("lego_plan_batch", _ptr(cand), _ptr(hist), _ptr(hist_len), nb or self.B, self.C, self.S, _ptr(tok), _ptr(tlen), width,
              _ptr(b["counters"]), _ptr(b["inst_item"]), _ptr(b["seg_off"]), _ptr(b["hist_off"]), _ptr(b["rowinfo"]),
              _ptr(b["row_tok"]), ctypes.c_void_p(stream.cuda_stream))
 
@@ -267,8 +279,8 @@ class NamlEngine(_Base):
         call("lego_plan_pairs", _ptr(b["seg_off"]), self.NIc, _ptr(b["counters"], 1), _ptr(b["pair_info"]),
              _ptr(b["counters"], 5), st)
 
-    def plan_on(self, stream, slot, cand, hist, hist_len):
-        super().plan_on(stream, slot, cand, hist, hist_len)
+    def plan_on(self, stream, slot, cand, hist, hist_len, nb=None):
+        super().plan_on(stream, slot, cand, hist, hist_len, nb)
         if self.Rc > 0:
             if self.wino:
                 self.plan_pairs(stream, self._slots[slot])
@@ -316,7 +328,7 @@ class NamlEngine(_Base):
         depends on; None = record one here.  `neck_ev`: recorded after the item tower, where the step enters its
         latency-bound user-side chain and most CUs idle -- TrainStep starts the next batch's sample / plan / gather
         there (any earlier and the gather competes with the row-strip GEMMs, which own every CU)."""
-        P, B, C, S, D, A, E0 = self.P, self.B, self.C, self.S, self.D, self.A, self.E0
+        P, B, C, S, D, A, E0 = self.P, self.nb, self.C, self.S, self.D, self.A, self.E0
         m, sb, sc = self._lanes()
         ev = self._evs
         _check(cand, torch.int32, "cand"); _check(hist, torch.int32, "hist"); _check(hist_len, torch.int32, "hist_len")
@@ -351,7 +363,7 @@ class NamlEngine(_Base):
 
     def _plan(self, cand, hist, hist_len):
         m, _, _ = self._lanes()
-        self.kk(m, None, "lego_plan_batch", _ptr(cand), _ptr(hist), _ptr(hist_len), self.B, self.C, self.S,
+        self.kk(m, None, "lego_plan_batch", _ptr(cand), _ptr(hist), _ptr(hist_len), self.nb, self.C, self.S,
                 _ptr(self.tb.title_tok), _ptr(self.tb.title_len), self.T,
                 _ptr(self.counters), _ptr(self.inst_item), _ptr(self.seg_off), _ptr(self.hist_off),
                 _ptr(self.rowinfo), _ptr(self.row_tok))
@@ -413,8 +425,8 @@ class NamlEngine(_Base):
     def _forward_users(self, training):
         """k7: AdaOperator = additive pool over the clicked items of each user (ada_operator.py:31-34)"""
         m, _, _ = self._lanes()
-        self._additive_fwd(m, "user_op.", _ptr(self.items, self.BC * self.D), self.B * self.S, self.cnt(3), self.Tu, self.Au,
-                           self.hist_off, None, self.B, None, self.user, self.wu)
+        self._additive_fwd(m, "user_op.", _ptr(self.items, self.BC * self.D), self.nb * self.S, self.cnt(3), self.Tu, self.Au,
+                           self.hist_off, None, self.nb, None, self.user, self.wu)
 
     def _additive_fwd(self, st, prefix, xp, rows_cap, rows_dyn, t, A, seg_off, extra, n_cap, n_dyn, out, wrow):
         P, D = self.P, self.D
@@ -425,12 +437,9 @@ class NamlEngine(_Base):
                 _ptr(seg_off), None, extra, n_cap, n_dyn, D, A, _ptr(out), D, _ptr(wrow))
 
     # ------------------------------------------------------------------ backward
-    def backward(self, G: Dict[str, torch.Tensor], gloss: float = 1.0, before_last=None):
-        """Accumulates d(loss)/d(param) into G (reference key names); call after forward(training...).
-        `before_last()`: called on the host right before the LAST gradient kernel (the projection weight gradient) is
-        enqueued, with every other gradient already ordered on the current stream -- TrainStep starts the all-reduce of
-        those there so that it overlaps the last GEMM."""
-        P, B, C, S, D, A, E0 = self.P, self.B, self.C, self.S, self.D, self.A, self.E0
+    def backward(self, G: Dict[str, torch.Tensor], gloss: float = 1.0):
+        """Accumulates d(loss)/d(param) into G (reference key names); call after forward(training...)."""
+        P, B, C, S, D, A, E0 = self.P, self.nb, self.C, self.S, self.D, self.A, self.E0
         m, sb, sc = self._lanes()
         ev = self._evs
         training = self._training
@@ -455,7 +464,6 @@ class NamlEngine(_Base):
         # item-side pool backward: dY direct part, dpre in place of T
         self._pool_bwd(m, "item_op.", G, _ptr(self.Y), _ptr(self.dY), self.Tt, A, self.seg_off, self.cnt(0), self.NIc,
                        self.cnt(1), self.d_items, self.wrow)
-        conv_w_main = os.environ.get("LEGO_CONVW", "main") == "main"
         keep = 1.0 / (1.0 - self.p_conv) if (training and self.p_conv > 0) else 1.0
         w1 = _ptr(P["item_op.additive_attention.encoder.0.weight"])
         self._fork(ev[4], m, sb)
@@ -477,22 +485,6 @@ class NamlEngine(_Base):
         # ---- main: token rows: dY = relu'(.)*keep * (dY + dpre.W1); column sums -> conv bias grad
         self.kk(m, "additive_bwd_data", "lego_linear_bwd_data", _ptr(self.Tt), A, w1, D, _ptr(self.dY), D, self.Rc, self.cnt(0), A, D, 1,
                 _ptr(self.Y), D, keep, None, None, _ptr(G["item_op.cnn.bias"]), None, None)
-        cw = m if conv_w_main else sc
-        if cw is not m:
-            self._fork(ev[5], m, sc)
-        # ---- conv weight gradient (side stream C, or LEGO_CONVW=main: after the data gradient on the main stream)
-
-        def conv_w():
-            if self.wino:
-                self.kk(cw, "conv3_bwd_weight", "lego_conv3_wino_bwd_weight", _ptr(self.dY), D, _ptr(self.H), D,
-                        _ptr(self.pair_info), self.Pc, self.cnt(5), _ptr(self.wino_du), D, D)
-                self.kk(cw, None, "lego_conv3_wino_unpack_add", _ptr(self.wino_du), _ptr(G["item_op.cnn.weight"]), D, D)
-                return
-            self.kk(cw, "conv3_bwd_weight", "lego_conv3_bwd_weight", _ptr(self.dY), D, _ptr(self.H), D, _ptr(self.rowinfo),
-                    _ptr(self.dwt), self.Rc, self.cnt(0), D, D)
-            self.kk(cw, None, "lego_conv3_unpack_add", _ptr(self.dwt), _ptr(G["item_op.cnn.weight"]), D, D)
-        if cw is not m:
-            conv_w()
         # ---- main: conv data gradient -> projection weight gradient
         if self.wino:
             self.kk(m, "conv3_bwd_data", "lego_conv3_wino_bwd_data", _ptr(self.dY), D, _ptr(self.wino_u), _ptr(self.wino_ut), _ptr(self.pair_info),
@@ -502,19 +494,18 @@ class NamlEngine(_Base):
             self.kk(m, "conv3_bwd_data", "lego_conv3_bwd_data", _ptr(self.dY), D, _ptr(self.wt), _ptr(self.rowinfo), _ptr(self.dH), D,
                     self.Rc, self.cnt(0), D, D, self.drop(self.p_proj, SITE_PROJ, training),
                     _ptr(G["embedding_vocab_table.glove.linear.bias"]), 0)
-        if cw is m:
-            conv_w()
-        joined = False
-        if before_last is not None and cw is m:
-            self._fork(ev[6], sb, m)                 # the side stream's gradients are part of the early all-reduce
-            joined = True
-            before_last()
+        # ---- conv weight gradient after the data gradient on the main stream (a third stream measured 1-1.5 % slower)
+        if self.wino:
+            self.kk(m, "conv3_bwd_weight", "lego_conv3_wino_bwd_weight", _ptr(self.dY), D, _ptr(self.H), D,
+                    _ptr(self.pair_info), self.Pc, self.cnt(5), _ptr(self.wino_du), D, D)
+            self.kk(m, None, "lego_conv3_wino_unpack_add", _ptr(self.wino_du), _ptr(G["item_op.cnn.weight"]), D, D)
+        else:
+            self.kk(m, "conv3_bwd_weight", "lego_conv3_bwd_weight", _ptr(self.dY), D, _ptr(self.H), D, _ptr(self.rowinfo),
+                    _ptr(self.dwt), self.Rc, self.cnt(0), D, D)
+            self.kk(m, None, "lego_conv3_unpack_add", _ptr(self.dwt), _ptr(G["item_op.cnn.weight"]), D, D)
         self.kk(m, "proj_bwd_weight", "lego_linear_bwd_weight", _ptr(self.dH), D, _ptr(self.X), E0,
                 _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Rc, self.cnt(0), D, E0, None, None)
-        if not joined:
-            self._fork(ev[6], sb, m)
-        if cw is not m:
-            self._fork(ev[7], sc, m)
+        self._fork(ev[6], sb, m)
         self.step = step_save
 
     def _pool_bwd(self, st, prefix, G, x_ptr, dx_ptr, t, A, seg_off, extra, n_cap, n_dyn, gout, wrow):
@@ -684,7 +675,7 @@ class NrmsEngine(_Base):
         return self.seq_tok, self.seq_len, self.L
 
     def forward(self, cand, hist, hist_len, training=False, with_loss=True, planned=False, fork_ev=None, neck_ev=None):
-        P, B, C, S, D = self.P, self.B, self.C, self.S, self.D
+        P, B, C, S, D = self.P, self.nb, self.C, self.S, self.D
         st = _stream()
         _check(cand, torch.int32, "cand"); _check(hist, torch.int32, "hist"); _check(hist_len, torch.int32, "hist_len")
         self._training = training
@@ -701,7 +692,7 @@ class NrmsEngine(_Base):
         return self.scores, self.loss
 
     def _plan(self, cand, hist, hist_len):
-        call("lego_plan_batch", _ptr(cand), _ptr(hist), _ptr(hist_len), self.B, self.C, self.S,
+        call("lego_plan_batch", _ptr(cand), _ptr(hist), _ptr(hist_len), self.nb, self.C, self.S,
              _ptr(self.seq_tok), _ptr(self.seq_len), self.L,
              _ptr(self.counters), _ptr(self.inst_item), _ptr(self.seg_off), _ptr(self.hist_off),
              _ptr(self.rowinfo), _ptr(self.row_tok), _stream())
@@ -729,11 +720,11 @@ class NrmsEngine(_Base):
                       self.items, SITE_ITEM_ATT, training, st)
 
     def _forward_users(self, training):
-        self._att_fwd("user_op.", self.user_ws, _ptr(self.items, self.BC * self.D), self.cnt(3), self.hist_off, self.B, None,
+        self._att_fwd("user_op.", self.user_ws, _ptr(self.items, self.BC * self.D), self.cnt(3), self.hist_off, self.nb, None,
                       self.user, SITE_USER_ATT, training, _stream())
 
     def backward(self, G, gloss: float = 1.0):
-        P, B, C, S, D = self.P, self.B, self.C, self.S, self.D
+        P, B, C, S, D = self.P, self.nb, self.C, self.S, self.D
         st = _stream()
         training = self._training
         step_save = self.step

@@ -19,6 +19,12 @@ _site = itertools.count(1)
 SEED = 2023
 
 
+def seed_streams(seed: int):
+    """seed of the Philox dropout streams of this process (data parallel: train_step.rank_seed(seed, rank))"""
+    global SEED
+    SEED = int(seed)
+
+
 def _drop(p, training):
     """(p, seed, site) with a fresh Philox stream per call, or None in eval / p == 0."""
     if not training or p <= 0:

@@ -11,12 +11,18 @@ import torch
 
 from ._lib import call
 from .engine import _ptr, _stream
+from .train_step import BatchSchedule, rank_seed
 
 
 class PluginStep:
     def __init__(self, model, data, B: int, K: int = 4, lr: float = 1e-3, total_steps: int = 0, warmup: int = 0,
-                 seed: int = 2023, process_group=None, world_size: int = 1, accumulate: int = 1, item_lr=None):
+                 seed: int = 2023, process_group=None, world_size: int = 1, accumulate: int = 1, item_lr=None,
+                 tail: str = "keep"):
         from legommenders_amd.loader.env import Env
+        from legommenders_amd import functional
+        functional.seed_streams(rank_seed(seed, data.rank))                 # dropout streams differ per rank
+        self.schedule = BatchSchedule(data.n_rows, B, tail)
+        self.steps_per_epoch = self.schedule.steps_per_epoch
         self.model, self.data, self.B, self.K, self.C = model, data, B, K, K + 1
         self.accumulate, self._acc, self.batch_idx = max(1, int(accumulate)), 0, 0     # trainer.py:171,197-203
         dev = data.tables.title_tok.device
@@ -45,19 +51,21 @@ class PluginStep:
         self.Env = Env
 
     def sample_batch(self):
-        d, B = self.data, self.B
-        start = (self.batch_idx * B) % max(1, d.n_rows - B + 1)
-        ru, ri = _ptr(d.row_user, start), _ptr(d.row_item, start)
-        call("lego_sample_negatives", ru, ri, _ptr(d.neg_list), _ptr(d.neg_len), d.neg_cap, B, self.K, d.n_items,
-             self.seed, self.batch_idx, _ptr(self.cand), _stream())
-        call("lego_gather_history", ru, _ptr(d.user_hist), _ptr(d.user_hist_len), B, d.S, _ptr(self.hist),
+        d = self.data
+        epoch, start, nb = self.schedule.at(self.batch_idx)
+        row_user, row_item = d.rows(epoch)                                  # per-epoch reshuffle (train_step.DeviceData)
+        ru, ri = _ptr(row_user, start), _ptr(row_item, start)
+        call("lego_sample_negatives", ru, ri, _ptr(d.neg_list), _ptr(d.neg_len), d.neg_cap, nb, self.K, d.n_items,
+             self.seed, self.batch_idx, d.rank, d.world_size, _ptr(self.cand), _stream())
+        call("lego_gather_history", ru, _ptr(d.user_hist), _ptr(d.user_hist_len), nb, d.S, _ptr(self.hist),
              _ptr(self.hist_len), _stream())
+        return nb
 
     def step(self):
         cm = self.model.cm
-        self.sample_batch()
-        batch = {cm.item_col: self.cand.long(), cm.history_col: self.hist.long(),
-                 cm.mask_col: (self.ar < self.hist_len[:, None]).long()}
+        nb = self.sample_batch()                                            # nb < B: the short last batch of an epoch
+        batch = {cm.item_col: self.cand[:nb].long(), cm.history_col: self.hist[:nb].long(),
+                 cm.mask_col: (self.ar < self.hist_len[:nb, None]).long()}
         self.Env.train()
         self.model.train()
         if self._acc == 0:
@@ -80,6 +88,20 @@ class PluginStep:
         self.sched.step()
         self.step_idx += 1
         return loss.detach().reshape(1)
+
+    # ---- checkpoint state, as the reference saves it (base_lego.py:257-267: optimizer.state_dict() + scheduler.state_dict())
+    def optimizer_state(self):
+        return self.opt.state_dict()
+
+    def load_optimizer_state(self, st):
+        self.opt.load_state_dict(st)
+
+    def scheduler_state(self):
+        return self.sched.state_dict()
+
+    def load_scheduler_state(self, st):
+        self.sched.load_state_dict(st)
+        self.step_idx = int(st.get("last_epoch", self.step_idx))
 
 
 class PluginEvaluator:

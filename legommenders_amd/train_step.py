@@ -56,61 +56,120 @@ class FlatParams:
         return {k: v.detach().clone() for k, v in self.P.items()}
 
 
+def rank_seed(seed: int, rank: int) -> int:
+    """seed of a rank-local Philox stream family (dropout keep bits: their counters are rank-local row indices, so the rank
+    goes into the key; rank 0 keeps `seed`)"""
+    return (int(seed) ^ (0x9E3779B97F4A7C15 * int(rank))) & 0xFFFFFFFFFFFFFFFF
+
+
 class DeviceData:
     """Train rows + user tables resident in HBM (replaces the DataLoader worker pipeline,
-    loader/manager.py:374-381, loader/data_set.py:61-85, loader/resampler.py:139-259)."""
+    loader/manager.py:374-381, loader/data_set.py:61-85, loader/resampler.py:139-259).
+
+    Row order = `DataLoader(shuffle=True)` (manager.py:374-381) iterated anew every epoch (trainer.py:186-190): epoch e
+    walks ONE permutation drawn from (seed, e), identical on every rank; it is cut to a multiple of the world size and rank r
+    takes positions r::world, so every rank has the same number of rows (and steps, and schedule length) and the
+    global batch of step s is the contiguous slice perm[s*W*B : (s+1)*W*B] a single device with batch W*B would take.
+    Two epochs are resident (buffer = epoch % 2): the batch after the last one of an epoch is sampled ahead of time."""
 
     def __init__(self, world: dict, device, rank=0, world_size=1, seed=2023):
         i32 = lambda a: torch.as_tensor(a).to(device=device, dtype=torch.int32).contiguous()
+        self.device = device
         self.tables = ItemTables(world["title_tok"], world["title_len"], world["cat"], device)
         self.user_hist, self.user_hist_len = i32(world["user_hist"]), i32(world["user_hist_len"])
         self.neg_list, self.neg_len = i32(world["neg_list"]), i32(world["neg_len"])
         self.neg_cap = self.neg_list.shape[1]
         self.S = self.user_hist.shape[1]
         self.n_items = self.tables.n_items
-        # one shared seeded permutation per epoch; rank r takes rows r::world (SURVEY.md section 8e)
-        g = torch.Generator().manual_seed(seed)
-        perm = torch.randperm(len(world["row_user"]), generator=g)
-        mine = perm[rank::world_size]
-        self.row_user = i32(world["row_user"])[mine.to(device)].contiguous()
-        self.row_item = i32(world["row_item"])[mine.to(device)].contiguous()
-        self.n_rows = self.row_user.numel()
+        self.rank, self.world_size, self.seed = int(rank), int(world_size), int(seed)
+        self._all_user, self._all_item = i32(world["row_user"]), i32(world["row_item"])
+        self.n_total = self._all_user.numel()
+        self.n_rows = self.n_total // self.world_size          # per rank, equal on every rank
+        self._buf = [dict(epoch=-1, user=None, item=None), dict(epoch=-1, user=None, item=None)]
+        self.ensure_epoch(0)
+
+    def epoch_permutation(self, epoch: int) -> torch.Tensor:
+        """host permutation of ALL train rows for `epoch` (same on every rank: seeded by (seed, epoch) only)"""
+        g = torch.Generator().manual_seed(self.seed + 1000003 * int(epoch))
+        return torch.randperm(self.n_total, generator=g)
+
+    def shard_of(self, epoch: int) -> torch.Tensor:
+        """this rank's row indices for `epoch`, in visiting order"""
+        perm = self.epoch_permutation(epoch)
+        return perm[: self.n_rows * self.world_size][self.rank::self.world_size]
+
+    def ensure_epoch(self, epoch: int):
+        """make the rows of `epoch` resident (enqueued on the current stream; a no-op when they already are)"""
+        b = self._buf[epoch % 2]
+        if b["epoch"] != epoch:
+            mine = self.shard_of(epoch).to(self.device)
+            if b["user"] is None:
+                b["user"], b["item"] = self._all_user[mine].contiguous(), self._all_item[mine].contiguous()
+            else:                                              # in place: sampling kernels hold these addresses
+                torch.index_select(self._all_user, 0, mine, out=b["user"])
+                torch.index_select(self._all_item, 0, mine, out=b["item"])
+            b["epoch"] = epoch
+        return b
+
+    def rows(self, epoch: int):
+        b = self.ensure_epoch(epoch)
+        return b["user"], b["item"]
+
+    # epoch-0 views (tests, tools)
+    @property
+    def row_user(self):
+        return self.rows(0)[0]
+
+    @property
+    def row_item(self):
+        return self.rows(0)[1]
+
+
+class BatchSchedule:
+    """batch index -> (epoch, first row, rows in the batch).  `tail="keep"`: the last batch of an epoch is the short one the
+    reference's DataLoader yields (drop_last=False, manager.py:374-381); `tail="drop"`: whole batches only (bench)."""
+
+    def __init__(self, n_rows: int, B: int, tail: str = "keep"):
+        assert tail in ("keep", "drop")
+        self.n_rows, self.B, self.tail = int(n_rows), int(B), tail
+        full = self.n_rows // self.B
+        self.steps_per_epoch = max(1, full + (1 if tail == "keep" and self.n_rows % self.B else 0))
+
+    def at(self, batch_idx: int):
+        epoch, k = divmod(int(batch_idx), self.steps_per_epoch)
+        start = k * self.B
+        return epoch, start, max(1, min(self.B, self.n_rows - start))
 
 
 class TrainStep:
+    BUCKET_BYTES = 64 << 20      # gradient buffers above this are all-reduced as a train of buckets (trainable token table)
+
     def __init__(self, kind: str, params: Dict[str, torch.Tensor], data: DeviceData, B: int, K: int = 4,
                  lr: float = 1e-3, total_steps: int = 0, warmup: int = 0, seed: int = 2023, heads: int = 8,
-                 glove: bool = True, process_group=None, world_size: int = 1, dropout: bool = True, micro: int = 1,
-                 force_allreduce: bool = False, accumulate: int = 1):
+                 glove: bool = True, process_group=None, world_size: int = 1, dropout: bool = True,
+                 force_allreduce: bool = False, accumulate: int = 1, tail: str = "keep", rank: Optional[int] = None):
         dev = data.tables.title_tok.device
         self.data, self.B, self.C, self.K = data, B, K + 1, K
+        self.rank = data.rank if rank is None else int(rank)
         frozen = ("embedding_vocab_table.glove.embedding.weight",) if "embedding_vocab_table.glove.embedding.weight" in params else ()
-        # the projection weight gradient is the last kernel of backward: with LEGO_AR_BUCKETS=2 it is all-reduced on its
-        # own after the rest (which then overlaps that GEMM).  Off by default: at world size 1 under torchrun the second
-        # collective's stream hops cost more than the overlap can save (0.851 vs 0.830 ms/step); to be re-measured on 8 GPUs.
-        last = ("embedding_vocab_table.glove.linear.weight",) if (kind == "naml" and micro == 1) else ()
+        # the big trainable token table (embed/null) goes LAST in the flat buffers: its gradient is the last thing backward
+        # produces, and everything before `fp.split` can be on the wire while it is still being scattered
+        last = tuple(k for k in ("embedding_vocab_table.glove.weight",) if k in params)
         self.fp = FlatParams(params, frozen, dev, last=last)
         pd = 0.1 if dropout else 0.0
         self.dropout = dropout
-        # `micro` > 1: the batch is processed as `micro` equal micro-batches on their own HIP streams.  Their kernel
-        # chains are independent, so one chain's prologue / epilogue / last-wave tail overlaps the other's MFMA main
-        # loops; gradients of all micro-batches accumulate (atomics) into the same flat buffer == the full-batch mean.
-        assert B % micro == 0, "batch must be divisible by the number of micro-batches"
-        self.micro, Bm = micro, B // micro
-        self.engines = []
-        for i in range(micro):
-            if kind == "naml":
-                e = NamlEngine(self.fp.P, data.tables, Bm, self.C, data.S, seed=seed + 7919 * i, p_proj=pd, p_conv=pd)
-            elif kind == "nrms":
-                e = NrmsEngine(self.fp.P, data.tables, Bm, self.C, data.S, heads=heads, glove=glove, seed=seed + 7919 * i,
-                               p_proj=pd, p_att=pd)
-            else:
-                raise ValueError(f"unknown model kind {kind!r} (the HIP path covers naml and nrms)")
-            self.engines.append(e)
-        if micro == 1 and kind == "naml":
-            self.engines[0].bind_grads(self.fp.G)          # fused user tower: forward writes its gradient partials
-        self.engine = self.engines[0]
-        self.streams = [torch.cuda.Stream(dev) for _ in range(micro)] if micro > 1 else [None]
+        # dropout streams are keyed on rank-local row counters, so the rank goes into their seed; the negative sampler is
+        # keyed on the row's position in the GLOBAL batch instead (sample_batch) and takes the plain seed
+        eseed = rank_seed(seed, self.rank)
+        if kind == "naml":
+            self.engine = NamlEngine(self.fp.P, data.tables, B, self.C, data.S, seed=eseed, p_proj=pd, p_conv=pd)
+            self.engine.bind_grads(self.fp.G)              # fused user tower: forward writes its gradient partials
+        elif kind == "nrms":
+            self.engine = NrmsEngine(self.fp.P, data.tables, B, self.C, data.S, heads=heads, glove=glove, seed=eseed,
+                                     p_proj=pd, p_att=pd)
+        else:
+            raise ValueError(f"unknown model kind {kind!r} (the HIP path covers naml and nrms)")
+        self.engines = [self.engine]
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         # two batch / plan slots: step N+1 is sampled and planned on `pre` while step N computes
@@ -118,7 +177,7 @@ class TrainStep:
         self._hist = [torch.zeros(B, data.S, **i32) for _ in range(2)]
         self._hist_len = [torch.zeros(B, **i32) for _ in range(2)]
         self.cand, self.hist, self.hist_len = self._cand[0], self._hist[0], self._hist_len[0]
-        self.prefetch = micro == 1 and str(dev) != "cpu"
+        self.prefetch = str(dev) != "cpu"
         if self.prefetch:
             self.engine.enable_plan_slots()
             self.pre = torch.cuda.Stream(dev)
@@ -128,6 +187,8 @@ class TrainStep:
             self._planned_step = -1
         self.lr, self.total_steps, self.warmup = lr, total_steps, warmup
         self.seed, self.step_idx = seed, 0
+        self.schedule = BatchSchedule(data.n_rows, B, tail)
+        self.steps_per_epoch = self.schedule.steps_per_epoch
         # `accumulate` batches per optimiser step (exp.policy.accumulate_batch, trainer.py:171,197-203): gradients of the
         # batch-mean losses ADD UP over the cycle (no 1/accumulate), then one all-reduce + Adam + scheduler step.
         # batch_idx counts batches (sampling, plan slots, dropout streams), step_idx optimiser steps (Adam bias, lr).
@@ -145,101 +206,114 @@ class TrainStep:
             return self.lr * step / max(1, self.warmup)
         return self.lr * max(0.0, (self.total_steps - step) / max(1, self.total_steps - self.warmup))
 
-    def sample_batch(self, step_idx=None, slot=0, stream=None):
-        """Resampler.rebuild on device for training step `step_idx` into batch slot `slot`"""
-        d, B = self.data, self.B
-        step_idx = self.batch_idx if step_idx is None else step_idx
-        start = (step_idx * B) % max(1, d.n_rows - B + 1)
+    def sample_batch(self, batch_idx=None, slot=0, stream=None):
+        """Resampler.rebuild on device for batch `batch_idx` into batch slot `slot`; returns the rows in the batch"""
+        d = self.data
+        batch_idx = self.batch_idx if batch_idx is None else batch_idx
+        epoch, start, nb = self.schedule.at(batch_idx)
+        row_user, row_item = d.rows(epoch)
         st = _stream() if stream is None else ctypes.c_void_p(stream.cuda_stream)
-        ru, ri = _ptr(d.row_user, start), _ptr(d.row_item, start)
-        call("lego_sample_negatives", ru, ri, _ptr(d.neg_list), _ptr(d.neg_len), d.neg_cap, B, self.K, d.n_items,
-             self.seed, step_idx, _ptr(self._cand[slot]), st)
-        call("lego_gather_history", ru, _ptr(d.user_hist), _ptr(d.user_hist_len), B, d.S, _ptr(self._hist[slot]),
+        ru, ri = _ptr(row_user, start), _ptr(row_item, start)
+        call("lego_sample_negatives", ru, ri, _ptr(d.neg_list), _ptr(d.neg_len), d.neg_cap, nb, self.K, d.n_items,
+             self.seed, batch_idx, d.rank, d.world_size, _ptr(self._cand[slot]), st)
+        call("lego_gather_history", ru, _ptr(d.user_hist), _ptr(d.user_hist_len), nb, d.S, _ptr(self._hist[slot]),
              _ptr(self._hist_len[slot]), st)
+        return nb
 
-    def _prefetch(self, step_idx, go=None):
-        """sample + plan training step `step_idx` on the side stream `pre` (slot = step_idx % 2)"""
-        slot = step_idx % 2
+    def _prefetch(self, batch_idx, go=None):
+        """sample + plan batch `batch_idx` on the side stream `pre` (slot = batch_idx % 2)"""
+        slot = batch_idx % 2
         if go is None:
             go = self._go
             go.record(torch.cuda.current_stream())
-        self.pre.wait_event(go)                    # the slot's previous user (step_idx - 2) is complete by then
-        self.sample_batch(step_idx, slot, self.pre)
-        self.engine.plan_on(self.pre, slot, self._cand[slot], self._hist[slot], self._hist_len[slot])
+        self.pre.wait_event(go)                    # the slot's previous user (batch_idx - 2) is complete by then
+        nb = self.sample_batch(batch_idx, slot, self.pre)
+        self.engine.plan_on(self.pre, slot, self._cand[slot], self._hist[slot], self._hist_len[slot], nb)
         if self.dropout and hasattr(self.engine, "prefetch_masks"):
-            self.engine.prefetch_masks(self.pre, slot)     # engine.step == step_idx here (one training forward per step)
+            self.engine.prefetch_masks(self.pre, slot)     # engine.step == batch_idx here (one training forward per batch)
         with torch.cuda.stream(self.pre):          # row statistics of the planned batch (bench.py), off the main stream
             self.counter_sum += self.engine._slots[slot]["counters"]
         self._ready[slot].record(self.pre)
-        self._planned_step = step_idx
+        self._planned_step = batch_idx
+
+    def sync_gradients(self):
+        """the ONE gradient exchange of an optimiser step: all-reduce(sum) of the flat buffer (1/world is applied inside
+        Adam).  A buffer above BUCKET_BYTES (the 410 MB trainable token table of embed/null) goes out as a train of
+        asynchronous bucket all-reduces on RCCL's stream, so the ring is busy with bucket k while k+1 is still being enqueued
+        and the wire time is bounded by bandwidth, not by one serial 410 MB launch."""
+        if not (self.world > 1 or self.force_allreduce):
+            return
+        g = self.fp.grad
+        per = max(1, self.BUCKET_BYTES // 4)
+        if g.numel() <= per:
+            torch.distributed.all_reduce(g, group=self.pg)
+            return
+        works = [torch.distributed.all_reduce(g[o:o + per], group=self.pg, async_op=True) for o in range(0, g.numel(), per)]
+        for w in works:
+            w.wait()
 
     def step(self):
         """sample -> forward -> backward -> all-reduce -> Adam.  Returns the device loss tensor (no sync)."""
+        loss, last_of_cycle = self.compute_gradients()
+        if last_of_cycle:
+            self.sync_gradients()
+            self.apply_update()
+        return loss
+
+    def compute_gradients(self):
+        """one batch: sample -> forward -> backward into the flat gradient buffer; returns (loss, optimiser step due)"""
         slot = self.batch_idx % 2 if self.prefetch else 0
         self.cand, self.hist, self.hist_len = self._cand[slot], self._hist[slot], self._hist_len[slot]
         last_of_cycle = self._acc + 1 == self.accumulate
+        epoch, _, nb = self.schedule.at(self.batch_idx)
+        self.data.ensure_epoch(epoch)
         if self.prefetch:
+            self.data.ensure_epoch(self.schedule.at(self.batch_idx + 1)[0])   # on this stream, before the events below
             if self._planned_step != self.batch_idx:
                 self._prefetch(self.batch_idx)
             torch.cuda.current_stream().wait_event(self._ready[slot])
             self.engine.use_slot(slot)
         else:
             self.sample_batch()
+        self.engine.set_batch(nb)
         if self._acc == 0 and not self._grad_clean:
             self.fp.grad.zero_()
-        if self.micro == 1:
-            go = neck = None
-            if self.prefetch:
-                go, neck = self._go, self._neck
-                go.record(torch.cuda.current_stream())         # everything before this step's forward
-            _, loss = self.engine.forward(self.cand, self.hist, self.hist_len, training=True, planned=self.prefetch,
-                                          fork_ev=go, neck_ev=neck)
-            if self.prefetch:
-                self._prefetch(self.batch_idx + 1, neck)       # next batch: starts where this step's item tower ends
-            dist_on = (self.world > 1 or self.force_allreduce) and last_of_cycle
-            early = None
-            if dist_on and self.fp.split > 0 and os.environ.get("LEGO_AR_BUCKETS", "1") == "2":
-                def early():       # everything but the projection weight gradient: overlaps the last backward GEMM
-                    self._work = torch.distributed.all_reduce(self.fp.grad[:self.fp.split], group=self.pg, async_op=True)
-            self._work = None
-            if early is not None:
-                self.engine.backward(self.fp.G, before_last=early)
-            else:
-                self.engine.backward(self.fp.G)
-        else:
-            main = torch.cuda.current_stream()
-            Bm = self.B // self.micro
-            for e, st in zip(self.engines, self.streams):
-                st.wait_stream(main)
-            for phase in ("fwd", "bwd"):                       # enqueue all forwards first so every stream has work early
-                for i, (e, st) in enumerate(zip(self.engines, self.streams)):
-                    with torch.cuda.stream(st):
-                        sl = slice(i * Bm, (i + 1) * Bm)
-                        if phase == "fwd":
-                            e.forward(self.cand[sl], self.hist[sl], self.hist_len[sl], training=True)
-                        else:
-                            e.backward(self.fp.G, gloss=1.0 / self.micro)
-            for st in self.streams:
-                main.wait_stream(st)
-            loss = self.loss
-            torch.mean(torch.stack([e.loss for e in self.engines]), dim=0, out=self.loss)
+        go = neck = None
+        if self.prefetch:
+            go, neck = self._go, self._neck
+            go.record(torch.cuda.current_stream())         # everything before this step's forward
+        _, loss = self.engine.forward(self.cand, self.hist, self.hist_len, training=True, planned=self.prefetch,
+                                      fork_ev=go, neck_ev=neck)
+        if self.prefetch:
+            self._prefetch(self.batch_idx + 1, neck)       # next batch: starts where this step's item tower ends
+        self.engine.backward(self.fp.G)
         self.batch_idx += 1
         if not self.prefetch:
-            for e in self.engines:
-                self.counter_sum += e.counters
-        if not last_of_cycle:                          # gradients stay in the flat buffer for the next batch of the cycle
-            self._acc += 1
-            return loss
-        self._acc = 0
-        if self.world > 1 or self.force_allreduce:
-            if getattr(self, "_work", None) is not None:
-                torch.distributed.all_reduce(self.fp.grad[self.fp.split:], group=self.pg)   # the late tail (same RCCL stream:
-                self._work.wait()                                                           # ordered after the early part)
-                self._work = None
-            else:
-                torch.distributed.all_reduce(self.fp.grad, group=self.pg)      # one RCCL all-reduce per step
+            self.counter_sum += self.engine.counters
+        self._grad_clean = False
+        self._acc = 0 if last_of_cycle else self._acc + 1      # else: gradients stay in the buffer for the cycle's next batch
+        return loss, last_of_cycle
+
+    def apply_update(self):
+        """Adam + linear schedule over the flat buffers (gradient scaled by 1/world, then cleared)"""
         self.step_idx += 1
         call("lego_adam_step", _ptr(self.fp.flat), _ptr(self.fp.grad), _ptr(self.fp.m), _ptr(self.fp.v),
              self.fp.numel, self.lr_at(self.step_idx - 1), 0.9, 0.999, 1e-8, self.step_idx, 1.0 / self.world, 1, _stream())
         self._grad_clean = True                    # Adam cleared the gradient buffer as it consumed it
-        return loss
+
+    # ---- optimiser / scheduler state in the shape the reference checkpoints (base_lego.py:257-267)
+    def optimizer_state(self):
+        return {"m": self.fp.m.detach().cpu(), "v": self.fp.v.detach().cpu(), "step": self.step_idx, "names": list(self.fp.names),
+                "offsets": dict(self.fp.offsets), "format": "lego_flat_adam"}
+
+    def load_optimizer_state(self, st):
+        if st.get("format") != "lego_flat_adam" or st["m"].numel() != self.fp.m.numel():
+            raise ValueError("optimizer state is not a flat-Adam state of this parameter layout")
+        self.fp.m.copy_(st["m"]); self.fp.v.copy_(st["v"])
+        self.step_idx = int(st["step"])
+
+    def scheduler_state(self):
+        return {"last_epoch": self.step_idx, "total_steps": self.total_steps, "warmup": self.warmup, "base_lr": self.lr}
+
+    def load_scheduler_state(self, st):
+        self.step_idx = int(st["last_epoch"])

@@ -153,7 +153,7 @@ class Trainer:
     def __init__(self, config: Obj):
         from legommenders_amd.evaluate import Evaluator
         from legommenders_amd.loader.env import Env
-        from legommenders_amd.train_step import DeviceData, TrainStep
+        from legommenders_amd.train_step import BatchSchedule, DeviceData, TrainStep
         self.config, self.exp = config, config.exp
         config.seed = int(config.seed or 2023)
         seeding(config.seed)
@@ -178,7 +178,9 @@ class Trainer:
         self.data = DeviceData(self.world, self.device, rank=self.rank, world_size=self.world_size, seed=config.seed)
         pol = self.exp.policy
         self.B = int(pol.batch_size)
-        self.steps_per_epoch = self.data.n_rows // self.B
+        # every row of the rank's shard once per epoch, the short last batch included (DataLoader drop_last=False,
+        # manager.py:374-381); shards are equal on all ranks, so steps and schedule length agree everywhere
+        self.steps_per_epoch = BatchSchedule(self.data.n_rows, self.B, "keep").steps_per_epoch
         accumulate = int(pol.accumulate_batch or 1)                       # trainer.py:171
         Env.simple_dev = bool(pol.simple_dev)                            # base_lego.py:121
         params = {k: v.detach() for k, v in self.legommender.state_dict().items()}
@@ -211,28 +213,35 @@ class Trainer:
                 f.write(" ".join(str(x) for x in a) + "\n")
 
     def save(self):
+        """{model, optimizer, scheduler} as base_lego.py:257-267.  `model` carries the reference's state_dict keys and loads
+        there.  `optimizer` / `scheduler`: the plug-in route stores torch's own state_dicts (interchangeable with the
+        reference); the engine route stores its flat Adam moments (`format: lego_flat_adam`, with the name -> offset map) --
+        not a torch.optim.Adam state_dict, so the reference can load such a checkpoint with `model_only: true` only."""
         path = os.path.join(self.ckpt_dir, self.signature + ".pt")
-        if self.kind == "plugin":
-            torch.save({"model": {k: v.detach().cpu() for k, v in self.legommender.state_dict().items()},
-                        "optimizer": self.ts.opt.state_dict()}, path)
-        else:
-            torch.save({"model": {k: v.detach().cpu() for k, v in self.ts.fp.P.items()},
-                        "optimizer": {"m": self.ts.fp.m.cpu(), "v": self.ts.fp.v.cpu(), "step": self.ts.step_idx}}, path)
+        model = self.legommender.state_dict() if self.kind == "plugin" else self.ts.fp.P
+        torch.save({"model": {k: v.detach().cpu() for k, v in model.items()},
+                    "optimizer": self.ts.optimizer_state(), "scheduler": self.ts.scheduler_state()}, path)
         self.log("save model to", path)
 
-    def load(self, sign):
+    def load(self, sign, model_only=None):
+        """base_lego.py:240-253: model always; optimizer + scheduler unless `exp.load.model_only`."""
         path = os.path.join(self.ckpt_dir, sign + ".pt")
-        state = torch.load(path, map_location=self.device)
+        state = torch.load(path, map_location=self.device, weights_only=False)
         if self.kind == "plugin":
             self.legommender.load_state_dict(state["model"], strict=bool(self.exp.load.strict))
-            self.log("load model from", path)
-            return
-        for k, v in state["model"].items():
-            if k in self.ts.fp.P:
-                self.ts.fp.P[k].copy_(v)
-            elif self.exp.load.strict:
-                raise KeyError(k)
-        self.log("load model from", path)
+        else:
+            for k, v in state["model"].items():
+                if k in self.ts.fp.P:
+                    self.ts.fp.P[k].copy_(v)
+                elif self.exp.load.strict:
+                    raise KeyError(k)
+        model_only = bool(self.exp.load.model_only) if model_only is None else model_only
+        if not model_only:
+            if "optimizer" not in state or "scheduler" not in state:
+                raise KeyError(f"{path} holds no optimizer / scheduler state (set exp.load.model_only: true)")
+            self.ts.load_optimizer_state(state["optimizer"])
+            self.ts.load_scheduler_state(state["scheduler"])
+        self.log("load model from", path, "(model only)" if model_only else "(model + optimizer + scheduler)")
 
     def evaluate(self, split, metrics):
         rows = self.world[split]
@@ -263,7 +272,7 @@ class Trainer:
             hist = torch.empty(b, S, dtype=torch.int32, device=dev)
             hist_len = torch.empty(b, dtype=torch.int32, device=dev)
             call("lego_sample_negatives", _ptr(users, s), _ptr(items, s), _ptr(d.neg_list), _ptr(d.neg_len), d.neg_cap, b, K,
-                 d.n_items, int(self.config.seed) + 1, bi, _ptr(cand), _stream())
+                 d.n_items, int(self.config.seed) + 1, bi, 0, 1, _ptr(cand), _stream())
             call("lego_gather_history", _ptr(users, s), _ptr(d.user_hist), _ptr(d.user_hist_len), b, S, _ptr(hist),
                  _ptr(hist_len), _stream())
             if self.kind == "plugin":
@@ -341,7 +350,7 @@ class Trainer:
         if self.world_size > 1:
             torch.distributed.barrier()                        # rank 0 may still be writing the best checkpoint
         if os.path.exists(os.path.join(self.ckpt_dir, self.signature + ".pt")):
-            self.load(self.signature)                          # every rank: the test caches are built from all shards
+            self.load(self.signature, model_only=True)         # every rank: the test caches are built from all shards
         out = self.test()
         if self.world_size > 1:
             torch.distributed.barrier()

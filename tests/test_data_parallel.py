@@ -52,20 +52,72 @@ def test_two_rank_allreduce_equals_global_batch(tmp_path):
         assert float(np.abs(got[k] - g).max()) <= 2e-4 * scale + 1e-9, k
 
 
-def test_shards_partition_the_permutation():
+def test_shards_are_equal_and_partition_the_epoch_permutation():
+    """every rank owns the same number of rows (ADVICE r1: unequal shards = unequal step counts = collective mismatch);
+    the union of the shards is the epoch's permutation cut to a multiple of the world size"""
     from legommenders_amd.synthetic import make_world
-    from legommenders_amd.train_step import DeviceData
+    from legommenders_amd.train_step import BatchSchedule, DeviceData
     w = make_world(seed=3, n_items=50, n_users=40, n_rows=101, V=100)
     world = 4
     shards = [DeviceData(w, "cpu", rank=r, world_size=world, seed=11) for r in range(world)]
-    sizes = [s.n_rows for s in shards]
-    assert sum(sizes) == 101 and max(sizes) - min(sizes) <= 1
-    pairs = set()
-    for s in shards:
-        pairs |= set(zip(s.row_user.tolist(), s.row_item.tolist(), range(10**6)))  # multiset via index below
-    allrows = sorted(zip(w["row_user"].tolist(), w["row_item"].tolist()))
-    got = sorted(sum([list(zip(s.row_user.tolist(), s.row_item.tolist())) for s in shards], []))
-    assert got == allrows
+    assert {s.n_rows for s in shards} == {101 // world}
+    assert len({BatchSchedule(s.n_rows, 13, "keep").steps_per_epoch for s in shards}) == 1       # N=101, W=4, B=13 (ADVICE)
+    for epoch in (0, 1, 5):
+        perm = shards[0].epoch_permutation(epoch)
+        assert all(torch.equal(perm, s.epoch_permutation(epoch)) for s in shards)                # same on every rank
+        kept = perm[: (101 // world) * world]
+        idx = [s.shard_of(epoch) for s in shards]
+        inter = torch.stack(idx, 1).reshape(-1)              # rank r holds positions r::world
+        assert torch.equal(inter, kept)
+        for s, i in zip(shards, idx):
+            ru, ri = s.rows(epoch)
+            assert ru.tolist() == w["row_user"][i.numpy()].tolist() and ri.tolist() == w["row_item"][i.numpy()].tolist()
+    # reshuffle: consecutive epochs visit the rows in different orders, and an epoch covers every kept row once
+    p0, p1 = shards[0].epoch_permutation(0), shards[0].epoch_permutation(1)
+    assert not torch.equal(p0, p1) and sorted(p0.tolist()) == sorted(p1.tolist()) == list(range(101))
+    # the global batch of step s is what ONE device with batch W*B takes: perm[s*W*B:(s+1)*W*B]
+    one = DeviceData(w, "cpu", rank=0, world_size=1, seed=11)
+    B = 5
+    for s_ in range(3):
+        glob = one.shard_of(0)[s_ * world * B:(s_ + 1) * world * B]
+        parts = torch.stack([s.shard_of(0)[s_ * B:(s_ + 1) * B] for s in shards], 1).reshape(-1)   # position b*W + r
+        assert torch.equal(parts, glob)
+
+
+def test_batch_schedule_keeps_the_short_last_batch():
+    """DataLoader(shuffle=True, drop_last=False) (manager.py:374-381): ceil(n/B) batches per epoch, the last one short"""
+    from legommenders_amd.train_step import BatchSchedule
+    s = BatchSchedule(25, 8, "keep")
+    assert s.steps_per_epoch == 4
+    assert [s.at(i) for i in range(9)] == [(0, 0, 8), (0, 8, 8), (0, 16, 8), (0, 24, 1), (1, 0, 8), (1, 8, 8), (1, 16, 8),
+                                          (1, 24, 1), (2, 0, 8)]
+    d = BatchSchedule(25, 8, "drop")
+    assert d.steps_per_epoch == 3 and d.at(3) == (1, 0, 8)
+    assert BatchSchedule(24, 8, "keep").steps_per_epoch == 3
+    assert BatchSchedule(5, 8, "keep").at(0) == (0, 0, 5)
+
+
+def _sync_worker(rank, world, port, out_dir):
+    """TrainStep.sync_gradients itself (not a copy of it) over gloo, single buffer and bucket train"""
+    from legommenders_amd.train_step import FlatParams, TrainStep
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    P = {"a": torch.zeros(7, 5), "b": torch.zeros(33), "embedding_vocab_table.glove.weight": torch.zeros(50, 8)}
+    for buckets in (1 << 30, 64 * 4):              # one all-reduce; a train of 64-float buckets
+        ts = TrainStep.__new__(TrainStep)
+        ts.fp = FlatParams(P, (), "cpu", last=("embedding_vocab_table.glove.weight",))
+        ts.pg, ts.world, ts.force_allreduce, ts.BUCKET_BYTES = dist.group.WORLD, world, False, buckets
+        g = torch.Generator().manual_seed(100 + rank)
+        ts.fp.grad.copy_(torch.randn(ts.fp.numel, generator=g))
+        ts.sync_gradients()
+        want = sum(torch.randn(ts.fp.numel, generator=torch.Generator().manual_seed(100 + r)) for r in range(world))
+        assert torch.allclose(ts.fp.grad, want, atol=1e-6), (rank, buckets)
+        assert ts.fp.split == ts.fp.offsets["embedding_vocab_table.glove.weight"] > 0      # the table is last in the buffer
+    dist.destroy_process_group()
+
+
+def test_train_step_sync_gradients_over_gloo():
+    world, port = 2, _free_port()
+    mp.spawn(_sync_worker, args=(world, port, ""), nprocs=world, join=True)
 
 
 def test_linear_schedule_matches_oracle():

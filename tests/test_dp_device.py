@@ -1,0 +1,180 @@
+"""Data-parallel contract on the device:
+
+  * rank r of W draws, for its b-th row, exactly what ONE device with batch W*B draws for global row b*W + r
+    (negatives keyed on the global position), while the dropout keep bits of different ranks differ;
+  * W ranks x B rows, gradients summed and scaled by 1/W, follow the same parameter trajectory as one device with W*B rows
+    -- first with the exchange done in-process, then through TrainStep.step() itself in two processes that share
+    the GPU and all-reduce over gloo (RCCL refuses two ranks on one device; the N > 1 RCCL run is the driver's);
+  * every epoch visits the rank's shard once, reshuffled, the short last batch included.
+"""
+import ctypes
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _world(n_rows=203):
+    from legommenders_amd.synthetic import make_world
+    return make_world(seed=21, n_items=500, n_users=200, n_rows=n_rows, V=3000)
+
+
+def test_rank_streams_differ_and_union_is_the_single_device_draw():
+    from legommenders_amd._lib import LegoDropout, call
+    from legommenders_amd.engine import _ptr, _stream
+    from legommenders_amd.synthetic import init_naml_params
+    from legommenders_amd.train_step import DeviceData, TrainStep
+    dev, w, W, B = _dev(), _world(), 2, 8
+    P = init_naml_params(D=64, A=64, V=3000, seed=5)
+    ranks = [TrainStep("naml", P, DeviceData(w, dev, rank=r, world_size=W, seed=9), B, seed=9, world_size=W) for r in range(W)]
+    one = TrainStep("naml", P, DeviceData(w, dev, seed=9), W * B, seed=9)
+    for batch_idx in (0, 3, one.steps_per_epoch + 1):                  # incl. a batch of the reshuffled second epoch
+        for t in ranks + [one]:
+            assert t.sample_batch(batch_idx, slot=0) == t.B
+        torch.cuda.synchronize()
+        g_c, g_h, g_l = one._cand[0].cpu(), one._hist[0].cpu(), one._hist_len[0].cpu()
+        for r, t in enumerate(ranks):
+            assert torch.equal(t._cand[0].cpu(), g_c[r::W]), (batch_idx, r)      # same positives AND the same negatives
+            assert torch.equal(t._hist[0].cpu(), g_h[r::W]) and torch.equal(t._hist_len[0].cpu(), g_l[r::W])
+        assert not torch.equal(ranks[0]._cand[0].cpu(), ranks[1]._cand[0].cpu())
+    # dropout: keep bits of the same (site, step, local row) differ between the ranks, same rate
+    assert ranks[0].engine.seed != ranks[1].engine.seed and ranks[0].engine.seed == one.engine.seed
+    rows, cols = 4096, 64
+    masks = []
+    for t in ranks:
+        m = torch.zeros(rows // 4 * cols + 1, dtype=torch.uint8, device=dev)
+        call("lego_dropout_mask", ctypes.byref(LegoDropout(0.1, t.engine.seed, 0, None)), rows, None, cols, _ptr(m), _stream())
+        masks.append(m[:-1].cpu().numpy())
+    assert (masks[0] != masks[1]).mean() > 0.2
+    for m in masks:
+        keep = np.unpackbits(m[:, None], axis=1)[:, 4:].mean()
+        assert abs(keep - 0.9) < 0.01
+
+
+def _trajectory_single(kind, P, w, dev, B, steps, seed=9, **kw):
+    from legommenders_amd.train_step import DeviceData, TrainStep
+    one = TrainStep(kind, P, DeviceData(w, dev, seed=seed), B, seed=seed, dropout=False, total_steps=50, **kw)
+    losses = [float(one.step()) for _ in range(steps)]
+    return one.fp, losses
+
+
+@pytest.mark.parametrize("kind", ["naml", "nrms"])
+def test_two_ranks_follow_the_single_device_trajectory(kind):
+    """exchange emulated in-process: grad_0 + grad_1 on both ranks, then Adam with 1/W"""
+    from legommenders_amd.synthetic import init_naml_params, init_nrms_params
+    from legommenders_amd.train_step import DeviceData, TrainStep
+    dev, w, W, B, steps = _dev(), _world(), 2, 8, 15               # 203 rows -> 101 per rank: 13 batches/epoch, the last of 5
+    P = init_naml_params(D=64, A=64, V=3000, seed=5) if kind == "naml" else init_nrms_params(D=64, A=64, V=3000, seed=5, glove=None)
+    kw = dict(glove=False) if kind == "nrms" else {}
+    ranks = [TrainStep(kind, P, DeviceData(w, dev, rank=r, world_size=W, seed=9), B, seed=9, world_size=W, dropout=False,
+                       total_steps=50, **kw) for r in range(W)]
+    rank_losses = []
+    for _ in range(steps):
+        ls = [t.compute_gradients()[0].clone() for t in ranks]
+        total = ranks[0].fp.grad + ranks[1].fp.grad                # what all_reduce(sum) leaves on every rank
+        for t in ranks:
+            t.fp.grad.copy_(total)
+            t.apply_update()
+        rank_losses.append(float(sum(ls)) / W)
+    # 203 rows: one device keeps all of them, two ranks keep 202 -- the 12 whole global batches of the first epoch are the same
+    # rows in both layouts, so the mean losses along the way (which depend on every earlier update) must agree
+    fp1, losses = _trajectory_single(kind, P, w, dev, W * B, steps, **kw)
+    assert torch.equal(ranks[0].fp.flat, ranks[1].fp.flat)
+    np.testing.assert_allclose(rank_losses[:12], losses[:12], rtol=5e-5)
+
+
+def test_two_ranks_equal_single_device_parameters_whole_batches():
+    """an even row count, so both layouts see identical rows in every step, short last batch included: parameters after two
+    epochs agree to fp32 summation-order noise"""
+    from legommenders_amd.synthetic import init_naml_params
+    from legommenders_amd.train_step import DeviceData, TrainStep
+    dev, W, B = _dev(), 2, 8
+    w = _world(n_rows=202)
+    P = init_naml_params(D=64, A=64, V=3000, seed=5)
+    ranks = [TrainStep("naml", P, DeviceData(w, dev, rank=r, world_size=W, seed=9), B, seed=9, world_size=W, dropout=False,
+                       total_steps=50) for r in range(W)]
+    steps = 2 * ranks[0].steps_per_epoch
+    assert ranks[0].steps_per_epoch == 13 and ranks[0].schedule.at(12) == (0, 96, 5)
+    for _ in range(steps):
+        for t in ranks:
+            t.compute_gradients()
+        total = ranks[0].fp.grad + ranks[1].fp.grad
+        for t in ranks:
+            t.fp.grad.copy_(total)
+            t.apply_update()
+    fp1, _ = _trajectory_single("naml", P, w, dev, W * B, steps)
+    for k in fp1.names:
+        a, b = fp1.P[k], ranks[0].fp.P[k]
+        assert float((a - b).abs().max()) <= 2e-4 * float(a.abs().max()) + 1e-7, k
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gloo_rank(rank, world, port, out_dir, steps):
+    import torch.distributed as dist
+    from legommenders_amd.synthetic import init_naml_params
+    from legommenders_amd.train_step import DeviceData, TrainStep
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    w = _world(n_rows=202)
+    P = init_naml_params(D=64, A=64, V=3000, seed=5)
+    ts = TrainStep("naml", P, DeviceData(w, dev, rank=rank, world_size=world, seed=9), 8, seed=9, world_size=world,
+                   process_group=dist.group.WORLD, dropout=False, total_steps=50)
+    for _ in range(steps):
+        ts.step()                                                    # the product's own step, all-reduce included
+    torch.cuda.synchronize()
+    torch.save({k: v.cpu() for k, v in ts.fp.P.items()}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_train_step_two_processes_on_one_gpu_over_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    from legommenders_amd.synthetic import init_naml_params
+    steps = 15
+    mp.get_context("spawn")
+    mp.spawn(_gloo_rank, args=(2, _free_port(), str(tmp_path), steps), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), f"rank{r}.pt")) for r in range(2))
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), k                          # replicas stay bit-identical
+    dev = _dev()
+    P = init_naml_params(D=64, A=64, V=3000, seed=5)
+    fp1, _ = _trajectory_single("naml", P, _world(n_rows=202), dev, 16, steps)
+    for k in fp1.names:
+        a, b = fp1.P[k].cpu(), r0[k]
+        assert float((a - b).abs().max()) <= 2e-4 * float(a.abs().max()) + 1e-7, k
+
+
+def test_epoch_visits_every_row_once_and_reshuffles():
+    from legommenders_amd.synthetic import init_naml_params
+    from legommenders_amd.train_step import DeviceData, TrainStep
+    dev, w = _dev(), _world(n_rows=100)
+    P = init_naml_params(D=64, A=64, V=3000, seed=5)
+    ts = TrainStep("naml", P, DeviceData(w, dev, seed=4), 16, seed=4)
+    assert ts.steps_per_epoch == 7
+    seen, last = [], None
+    for e in range(2):
+        pos = []
+        for k in range(ts.steps_per_epoch):
+            nb = ts.schedule.at(ts.batch_idx)[2]
+            last = ts.step()
+            pos += ts.cand[:nb, 0].cpu().tolist()
+        seen.append(pos)
+    want = sorted(w["row_item"].tolist())
+    assert sorted(seen[0]) == want and sorted(seen[1]) == want and seen[0] != seen[1]
+    assert ts.step_idx == 14 and np.isfinite(float(last))

@@ -273,12 +273,14 @@ def test_train_step_runs_and_updates():
     # negatives obey the sampler contract of the reference (resampler.py:159-171)
     from oracle import lego_oracle as O
     cand = ts.cand.cpu().numpy()
-    start = ((ts.step_idx - 1) * 16) % max(1, ts.data.n_rows - 16 + 1)
-    users = ts.data.row_user[start:start + 16].cpu().numpy()
+    epoch, start, nb = ts.schedule.at(ts.batch_idx - 1)
+    row_user, row_item = ts.data.rows(epoch)
+    users = row_user[start:start + 16].cpu().numpy()
+    assert nb == 16
     for b in range(16):
         negs = w["neg_list"][users[b], : w["neg_len"][users[b]]].tolist()
         assert O.sample_negatives_semantics(cand[b].tolist(), negs, w["n_items"], K=4)
-        assert cand[b, 0] == ts.data.row_item[start + b].item()
+        assert cand[b, 0] == row_item[start + b].item()
 
 
 @pytest.mark.parametrize("name", ["naml_glove_d64", "nrms_null_d64"])
