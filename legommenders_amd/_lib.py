@@ -130,9 +130,39 @@ def call(name: str, *args) -> None:
         raise LegoHipError(f"{name}: {handle.lego_last_error().decode(errors='replace')}")
 
 
-def declared_symbols():
-    """Function names declared in include/lego_hip.h (used by the CPU-side ABI test)."""
+def _header_text():
     import re
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(lego_[a-z0-9_]+)\s*\(", text)))
+    return re.sub(r"//[^\n]*", "", text)
+
+
+def declared_symbols():
+    """Function names declared in include/lego_hip.h (used by the CPU-side ABI test)."""
+    import re
+    return sorted(set(re.findall(r"\b(lego_[a-z0-9_]+)\s*\(", _header_text())))
+
+
+_C_KINDS = {"int": I, "int32_t": I, "float": F, "int64_t": I64, "uint64_t": U64, "uint32_t": U32}
+
+
+def declared_prototypes():
+    """name -> (restype token, [ctypes kind per parameter]) parsed from include/lego_hip.h: every pointer parameter is
+    c_void_p, scalars by their C type.  tests/test_abi.py holds SIGNATURES to this, so a changed argument list in the
+    header (or in the binding) fails on the CPU, not as a crash in a GPU test."""
+    import re
+    out = {}
+    for ret, name, args in re.findall(r"\b(int|const\s+char\s*\*)\s+(lego_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", _header_text()):
+        kinds = []
+        for a in (x.strip() for x in args.split(",")):
+            if not a or a == "void":
+                continue
+            if "*" in a:
+                kinds.append(P)
+                continue
+            toks = [t for t in re.split(r"\s+", a) if t not in ("const", "unsigned")]
+            if toks[0] not in _C_KINDS:
+                raise LegoHipError(f"{name}: cannot classify parameter {a!r}")
+            kinds.append(_C_KINDS[toks[0]])
+        out[name] = (ret, kinds)
+    return out

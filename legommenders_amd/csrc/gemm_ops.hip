@@ -242,11 +242,11 @@ static int num_cus() {
 }
 
 // one block per CU, each a strip of ceil(M / #CU) rows x all N <= 256 columns (gemm_strip.hpp)
-template <bool B_MC, class EK, class AL, class BL, int DBG = 0>
+template <bool B_MC, class EK, class AL, class BL>
 static int launch_strip(const GemmDims& d, const AL& a, const BL& b, const Epi& e0, hipStream_t st, const char* what) {
     EK e;
     static_cast<EpiArgs&>(e) = e0;
-    auto k = strip_kernel<B_MC, AL, BL, EK, DBG>;
+    auto k = strip_kernel<B_MC, AL, BL, EK>;
     constexpr size_t lds = strip_lds_bytes<B_MC>();
     static bool attr_done = false;
     if (!attr_done) {
@@ -279,9 +279,8 @@ template <bool B_MC, class EK, class AL, class BL>
 static int launch_rows(const GemmDims& d, const AL& a, const BL& b, const Epi& e, hipStream_t st, const char* what) {
     const int tm = (d.M + 127) / 128;
     if (d.M >= 32 * num_cus() && d.N <= 4 * STRIP_BN) return launch_strip<B_MC, EK>(d, a, b, e, st, what);
-    static const bool oneshot_on = !(getenv("LEGO_ONESHOT") && atoi(getenv("LEGO_ONESHOT")) == 0);
     if constexpr (std::is_same<AL, KcRows>::value)
-        if (oneshot_on && d.K <= ONE_KMAX && d.K % 4 == 0 &&
+        if (d.K <= ONE_KMAX && d.K % 4 == 0 &&
             ((d.M + ONE_BM - 1) / ONE_BM) * ((d.N + ONE_BN - 1) / ONE_BN) <= num_cus())     // one round of whole-CU blocks
             return launch_oneshot<B_MC, EK>(d, a, b, e, st, what);
     if (tm * ((d.N + 127) / 128) < 128) {         // few row tiles (user / category side): 64-row tiles fill more CUs
@@ -298,8 +297,7 @@ static int launch_rows(const GemmDims& d, const AL& a, const BL& b, const Epi& e
 template <class AL, class BL>
 static int launch_tn(const GemmDims& d, const AL& a, const BL& b, const Epi& e, int taps, hipStream_t st, const char* what) {
     const int gz = taps * d.split_k;
-    static const bool all_big = getenv("LEGO_TN_TILE") && atoi(getenv("LEGO_TN_TILE")) == 128;
-    if ((taps > 1 || all_big) && d.M > 64 && d.N > 64)
+    if (taps > 1 && d.M > 64 && d.N > 64)
         return launch<C128x128, true, true, EpiAtomic>(d, a, b, e, (d.M + 127) / 128, (d.N + 127) / 128, gz, st, what);
     return launch<C64x64, true, true, EpiAtomic>(d, a, b, e, (d.M + 63) / 64, (d.N + 63) / 64, gz, st, what);
 }
@@ -307,13 +305,10 @@ static int launch_tn(const GemmDims& d, const AL& a, const BL& b, const Epi& e, 
 static int pick_split(int rows_cap, int M, int N, int taps) {
     // plain products: ~1024 blocks of 64 x 64 (4 x 32 KB of LDS per CU); conv: two rounds of 128 x 128 blocks;
     // at least 128 reduction rows per block
-    static const bool all_big = getenv("LEGO_TN_TILE") && atoi(getenv("LEGO_TN_TILE")) == 128;
-    const bool big = (taps > 1 || all_big) && M > 64 && N > 64;
+    const bool big = taps > 1 && M > 64 && N > 64;
     const int t = big ? 128 : 64;
     const int tiles = ((M + t - 1) / t) * ((N + t - 1) / t) * taps;
-    static const int big_blocks = getenv("LEGO_TN_BIG") ? atoi(getenv("LEGO_TN_BIG")) : 512;
-    static const int small_blocks = getenv("LEGO_TN_SMALL") ? atoi(getenv("LEGO_TN_SMALL")) : 1024;
-    int s = (big ? big_blocks : small_blocks) / tiles;
+    int s = (big ? 512 : 1024) / tiles;
     const int max_s = (rows_cap + 127) / 128;
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
@@ -491,6 +486,7 @@ extern "C" int lego_conv3_wino_bwd_weight(const float* gy, int ldg, const float*
     return launch_tn(d, a, b, e, 4, (hipStream_t)stream, "lego_conv3_wino_bwd_weight");
 }
 
+#ifdef LEGO_TUNING_HOOKS   // `make tune` only (liblego_hip_tune.so, tools/*_variants.py): never in the product library
 // ---- internal tuning hook (not part of the public ABI): plain NT product with a selectable tile config
 extern "C" int lego_debug_gemm_nt(int variant, const float* x, const float* W, const float* bias, float* out,
                                   int M, int N, int K, void* stream) {
@@ -511,8 +507,6 @@ extern "C" int lego_debug_gemm_nt(int variant, const float* x, const float* W, c
         case 7: return launch<TileCfg<128, 128, 4, 2, true>, false, false, EpiPlain>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, 1, st, "dbg7");
         case 8: return launch<TileCfg<128, 128, 2, 4, true>, false, false, EpiPlain>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, 1, st, "dbg8");
         case 9: return launch_strip<false, EpiPlain>(d, a, b, e, st, "dbg9");
-        case 10: return launch_strip<false, EpiPlain, KcRows, KcRows, 1>(d, a, b, e, st, "dbg10");
-        case 11: return launch_strip<false, EpiPlain, KcRows, KcRows, 3>(d, a, b, e, st, "dbg11");
         default: return set_error("lego_debug_gemm_nt: unknown variant %d", variant);
     }
 }
@@ -533,3 +527,4 @@ extern "C" int lego_debug_gemm_tn(int variant, int split, const float* g, const 
         default: return set_error("lego_debug_gemm_tn: unknown variant %d", variant);
     }
 }
+#endif

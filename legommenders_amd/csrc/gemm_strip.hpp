@@ -38,7 +38,7 @@ __host__ __device__ inline StripPlan strip_plan(int M, int G) {
     return {s, sub, sub / 16};
 }
 
-template <int NF, bool B_MC, int DBG, class ALoad, class BLoad, class Epi>
+template <int NF, bool B_MC, class ALoad, class BLoad, class Epi>
 __device__ __forceinline__ void strip_pass(const ALoad& la0, const BLoad& lb0, Epi& epi, float* As0, float* Bs0,
                                            const typename BLoad::Row (&rb)[4], int m0, int m_end, int n0, int K) {
     constexpr int NT = STRIP_THREADS, BN = STRIP_BN;
@@ -134,17 +134,15 @@ __device__ __forceinline__ void strip_pass(const ALoad& la0, const BLoad& lb0, E
         const float* B_ = Bs0 + buf * B_FLOATS;
         float* An = As0 + (buf ^ 1) * A_FLOATS;
         float* Bn = Bs0 + (buf ^ 1) * B_FLOATS;
-        if (!(DBG & 2) || k0 == 0) read_frags(A_, B_, 1, fa1, fb1);
+        read_frags(A_, B_, 1, fa1, fb1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) mfma_j(fa0, fb0, j);
-        if (!(DBG & 1)) {
-            commit(An, Bn);                 // unconditional: past the end this writes the unused buffer
-            fetch(k0 + 2 * BK);
-        }
+        commit(An, Bn);                     // unconditional: past the end this writes the unused buffer
+        fetch(k0 + 2 * BK);
 #pragma unroll
         for (int j = 0; j < 3; ++j) mfma_j(fa1, fb1, j);
         __syncthreads();
-        if (!(DBG & 2)) read_frags(An, Bn, 0, fa0, fb0);
+        read_frags(An, Bn, 0, fa0, fb0);
         mfma_j(fa1, fb1, 3);
         buf ^= 1;
     }
@@ -153,7 +151,7 @@ __device__ __forceinline__ void strip_pass(const ALoad& la0, const BLoad& lb0, E
     epi.template run16<NF>(acc, m0, m_end, n0 + wave * 32, l16, g4);
 }
 
-template <bool B_MC, class ALoad, class BLoad, class Epi, int DBG = 0>
+template <bool B_MC, class ALoad, class BLoad, class Epi>
 __global__ __launch_bounds__(STRIP_THREADS) void strip_kernel(GemmDims dims, ALoad la, BLoad lb, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const As0 = smem;
@@ -184,11 +182,11 @@ __global__ __launch_bounds__(STRIP_THREADS) void strip_kernel(GemmDims dims, ALo
         const int m_end = min(strip_end, m0 + sp.sub);
         const int nf = (m_end - m0 + 15) >> 4;              // block-uniform
         switch (nf) {
-            case 1: case 2: strip_pass<2, B_MC, DBG>(la, lb, epi, As0, Bs0, rb, m0, m_end, n0, K); break;
-            case 3: case 4: strip_pass<4, B_MC, DBG>(la, lb, epi, As0, Bs0, rb, m0, m_end, n0, K); break;
-            case 5: case 6: strip_pass<6, B_MC, DBG>(la, lb, epi, As0, Bs0, rb, m0, m_end, n0, K); break;
-            case 7: strip_pass<7, B_MC, DBG>(la, lb, epi, As0, Bs0, rb, m0, m_end, n0, K); break;
-            default: strip_pass<8, B_MC, DBG>(la, lb, epi, As0, Bs0, rb, m0, m_end, n0, K); break;
+            case 1: case 2: strip_pass<2, B_MC>(la, lb, epi, As0, Bs0, rb, m0, m_end, n0, K); break;
+            case 3: case 4: strip_pass<4, B_MC>(la, lb, epi, As0, Bs0, rb, m0, m_end, n0, K); break;
+            case 5: case 6: strip_pass<6, B_MC>(la, lb, epi, As0, Bs0, rb, m0, m_end, n0, K); break;
+            case 7: strip_pass<7, B_MC>(la, lb, epi, As0, Bs0, rb, m0, m_end, n0, K); break;
+            default: strip_pass<8, B_MC>(la, lb, epi, As0, Bs0, rb, m0, m_end, n0, K); break;
         }
     }
 }

@@ -1130,7 +1130,7 @@ extern "C" int lego_additive_pool_bwd(float* t_dpre, int ldt, const float* x, in
     LEGO_REQUIRE((D & 3) == 0 && (A & 3) == 0 && D <= 256 * kMaxChunks && A <= 256 * kMaxChunks,
                  "lego_additive_pool_bwd: D=%d A=%d must be multiples of 4 and <= %d", D, A, 256 * kMaxChunks);
     if (n_cap <= 0) return 0;
-    static const int cap = getenv("LEGO_POOLB_BLOCKS") ? atoi(getenv("LEGO_POOLB_BLOCKS")) : 1024;
+    const int cap = 1024;
     int blocks = n_cap;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(additive_pool_bwd_kernel, dim3(blocks), dim3(256), 0, ST, t_dpre, ldt, x, ldx, w2, seg_off, extra_off_dyn,

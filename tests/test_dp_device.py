@@ -67,6 +67,19 @@ def _trajectory_single(kind, P, w, dev, B, steps, seed=9, **kw):
     return one.fp, losses
 
 
+def _same_trajectory(A, Bp, init, names, steps, lr=1e-3):
+    """two runs of the same training differ only by fp32 summation order (split-K / scatter atomics, ragged row order).
+    Adam turns a gradient that is pure rounding noise into a step of up to lr whatever its size, so single elements may
+    drift by a few lr; the bar is on the distance travelled: the runs' difference is below 1 % of the parameter's own
+    movement (Frobenius), and no element differs by more than 10 % of the largest possible movement lr * steps."""
+    for k in names:
+        a, b, p0 = A[k].float().cpu(), Bp[k].float().cpu(), init[k].float().cpu()
+        moved = float((a - p0).norm())
+        assert moved > 0, k
+        assert float((a - b).norm()) <= 1e-2 * moved, (k, float((a - b).norm()), moved)
+        assert float((a - b).abs().max()) <= 0.1 * lr * steps, k
+
+
 @pytest.mark.parametrize("kind", ["naml", "nrms"])
 def test_two_ranks_follow_the_single_device_trajectory(kind):
     """exchange emulated in-process: grad_0 + grad_1 on both ranks, then Adam with 1/W"""
@@ -112,9 +125,7 @@ def test_two_ranks_equal_single_device_parameters_whole_batches():
             t.fp.grad.copy_(total)
             t.apply_update()
     fp1, _ = _trajectory_single("naml", P, w, dev, W * B, steps)
-    for k in fp1.names:
-        a, b = fp1.P[k], ranks[0].fp.P[k]
-        assert float((a - b).abs().max()) <= 2e-4 * float(a.abs().max()) + 1e-7, k
+    _same_trajectory(fp1.P, ranks[0].fp.P, P, fp1.names, steps)
 
 
 def _free_port():
@@ -155,9 +166,7 @@ def test_train_step_two_processes_on_one_gpu_over_gloo(tmp_path):
     dev = _dev()
     P = init_naml_params(D=64, A=64, V=3000, seed=5)
     fp1, _ = _trajectory_single("naml", P, _world(n_rows=202), dev, 16, steps)
-    for k in fp1.names:
-        a, b = fp1.P[k].cpu(), r0[k]
-        assert float((a - b).abs().max()) <= 2e-4 * float(a.abs().max()) + 1e-7, k
+    _same_trajectory({k: v.cpu() for k, v in fp1.P.items()}, r0, P, fp1.names, steps)
 
 
 def test_epoch_visits_every_row_once_and_reshuffles():

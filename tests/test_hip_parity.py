@@ -427,6 +427,30 @@ def test_fused_user_tower_matches_unfused():
     _grads_close(g_fused, G, "fused")
 
 
+@pytest.mark.parametrize("env", [{"LEGO_SERIAL": "1"}, {"LEGO_WINO": "0"}, {"LEGO_SERIAL": "1", "LEGO_WINO": "0"}])
+def test_switches_keep_the_result(env, monkeypatch):
+    """the two environment switches the product still reads (tools/README.md): single-stream launch order for profiling and
+    the direct three-tap conv instead of the Winograd form -- same logits, loss and gradients as the reference fixture"""
+    from legommenders_amd.engine import ItemTables, NamlEngine
+    dev = _dev()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    meta, P, G, tables, batch, logits, loss = load_model_fixture("naml_glove_cfg1")
+    Pd = {k: torch.tensor(v).to(dev).contiguous() for k, v in P.items()}
+    tb = ItemTables(tables["title_tok"], tables["title_len"], tables["cat"], dev)
+    B, C = batch["cand"].shape
+    ids = [torch.tensor(batch[k]).int().to(dev).contiguous() for k in ("cand", "hist", "hist_len")]
+    eng = NamlEngine(Pd, tb, B, C, batch["hist"].shape[1], p_proj=0.0, p_conv=0.0)
+    assert eng.wino == ("LEGO_WINO" not in env)
+    g = eng.grads_like()
+    scores, l = eng.forward(*ids, training=True)
+    eng.backward(g)
+    torch.cuda.synchronize()
+    _close(scores.cpu(), logits, rtol=1e-4, atol=2e-5, what="logits")
+    assert abs(float(l) - loss) < 2e-5
+    _grads_close(g, G, str(env))
+
+
 def test_precomputed_dropout_mask_equals_in_kernel_draw():
     """lego_dropout_mask writes the keep bits the epilogues would draw: a product run with the mask is bit-identical
     to the same product drawing Philox in the kernel (strip GEMM, small-tile GEMM and the Winograd conv)."""

@@ -1,5 +1,7 @@
 import sys, os, ctypes, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# tile-variant hooks live in the tuning build only: `make -C legommenders_amd/csrc tune`
+os.environ.setdefault('LEGO_HIP_LIB', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'legommenders_amd', 'csrc', 'liblego_hip_tune.so'))
 from legommenders_amd import _lib
 L = _lib.lib()
 P, I = ctypes.c_void_p, ctypes.c_int
@@ -14,11 +16,11 @@ def bench(fn, n=20):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-names = {0: "128x128 4w(2x2)", 1: "128x128 8w(2x4)", 2: "256x128 8w(4x2)", 3: "128x256 8w(2x4)", 4: "64x128 4w(1x4)", 5: "128x128 8w(4x2)", 6: "64x256 4w(1x4)", 7: "128x128 8w(4x2) stag", 8: "128x128 8w(2x4) stag", 9: "strip 16x16x4", 10: "strip no-global", 11: "strip mfma-only"}
+names = {0: "128x128 4w(2x2)", 1: "128x128 8w(2x4)", 2: "256x128 8w(4x2)", 3: "128x256 8w(2x4)", 4: "64x128 4w(1x4)", 5: "128x128 8w(4x2)", 6: "64x256 4w(1x4)", 7: "128x128 8w(4x2) stag", 8: "128x128 8w(2x4) stag", 9: "strip 16x16x4"}
 for (M, N, Kd) in [(26368, 256, 768), (24000, 256, 768), (28672, 256, 768), (32768, 256, 768), (65536, 256, 768), (26368, 256, 256), (26368, 256, 300), (26368, 200, 256), (1000, 256, 768), (26368+5, 240, 96), (3200, 200, 256), (3200, 256, 256), (3520, 256, 256), (6400, 256, 256)]:
     x = torch.randn(M, Kd, device=dev); W = torch.randn(N, Kd, device=dev) * 0.05; b = torch.randn(N, device=dev)
     ref = x @ W.T + b
-    for v in ((9, 10, 11) if os.environ.get('STRIP_ABLATE') else (9,)):
+    for v in (9,):
         y = torch.zeros(M, N, device=dev)
         def run():
             rc = L.lego_debug_gemm_nt(v, x.data_ptr(), W.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, Kd, None)

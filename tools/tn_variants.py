@@ -1,5 +1,7 @@
 import sys, os, ctypes, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# tile-variant hooks live in the tuning build only: `make -C legommenders_amd/csrc tune`
+os.environ.setdefault('LEGO_HIP_LIB', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'legommenders_amd', 'csrc', 'liblego_hip_tune.so'))
 from legommenders_amd import _lib
 L = _lib.lib()
 P, I = ctypes.c_void_p, ctypes.c_int
