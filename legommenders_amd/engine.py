@@ -130,6 +130,21 @@ class _Base:
         e1.record()
         t.setdefault(tag, []).append((e0, e1))
 
+    @staticmethod
+    def _sp(stream):
+        return ctypes.c_void_p(stream.cuda_stream)
+
+    def kk(self, stream, tag, name, *args):
+        """launch on `stream`; with timers on, bracket the launch with HIP events on that same stream"""
+        t = self.timers
+        if t is None or tag is None:
+            return call(name, *args, self._sp(stream))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        call(name, *args, self._sp(stream))
+        e1.record(stream)
+        t.setdefault(tag, []).append((e0, e1))
+
     def cnt(self, k):
         """device pointer to counters[k] (0 = token rows R, 1 = instances NI, 2 = R+NI, 3 = history instances)"""
         return _ptr(self.counters, k)
@@ -268,9 +283,12 @@ class NamlEngine(_Base):
     def gather_tokens(self, stream=None, into=None):
         """k1: X[r, :] = glove[row_tok[r], :] for the planned token rows (embedding_hub.py:95, frozen table)"""
         b = self.__dict__ if into is None else into
-        st = _stream() if stream is None else ctypes.c_void_p(stream.cuda_stream)
-        call("lego_gather_rows", _ptr(self.P["embedding_vocab_table.glove.embedding.weight"]), self.E0, self.E0,
-             _ptr(b["row_tok"]), self.Rc, _ptr(b["counters"], 0), _ptr(b["X"]), self.E0, 0, st)
+        s = torch.cuda.current_stream() if stream is None else stream
+        # with timers on (bench.py) the launch is bracketed by HIP events on the stream it runs on: on the prefetch stream
+        # that is the gather's duration INSIDE the step, overlapped with the previous step's user-side chain
+        self.kk(s, "gather_rows_in_step" if stream is not None else "gather_rows", "lego_gather_rows",
+                _ptr(self.P["embedding_vocab_table.glove.embedding.weight"]), self.E0, self.E0,
+                _ptr(b["row_tok"]), self.Rc, _ptr(b["counters"], 0), _ptr(b["X"]), self.E0, 0)
 
     def plan_pairs(self, stream=None, into=None):
         """row pairs of the Winograd conv from the plan's seg_off; the pair count lands in counters[5]"""
@@ -298,10 +316,6 @@ class NamlEngine(_Base):
             return m, m, m
         return m, self._side[0], self._side[1]
 
-    @staticmethod
-    def _sp(stream):
-        return ctypes.c_void_p(stream.cuda_stream)
-
     def _fork(self, ev, src, *dst):
         dst = [d for d in dst if d is not src]
         if not dst:
@@ -309,17 +323,6 @@ class NamlEngine(_Base):
         ev.record(src)
         for d in dst:
             d.wait_event(ev)
-
-    def kk(self, stream, tag, name, *args):
-        """launch on `stream`; with timers on, bracket the launch with HIP events on that same stream"""
-        t = self.timers
-        if t is None or tag is None:
-            return call(name, *args, self._sp(stream))
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        call(name, *args, self._sp(stream))
-        e1.record(stream)
-        t.setdefault(tag, []).append((e0, e1))
 
     # ------------------------------------------------------------------ forward
     def forward(self, cand, hist, hist_len, training=False, with_loss=True, planned=False, gloss=1.0, fork_ev=None,
@@ -593,19 +596,21 @@ class NrmsEngine(_Base):
     def _att_fwd(self, pre, ws, x_ptr, rows_dyn, seg_off, n_cap, n_dyn, out, site, training, st):
         P, D, A = self.P, self.D, self.A
         rows = ws["rows"]
-        call("lego_linear_fwd", x_ptr, D, _ptr(P[pre + "multi_head_attention.in_proj_weight"]), D,
-             _ptr(P[pre + "multi_head_attention.in_proj_bias"]), _ptr(ws["qkv"]), 3 * D, rows, rows_dyn, 3 * D, D, 0,
-             None, None, None, None, st)
-        call("lego_mhsa_core_fwd", _ptr(ws["qkv"]), 3 * D, _ptr(seg_off), n_cap, n_dyn, D, self.heads, _ptr(ws["o"]), D,
-             _ptr(ws["probs"]), ws["Lmax"], self.drop(self.p_att, site, training), rows, st)
-        call("lego_linear_fwd", _ptr(ws["o"]), D, _ptr(P[pre + "multi_head_attention.out_proj.weight"]), D,
-             _ptr(P[pre + "multi_head_attention.out_proj.bias"]), _ptr(ws["att"]), D, rows, rows_dyn, D, D, 0,
-             None, None, None, None, st)
-        call("lego_linear_fwd", _ptr(ws["att"]), D, _ptr(P[pre + "linear.weight"]), D, _ptr(P[pre + "linear.bias"]),
-             _ptr(ws["lin"]), D, rows, rows_dyn, D, D, 0, None, None, None, None, st)
-        call("lego_linear_fwd", _ptr(ws["lin"]), D, _ptr(P[pre + "additive_attention.encoder.0.weight"]), D,
-             _ptr(P[pre + "additive_attention.encoder.0.bias"]), _ptr(ws["t"]), A, rows, rows_dyn, A, D, 2,
-             None, None, None, None, st)
+        m = torch.cuda.current_stream()          # == st; tagged launches are HIP-event timed on it when bench.py asks
+        tg = pre[:4]
+        self.kk(m, "qkv_fwd_" + tg, "lego_linear_fwd", x_ptr, D, _ptr(P[pre + "multi_head_attention.in_proj_weight"]), D,
+                _ptr(P[pre + "multi_head_attention.in_proj_bias"]), _ptr(ws["qkv"]), 3 * D, rows, rows_dyn, 3 * D, D, 0,
+                None, None, None, None)
+        self.kk(m, "mhsa_core_fwd_" + tg, "lego_mhsa_core_fwd", _ptr(ws["qkv"]), 3 * D, _ptr(seg_off), n_cap, n_dyn, D, self.heads,
+                _ptr(ws["o"]), D, _ptr(ws["probs"]), ws["Lmax"], self.drop(self.p_att, site, training), rows)
+        self.kk(m, "out_proj_fwd_" + tg, "lego_linear_fwd", _ptr(ws["o"]), D, _ptr(P[pre + "multi_head_attention.out_proj.weight"]), D,
+                _ptr(P[pre + "multi_head_attention.out_proj.bias"]), _ptr(ws["att"]), D, rows, rows_dyn, D, D, 0,
+                None, None, None, None)
+        self.kk(m, "linear_fwd_" + tg, "lego_linear_fwd", _ptr(ws["att"]), D, _ptr(P[pre + "linear.weight"]), D, _ptr(P[pre + "linear.bias"]),
+                _ptr(ws["lin"]), D, rows, rows_dyn, D, D, 0, None, None, None, None)
+        self.kk(m, "additive_fwd_" + tg, "lego_linear_fwd", _ptr(ws["lin"]), D, _ptr(P[pre + "additive_attention.encoder.0.weight"]), D,
+                _ptr(P[pre + "additive_attention.encoder.0.bias"]), _ptr(ws["t"]), A, rows, rows_dyn, A, D, 2,
+                None, None, None, None)
         call("lego_additive_pool_fwd", _ptr(ws["t"]), A, _ptr(ws["lin"]), D,
              _ptr(P[pre + "additive_attention.encoder.2.weight"]), _ptr(seg_off), None, None, n_cap, n_dyn, D, A,
              _ptr(out), D, _ptr(ws["wrow"]), st)
@@ -658,8 +663,9 @@ class NrmsEngine(_Base):
         # ---- main: out-projection data gradient, attention core
         call("lego_linear_bwd_data", _ptr(ws["d_att"]), D, _ptr(P[pre + "multi_head_attention.out_proj.weight"]), D,
              _ptr(ws["d_o"]), D, rows, rows_dyn, D, D, 0, None, 0, 1.0, None, None, None, None, None, st)
-        call("lego_mhsa_core_bwd", _ptr(ws["qkv"]), 3 * D, _ptr(seg_off), n_cap, n_dyn, D, self.heads, _ptr(ws["d_o"]), D,
-             _ptr(ws["probs"]), ws["Lmax"], self.drop(self.p_att, site, training), rows, _ptr(ws["d_qkv"]), 3 * D, st)
+        self.kk(torch.cuda.current_stream(), "mhsa_core_bwd_" + pre[:4], "lego_mhsa_core_bwd", _ptr(ws["qkv"]), 3 * D, _ptr(seg_off),
+                n_cap, n_dyn, D, self.heads, _ptr(ws["d_o"]), D, _ptr(ws["probs"]), ws["Lmax"],
+                self.drop(self.p_att, site, training), rows, _ptr(ws["d_qkv"]), 3 * D)
         if sw is not m:
             ev[1].record(m)
             sw.wait_event(ev[1])

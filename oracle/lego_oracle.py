@@ -4,7 +4,7 @@ This file is a from-scratch *functional restatement* (flat id tensors, fp32 torc
 arithmetic) of the reference's `Legommender.forward` path for NAML and NRMS.  It is the
 checker the HIP kernels are compared against and the `cpu_baseline` ("port") leg of
 bench.py.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import it;
-the product package `legommenders_amd` never does (tests/test_no_oracle_in_product.py).
+the product package `legommenders_amd` never does (tests/test_product_isolation.py).
 
 Pinning: every function below is checked against golden vectors produced by importing the
 REAL reference in the build container (tests/golden/make_golden.py -> tests/golden/*.npz;
