@@ -185,6 +185,7 @@ using Epi = EpiArgs;      // host-side view; the kernel is instantiated with one
 
 }  // namespace lego
 #include "gemm_wino.hpp"
+#include "gemm_tn.hpp"
 namespace lego {
 
 static Epi make_epi(float* C, int ldc) {
@@ -290,29 +291,49 @@ static int launch_rows(const GemmDims& d, const AL& a, const BL& b, const Epi& e
     if (d.N > 64) return launch<C128x128, false, B_MC, EK>(d, a, b, e, tm, (d.N + 127) / 128, 1, st, what);
     return launch<C128x64, false, B_MC, EK>(d, a, b, e, tm, (d.N + 63) / 64, 1, st, what);
 }
-// TN: small [M,N] output, reduction over the (ragged) rows split along gridDim.z.  64 x 64 tiles: the
-// atomic traffic of the split-K epilogue is (#splits x M x N x 4 B), so small tiles (= fewer splits for
-// the same number of blocks) beat 128 x 128 by 1.6x here (tools/tn_variants.py: 44 vs 70 us).
-// (the three-tap conv product keeps 128 x 128: its shifted-row loader pays a rowinfo look-up per row and tile)
-template <class AL, class BL>
-static int launch_tn(const GemmDims& d, const AL& a, const BL& b, const Epi& e, int taps, hipStream_t st, const char* what) {
-    const int gz = taps * d.split_k;
-    if (taps > 1 && d.M > 64 && d.N > 64)
-        return launch<C128x128, true, true, EpiAtomic>(d, a, b, e, (d.M + 127) / 128, (d.N + 127) / 128, gz, st, what);
-    return launch<C64x64, true, true, EpiAtomic>(d, a, b, e, (d.M + 63) / 64, (d.N + 63) / 64, gz, st, what);
+// TN (weight gradients): small [M,N] output, reduction over the (ragged) rows split along gridDim.z.
+//   * long reductions (>= TN_LONG rows of capacity): tn_kernel of gemm_tn.hpp, one workgroup of 128 x 128 per CU, loads two
+//     k tiles ahead, split chosen so that the grid is one round of CUs;
+//   * short ones (user side, category column): 64 x 64 tiles of the generic tile kernel, ~1024 workgroups (more tiles =
+//     more CUs busy for a reduction of a few thousand rows).
+constexpr int TN_LONG = 8192;
+
+static int pick_split_small(int rows_cap, int M, int N) {
+    const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
+    int s = 1024 / tiles;
+    const int max_s = (rows_cap + 127) / 128;       // at least 128 reduction rows per block
+    if (s > max_s) s = max_s;
+    return s < 1 ? 1 : s;
 }
 
-static int pick_split(int rows_cap, int M, int N, int taps) {
-    // plain products: ~1024 blocks of 64 x 64 (4 x 32 KB of LDS per CU); conv: two rounds of 128 x 128 blocks;
-    // at least 128 reduction rows per block
-    const bool big = taps > 1 && M > 64 && N > 64;
-    const int t = big ? 128 : 64;
-    const int tiles = ((M + t - 1) / t) * ((N + t - 1) / t) * taps;
-    int s = (big ? 512 : 1024) / tiles;
-    const int max_s = (rows_cap + 127) / 128;
-    if (s > max_s) s = max_s;
-    if (s < 1) s = 1;
-    return s;
+template <class AL, class BL>
+static int launch_tn(int M, int N, int K_cap, const int* k_dyn, const AL& a, const BL& b, const Epi& e, int taps, hipStream_t st,
+                     const char* what) {
+    static const int mode = getenv("LEGO_TN_MODE") ? atoi(getenv("LEGO_TN_MODE")) : 2;   // EXPERIMENT SWITCH (to be removed)
+    const bool use_new = K_cap >= TN_LONG && (mode == 1 || (mode == 2 && IsDual<AL>::value));
+    if (!use_new) {
+        if (K_cap >= TN_LONG && taps > 1) {      // round-1 configuration of the conv products
+            int s = 512 / (((M + 127) / 128) * ((N + 127) / 128) * taps);
+            GemmDims d{M, N, K_cap, nullptr, k_dyn, s < 1 ? 1 : s};
+            return launch<C128x128, true, true, EpiAtomic>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, taps * d.split_k, st, what);
+        }
+        GemmDims d{M, N, K_cap, nullptr, k_dyn, pick_split_small(K_cap, M, N)};
+        return launch<C64x64, true, true, EpiAtomic>(d, a, b, e, (M + 63) / 64, (N + 63) / 64, taps * d.split_k, st, what);
+    }
+    const int tm = (M + TN_BM - 1) / TN_BM, tn = (N + TN_BN - 1) / TN_BN;
+    int split = num_cus() / (tm * tn * taps);
+    const int max_s = (K_cap + 255) / 256;          // at least 8 k tiles per workgroup
+    if (split > max_s) split = max_s;
+    if (split < 1) split = 1;
+    TnDims d{M, N, K_cap, k_dyn, split, taps, 0};
+    auto k = tn_kernel<AL, BL, false>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tn_lds_bytes());
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(tm, tn, taps * split), dim3(TN_THREADS), tn_lds_bytes(), st, d, a, b, e);
+    return check_launch(what);
 }
 
 }  // namespace lego
@@ -374,11 +395,10 @@ extern "C" int lego_linear_bwd_weight(const float* g, int ldg, const float* x, i
     CHECK4(ldg); CHECK4(ldx); CHECK4(N); CHECK4(K);
     if (M_cap <= 0) return 0;
     // dW[N,K] += sum_r g[r,:]^T x[r,:]: TN product, reduction over the rows
-    GemmDims d{/*M=*/N, /*N=*/K, /*K=*/M_cap, nullptr, M_dyn, pick_split(M_cap, N, K, 1)};
     McRows a{g, ldg, N, M_cap, g_row_off_dyn};
     McRows b{x, ldx, K, M_cap, x_row_off_dyn};
     Epi e = make_epi(dW, lddw);
-    return launch_tn(d, a, b, e, 1, (hipStream_t)stream, "lego_linear_bwd_weight");
+    return launch_tn(/*M=*/N, /*N=*/K, /*K=*/M_cap, M_dyn, a, b, e, 1, (hipStream_t)stream, "lego_linear_bwd_weight");
 }
 
 extern "C" int lego_conv3_fwd(const float* h, int ldh, const float* wt, const float* bias, const int32_t* rowinfo,
@@ -420,12 +440,11 @@ extern "C" int lego_conv3_bwd_weight(const float* gy, int ldg, const float* h, i
     CHECK4(ldg); CHECK4(ldh); CHECK4(Dout); CHECK4(Din);
     if (R_cap <= 0) return 0;
     // dwt[tap][o][c] += sum_r gy[r,o] h[r+tap-1,c]: three TN products (gridDim.z = 3 * split)
-    GemmDims d{Dout, Din, R_cap, nullptr, R_dyn, pick_split(R_cap, Dout, Din, 3)};
     McRows a{gy, ldg, Dout, R_cap, nullptr};
     McShiftRows b{h, ldh, Din, R_cap, rowinfo, 0};
     Epi e = make_epi(dwt, Din);
     e.tap_stride = (size_t)Dout * Din;
-    return launch_tn(d, a, b, e, 3, (hipStream_t)stream, "lego_conv3_bwd_weight");
+    return launch_tn(Dout, Din, R_cap, R_dyn, a, b, e, 3, (hipStream_t)stream, "lego_conv3_bwd_weight");
 }
 
 
@@ -478,12 +497,11 @@ extern "C" int lego_conv3_wino_bwd_weight(const float* gy, int ldg, const float*
     CHECK4(ldg); CHECK4(ldh); CHECK4(Dout); CHECK4(Din);
     if (P_cap <= 0) return 0;
     // du[set][o][c] += sum_pairs dM_set[o] * A_set[c]: four TN products over the pair rows (gridDim.z = 4 * split)
-    GemmDims d{Dout, Din, P_cap, nullptr, P_dyn, pick_split(P_cap, Dout, Din, 4)};
     McPair a{gy, ldg, Dout, P_cap, pair_info, 1, 0};
     McPair b{h, ldh, Din, P_cap, pair_info, 0, 0};
     Epi e = make_epi(du, Din);
     e.tap_stride = (size_t)Dout * Din;
-    return launch_tn(d, a, b, e, 4, (hipStream_t)stream, "lego_conv3_wino_bwd_weight");
+    return launch_tn(Dout, Din, P_cap, P_dyn, a, b, e, 4, (hipStream_t)stream, "lego_conv3_wino_bwd_weight");
 }
 
 #ifdef LEGO_TUNING_HOOKS   // `make tune` only (liblego_hip_tune.so, tools/*_variants.py): never in the product library

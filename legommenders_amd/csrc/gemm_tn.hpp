@@ -1,0 +1,169 @@
+// Split-K TN products (weight gradients): C[M,N] (+)= sum_r A[r,m] * B[r,n], both operands M-contiguous in memory (the reduction
+// index r is the memory row), on v_mfma_f32_32x32x2_f32.  Included by gemm_ops.hip after EpiArgs / gemm_wino.hpp.
+//
+// Why its own kernel (the generic tile kernel of gemm_core.hpp served these in round 1): a weight gradient has a SMALL output
+// (256 x 256 .. 1024 x 256 floats) and a LONG ragged reduction (13 k pairs .. 27 k rows), so every workgroup owns one
+// 128 x 128 output tile and a short k range (a few hundred rows = ~13 k tiles).  With so few tiles per workgroup the PMC pass
+// showed the waves waiting on s_waitcnt for 41-55 % of their cycles (profiles/r01_pmc_mfma_lds.json): one k tile of MFMA
+// work (0.85 us per wave) does not cover a global load issued at the top of that tile, least of all the Winograd pair
+// operands, whose row address depends on a pair_info word that is itself a global load.  Here
+//   * global loads run TWO k tiles ahead of their use (two staging register sets, loop unrolled by two),
+//   * the pair_info words of the workgroup's whole k range are copied to LDS once, so an operand load never waits for another,
+//   * one workgroup per CU (512 threads, 8 waves as 2 x 4, wave tile 64 x 32), 2 LDS stages of 32 KB.
+// Partial tiles either go out as fp32 atomics (ATOMIC) or as plain stores into a slab [split][M][N] that one combine launch
+// folds later (the conv's unpack kernel, lego_combine_slabs for the Linear weights).
+#pragma once
+#include "gemm_wino.hpp"
+
+namespace lego {
+
+constexpr int TN_BM = 128, TN_BN = 128, TN_THREADS = 512;
+constexpr int TN_INFO_CAP = 2048;            // pair_info words cached in LDS (k range of one workgroup); longer ranges read global
+
+struct TnDims {
+    int M, N, K;                 // output M x N, static bound of the reduction length
+    const int* k_dyn;            // device scalar overriding K
+    int split_k, taps;           // gridDim.z = taps * split_k
+    size_t slab_stride;          // SLAB: floats between the partial outputs of consecutive k splits (taps * tap_stride)
+};
+
+constexpr size_t tn_lds_bytes() { return (size_t)(2 * 2 * BK * TN_BM + TN_INFO_CAP) * sizeof(float); }
+
+template <class ALoad, class BLoad, bool SLAB>
+__global__ __launch_bounds__(TN_THREADS) void tn_kernel(TnDims dims, ALoad la, BLoad lb, EpiArgs e) {
+    constexpr int BM = TN_BM, BN = TN_BN, NT = TN_THREADS;
+    constexpr int STAGE = BK * BM;                       // floats per operand stage ([BK][128])
+    constexpr int PER = BM / 4, STEP = NT / PER;         // 32 float4 per k row, 16 k rows per pass of the workgroup
+    constexpr int NJ = BK / STEP;                        // 2 float4 per thread, operand and k tile
+    constexpr bool A2 = IsDual<ALoad>::value, B2 = IsDual<BLoad>::value;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const As0 = smem;
+    float* const Bs0 = smem + 2 * STAGE;
+    int* const s_info = reinterpret_cast<int*>(smem + 4 * STAGE);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 2, wn = wave & 3;             // 2 x 4 waves, wave tile 64 x 32
+
+    int K = dims.K;
+    if (dims.k_dyn != nullptr) K = min(K, *dims.k_dyn);
+    const int M = dims.M, N = dims.N;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int z = blockIdx.z % dims.split_k, tap = blockIdx.z / dims.split_k;
+    int chunk = (K + dims.split_k - 1) / dims.split_k;
+    chunk = (chunk + BK - 1) / BK * BK;
+    const int kbeg = z * chunk, kend = min(K, kbeg + chunk);
+    float* C = e.C + (size_t)tap * e.tap_stride + (SLAB ? (size_t)z * dims.slab_stride : 0);
+    if (kbeg >= kend) {
+        if constexpr (SLAB) {                            // an empty split still owns a slab tile: the combine reads every slab
+            for (int i = tid; i < BM * (BN / 4); i += NT) {
+                const int r = m0 + i / (BN / 4), c = n0 + (i % (BN / 4)) * 4;
+                if (r < M && c < N) *reinterpret_cast<f32x4*>(C + (size_t)r * e.ldc + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        return;
+    }
+    la.K = kend; lb.K = kend;
+    la.prepare(tap); lb.prepare(tap);
+    if constexpr (A2 || B2) {
+        const int n_info = min(kend - kbeg, TN_INFO_CAP);
+        const int* src = A2 ? la.info_src() : lb.info_src();
+        for (int i = tid; i < n_info; i += NT) s_info[i] = src[kbeg + i];
+        if constexpr (A2) la.cache(s_info, kbeg, n_info);
+        if constexpr (B2) lb.cache(s_info, kbeg, n_info);
+        __syncthreads();
+    }
+
+    const int kr = tid / PER, c4 = (tid % PER) * 4;      // this thread's k row inside a pass and its 4 columns
+    struct Regs { f32x4 a[NJ], b[NJ], a2[A2 ? NJ : 1], b2[B2 ? NJ : 1]; bool pa[NJ], pb[NJ], pa2[A2 ? NJ : 1], pb2[B2 ? NJ : 1]; };
+    auto fetch = [&](Regs& r, int k0) {
+        k0 = min(k0, kend - 1);                          // past the end: re-read the last rows (never committed to a used stage)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int kk = k0 + kr + STEP * j;
+            if constexpr (A2) la.load2(kk, m0 + c4, r.a[j], r.pa[j], r.a2[j], r.pa2[j]); else r.a[j] = la.load(kk, m0 + c4, r.pa[j]);
+            if constexpr (B2) lb.load2(kk, n0 + c4, r.b[j], r.pb[j], r.b2[j], r.pb2[j]); else r.b[j] = lb.load(kk, n0 + c4, r.pb[j]);
+        }
+    };
+    auto commit = [&](const Regs& r, float* A_, float* B_) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            f32x4 va, vb;
+            if constexpr (A2) va = la.combine(r.a[j], r.pa[j], r.a2[j], r.pa2[j]); else va = zero_unless(r.pa[j], r.a[j]);
+            if constexpr (B2) vb = lb.combine(r.b[j], r.pb[j], r.b2[j], r.pb2[j]); else vb = zero_unless(r.pb[j], r.b[j]);
+            *reinterpret_cast<f32x4*>(A_ + (kr + STEP * j) * BM + c4) = va;
+            *reinterpret_cast<f32x4*>(B_ + (kr + STEP * j) * BN + c4) = vb;
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[a][v] = 0.f;
+    auto tile_mfma = [&](const float* A_, const float* B_) {
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
+            float fa[2][4], fb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 8 * q + 4 * lh + j;        // lane half h takes k = 8q + 4h + j for MFMA j, A and B alike
+                fa[0][j] = A_[k * BM + wm * 64 + li];
+                fa[1][j] = A_[k * BM + wm * 64 + 32 + li];
+                fb[j] = B_[k * BN + wn * 32 + li];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][j], fb[j], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][j], fb[j], acc[1], 0, 0, 0);
+            }
+        }
+    };
+
+    // tile t lives in LDS stage t & 1; its global loads are issued at the top of iteration t - 2 and committed at the bottom of
+    // iteration t - 1 (after that iteration's MFMAs), i.e. two tiles of matrix work cover every load
+    Regs r0, r1;
+    fetch(r0, kbeg);
+    commit(r0, As0, Bs0);
+    fetch(r1, kbeg + BK);
+    __syncthreads();
+    const int nt = (kend - kbeg + BK - 1) / BK;
+    for (int t = 0; t < nt; t += 2) {
+        fetch(r0, kbeg + (t + 2) * BK);
+        tile_mfma(As0, Bs0);
+        commit(r1, As0 + STAGE, Bs0 + STAGE);            // tile t + 1
+        __syncthreads();
+        if (t + 1 >= nt) break;
+        fetch(r1, kbeg + (t + 3) * BK);
+        tile_mfma(As0 + STAGE, Bs0 + STAGE);
+        commit(r0, As0, Bs0);                            // tile t + 2
+        __syncthreads();
+    }
+
+    // epilogue: lane holds column li x rows {(v & 3) + 8 * (v >> 2) + 4 * lh} of each 32 x 32 sub-tile
+    const int col = n0 + wn * 32 + li;
+    if (col < N) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = m0 + wm * 64 + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+                if (row < M) {
+                    float* dst = C + (size_t)row * e.ldc + col;
+                    if constexpr (SLAB) *dst = acc[a][v]; else atomicAdd(dst, acc[a][v]);
+                }
+            }
+    }
+}
+
+// out[i] += sum_s slabs[s * stride + i]  (i < n): the fold of a slab set, 16 B per lane
+__global__ __launch_bounds__(256) void combine_slabs_kernel(const float* __restrict__ slabs, size_t stride, int S, float* __restrict__ out, int n4) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(out + (size_t)i * 4);
+        for (int k = 0; k < S; ++k) s += *reinterpret_cast<const f32x4*>(slabs + (size_t)k * stride + (size_t)i * 4);
+        *reinterpret_cast<f32x4*>(out + (size_t)i * 4) = s;
+    }
+}
+
+}  // namespace lego

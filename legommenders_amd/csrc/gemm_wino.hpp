@@ -277,12 +277,20 @@ struct McPair {
     static constexpr bool kDual = true;
     const float* p; int ld; int ext; int K; const int* pair_info; int side;     // side 0: A_s from h, 1: dM_s from gy
     int set;
+    const int* s_info = nullptr; int s_base = 0, s_n = 0;     // pair_info words [s_base, s_base + s_n) cached in LDS (gemm_tn.hpp)
     struct Row {};
     __device__ __forceinline__ void prepare(int tap) { set = tap; }
     __device__ __forceinline__ void tile(int) {}
+    __device__ __forceinline__ const int* info_src() const { return pair_info; }
+    __device__ __forceinline__ void cache(const int* s, int base, int n) { s_info = s; s_base = base; s_n = n; }
+    __device__ __forceinline__ int info_at(int kk) const {
+        const int kc = min(kk, K - 1);
+        const int i = kc - s_base;
+        return (s_info != nullptr && i < s_n) ? s_info[i] : pair_info[kc];
+    }
     // value = c1 * (keep1 ? v1 : 0) + c2 * (keep2 ? v2 : 0)
     __device__ __forceinline__ void load2(int kk, int c, f32x4& v1, bool& k1, f32x4& v2, bool& k2) const {
-        const int info = pair_info[min(kk, K - 1)];
+        const int info = info_at(kk);
         const bool in = kk < K;
         const bool ok0 = (info & PI_LEFT) != 0, ok2 = (info & PI_HAS2) != 0, ok3 = (info & PI_RIGHT2) != 0;
         const float* base = p + (size_t)(info >> PI_ROW_SHIFT) * ld + min(c, ext - 4);
@@ -301,7 +309,7 @@ struct McPair {
         v2 = *reinterpret_cast<const f32x4*>(base + (k2 ? rb * ld : 0));
     }
     __device__ __forceinline__ f32x4 combine(const f32x4& v1, bool k1, const f32x4& v2, bool k2) const {
-        const float c2 = side == 0 ? (set == 1 ? 1.f : -1.f) : (set == 1 ? 1.f : -1.f);
+        const float c2 = set == 1 ? 1.f : -1.f;
         return zero_unless(k1, v1) + c2 * zero_unless(k2, v2);
     }
 };

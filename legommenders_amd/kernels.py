@@ -243,7 +243,7 @@ def mhsa_fwd(x, mask, in_w, in_b, out_w, out_b, heads, drop=None):
     xc = gather_rows(x.view(n * L, D), idx)
     qkv = linear_fwd(xc, in_w, in_b)
     o = torch.empty(R, D, dtype=torch.float32, device=x.device)
-    probs = torch.empty(R, heads, L, dtype=torch.float32, device=x.device)
+    probs = torch.zeros(R, heads, L, dtype=torch.float32, device=x.device)   # slots past a segment's length are never written
     call("lego_mhsa_core_fwd", _ptr(qkv), 3 * D, _ptr(seg_off), n, None, D, heads, _ptr(o), D, _ptr(probs), L,
          _drop(drop), R, _stream())
     yc = linear_fwd(o, out_w, out_b)

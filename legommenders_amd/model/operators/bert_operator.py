@@ -140,7 +140,15 @@ class BertOperator(LMOperator, abc.ABC):
             return
         dev = Env.device
         n_items = int(legommender.item_table.title_tok.shape[0])
-        if os.path.exists(self._get_cache_path(k)) and os.path.exists(self._get_mask_path()):
+        # files are trusted only in single-process runs or when they predate this launch on every rank; with WORLD_SIZE > 1 a
+        # missing file on ANY rank's first look means some rank may be writing: then nobody reads, everybody computes
+        multi = int(os.environ.get("WORLD_SIZE", "1")) > 1
+        have = os.path.exists(self._get_cache_path(k)) and os.path.exists(self._get_mask_path())
+        if multi and torch.distributed.is_available() and torch.distributed.is_initialized():
+            flag = torch.tensor([int(have)], device=dev)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            have = bool(flag.item())
+        if have:
             mask = torch.from_numpy(np.load(self._get_mask_path())).to(dev)
             hidden = torch.from_numpy(np.load(self._get_cache_path(k))).to(dev).float()
             hidden = hidden.view(*mask.shape[:2], hidden.shape[-1])
@@ -163,10 +171,14 @@ class BertOperator(LMOperator, abc.ABC):
                 ms.append(m.long())
             hidden, mask = torch.cat(hs, 0).contiguous(), torch.cat(ms, 0).contiguous()
             self.transformer.train(was_training)
-            if os.environ.get("LEGO_LAYER_CACHE_SAVE", "1") != "0":
+            # under torchrun every rank computes its own HBM-resident cache (identical checkpoint -> identical values); only
+            # rank 0 writes the files, through a temporary name + os.replace, so no reader ever sees a half-written array
+            if os.environ.get("LEGO_LAYER_CACHE_SAVE", "1") != "0" and int(os.environ.get("RANK", "0")) == 0:
                 os.makedirs(self._cache_base_dir, exist_ok=True)
-                np.save(self._get_cache_path(k), hidden.cpu().numpy())
-                np.save(self._get_mask_path(), mask.cpu().numpy())
+                for path, arr in ((self._get_cache_path(k), hidden), (self._get_mask_path(), mask)):
+                    tmp = f"{path}.tmp{os.getpid()}.npy"
+                    np.save(tmp, arr.cpu().numpy())
+                    os.replace(tmp, path)
         nan_rows = torch.isnan(hidden).any(-1)                        # once_operator.py:116-124
         if bool(nan_rows.any()):
             hidden[nan_rows] = torch.rand_like(hidden[nan_rows])

@@ -44,6 +44,45 @@ def test_converter_semantics(tmp_path):
     assert np.load(tmp_path / "data" / "embeddings" / "glove.npy").shape == (11, 300)
 
 
+def test_tables_match_the_reference_processor(tmp_path):
+    """SURVEY.md 8f-3 pin: the reference's own MINDProcessor.load() was run on tests/golden/mind_raw (make_golden_mind.py,
+    unitok replaced by recording stand-ins) -- item / user order after compression, histories, negative lists, the seeded
+    10 % validation split and the three interaction tables must come out the same here."""
+    import json
+    from legommenders_amd.process_mind import build, build_tables
+    here = os.path.dirname(os.path.abspath(__file__))
+    gold = json.load(open(os.path.join(here, "golden", "mind_tables.json")))
+    raw = os.path.join(here, "golden", "mind_raw")
+    t = build_tables(raw, seed=gold["seed"])
+    assert list(t["news"]) == gold["items"]["nid"]                                   # N19 (never referenced) is gone
+    assert [c for c, _ in t["news"].values()] == gold["items"]["category"]
+    assert [ti for _, ti in t["news"].values()] == gold["items"]["title"]
+    assert list(t["users"]) == gold["users"]["uid"]                                  # U4, U5, U19 dropped
+    assert list(t["users"].values()) == gold["users"]["history"]
+    assert [t["neg"][u] for u in t["users"]] == gold["users"]["neg"]
+    for name in ("train", "valid", "test"):
+        g = gold[name]
+        assert t[name] == list(zip(g["uid"], g["nid"], g["click"])), name
+    # ... and the npz tables carry exactly that, as indices into the compressed tables
+    words = ["the", "storm", "stocks"]
+    (tmp_path / "glove.txt").write_text("\n".join(w + " " + " ".join(["0.1"] * 300) for w in words) + "\n")
+    out = tmp_path / "data" / "mind"
+    build(raw, str(tmp_path / "glove.txt"), str(out), seed=gold["seed"])
+    it, us = np.load(out / "items.npz"), np.load(out / "users.npz")
+    nid, uid = it["nid"].tolist(), us["uid"].tolist()
+    assert nid == gold["items"]["nid"] and uid == gold["users"]["uid"]
+    assert [it["category"][c] for c in it["cat"]] == gold["items"]["category"]
+    for r, (h, ng) in enumerate(zip(gold["users"]["history"], gold["users"]["neg"])):
+        assert [nid[i] for i in us["user_hist"][r, : us["user_hist_len"][r]]] == h[:50]
+        assert [nid[i] for i in us["neg_list"][r, : us["neg_len"][r]]] == ng
+    tr = np.load(out / "train.npz")
+    pos = [(u, n) for u, n, c in zip(*(gold["train"][k] for k in ("uid", "nid", "click"))) if c == 1]
+    assert [(uid[u], nid[n]) for u, n in zip(tr["row_user"], tr["row_item"])] == pos
+    for name in ("valid", "test"):
+        z, g = np.load(out / f"{name}.npz"), gold[name]
+        assert [uid[u] for u in z["user"]] == g["uid"] and [nid[n] for n in z["item"]] == g["nid"] and z["label"].tolist() == g["click"]
+
+
 def test_trainer_loader_reads_converted_tables(tmp_path, monkeypatch):
     from legommenders_amd.config_init import Obj
     from legommenders_amd.process_mind import build
