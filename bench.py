@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (impressions per step)")
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--model", default="naml", choices=["naml", "nrms"])
+    ap.add_argument("--embed", default="glove", choices=["glove", "null"],
+                    help="nrms only: null = trainable [V, hidden] token table (config/embed/null.yaml) instead of frozen GloVe + Linear")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the long run and the secondary configurations")
     ap.add_argument("--cpu-steps", type=int, default=12)
@@ -177,18 +179,19 @@ def main():
     glove = glove_like(cfg["V"], 300, seed=2024, device=dev)
     B, D, E0 = args.batch, args.hidden, 300
 
-    def make_ts(kind, d, force=False):
+    def make_ts(kind, d, force=False, embed="glove"):
         init = init_naml_params if kind == "naml" else init_nrms_params
-        params = init(D=D, V=cfg["V"], n_cat=cfg["n_cat"], glove=glove)
+        use_glove = not (kind == "nrms" and embed == "null")
+        params = init(D=D, V=cfg["V"], n_cat=cfg["n_cat"], glove=glove if use_glove else None)
         return TrainStep(kind, params, d, B, K=4, lr=1e-3, total_steps=0, seed=2023, process_group=pg, world_size=world_size,
-                         dropout=True, force_allreduce=force, tail="drop")
+                         dropout=True, force_allreduce=force, tail="drop", glove=use_glove)
 
     def barrier():
         if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    ts = make_ts(args.model, data, force=args.force_dist)
+    ts = make_ts(args.model, data, force=args.force_dist, embed=args.embed)
     dt, timers, loss = timed_steps(ts, args.steps, args.warmup, barrier, args.time_every)
     host_ms = timed_steps.host_s / args.steps * 1e3
     if dist_on:

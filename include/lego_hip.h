@@ -104,7 +104,10 @@ int lego_conv3_unpack_add(float* dwt /*[3,Dout,Din], cleared on return*/, float*
 /* Winograd F(2,3) form of the same conv over ROW PAIRS (two thirds of the direct form's MFMA work; same result up to
  * fp32 rounding).  lego_plan_pairs derives the pairs from seg_off: pair_info[p] = first_row << 3 | has_second |
  * has_left << 1 | has_right2 << 2, *n_pairs_out = P.  u / du are the transformed weights [4][Dout][Din]
- * (lego_conv3_wino_pack; lego_conv3_wino_unpack_add adds the transposed transform of du into dw and clears du).
+ * (lego_conv3_wino_pack).  The weight gradient writes its partial results as S = lego_conv3_wino_du_slabs(Dout, Din, P_cap)
+ * slabs du[S][4][Dout][Din]: S > 1 (long reductions) = one slab per k split, written whole with plain stores, no fp32
+ * atomics and nothing to clear; S == 1 = an atomics accumulator that must be zero on entry.  lego_conv3_wino_unpack_add sums
+ * the S slabs, adds the transposed transform into dw and, for S == 1, hands du back cleared.
  * Every planned row must be live (ragged plans).  Din, Dout multiples of 32, <= 256.  Same reference lines as
  * lego_conv3_*: nn.Conv1d(k=3, padding='same') -> ReLU -> Dropout of model/operators/cnn_operator.py:33-38,54-57 and its
  * autograd backward. */
@@ -112,7 +115,8 @@ int lego_plan_pairs(const int32_t* seg_off, int n_cap, const int32_t* n_dyn, int
                     void* stream);
 int lego_conv3_wino_pack(const float* w /*[Dout,Din,3]*/, float* u /*[4,Dout,Din]*/, float* ut /*nullable [4,Din,Dout]: u transposed*/,
                          int Dout, int Din, void* stream);
-int lego_conv3_wino_unpack_add(float* du /*[4,Dout,Din], cleared*/, float* dw /*[Dout,Din,3], +=*/, int Dout, int Din, void* stream);
+int lego_conv3_wino_du_slabs(int Dout, int Din, int P_cap);
+int lego_conv3_wino_unpack_add(float* du /*[S,4,Dout,Din]*/, int n_slabs, float* dw /*[Dout,Din,3], +=*/, int Dout, int Din, void* stream);
 int lego_conv3_wino_fwd(const float* h, int ldh, const float* u, const float* bias, const int32_t* pair_info,
                         int P_cap, const int32_t* P_dyn, float* y, int ldy, int Dout, int Din,
                         const lego_dropout* drop, void* stream);
@@ -121,7 +125,7 @@ int lego_conv3_wino_bwd_data(const float* gy, int ldg, const float* u, const flo
                              int P_cap, const int32_t* P_dyn, float* dh, int lddh, int Dout, int Din,
                              const lego_dropout* drop_in, float* colsum, void* stream);
 int lego_conv3_wino_bwd_weight(const float* gy, int ldg, const float* h, int ldh, const int32_t* pair_info,
-                               int P_cap, const int32_t* P_dyn, float* du, int Dout, int Din, void* stream);
+                               int P_cap, const int32_t* P_dyn, float* du /*[S,4,Dout,Din]*/, int Dout, int Din, void* stream);
 int lego_conv3_fwd(const float* h, int ldh, const float* wt, const float* bias, const int32_t* rowinfo,
                    float* y, int ldy, int R_cap, const int32_t* R_dyn, int Dout, int Din,
                    const lego_dropout* drop, int mask_rows /*0: every row is live (ragged plan), skip the live-bit loads*/,
@@ -192,13 +196,22 @@ int lego_mhsa_core_fwd(const float* qkv, int ldq, const int32_t* seg_off, int n_
                        int Lmax, const lego_dropout* drop, int rows_cap, void* stream);
 int lego_mhsa_core_bwd(const float* qkv, int ldq, const int32_t* seg_off, int n_cap, const int32_t* n_dyn,
                        int D, int heads, const float* gout, int ldgo, const float* probs, int Lmax,
-                       const lego_dropout* drop, int rows_cap, float* gqkv, int ldgq, void* stream);
+                       const lego_dropout* drop, int rows_cap, float* gqkv, int ldgq,
+                       float* colsum /*nullable [3*D]: += column sums of gqkv = the in_proj_bias gradient*/, void* stream);
 
 /* ---- a13: torch.optim.Adam (defaults, base_lego.py:201-204) over one flat fp32 buffer;
  * grad is multiplied by grad_scale first (1/world after the RCCL all-reduce). step is 1-based.
  * zero_grad != 0: g is cleared as it is consumed (optimizer.zero_grad() of the next step, trainer.py:199). */
 int lego_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                    float eps, int step, float grad_scale, int zero_grad, void* stream);
+/* The same update over the rows of a trainable [rows, width] embedding table (config/embed/null.yaml: nn.Embedding(400k, D),
+ * loader/embedding_hub.py:325-335 -- dense gradient, dense Adam), skipping rows whose byte in `touched` is 0.  A row that
+ * has never received a gradient has g = m = v = 0, where Adam's update is exactly 0: skipping it is bit-identical to the
+ * dense rule, and once touched a row is updated every step.  lego_mark_rows sets the bytes of idx[0..n) (ids < 0 ignored);
+ * data-parallel ranks merge their flags (all-reduce MAX) with the gradient all-reduce. */
+int lego_adam_step_rows(float* p, float* g, float* m, float* v, int rows, int width, const uint8_t* touched /*[rows]*/,
+                        float lr, float beta1, float beta2, float eps, int step, float grad_scale, int zero_grad, void* stream);
+int lego_mark_rows(const int32_t* idx, int n_cap, const int32_t* n_dyn, int rows, uint8_t* touched, void* stream);
 
 /* ---- a11: negative sampling of Resampler.rebuild_candidates (loader/resampler.py:159-171) on
  * device: cand[b,0] = positive; min(K,len) distinct draws from the user's true-negative list,
@@ -219,6 +232,12 @@ int lego_gather_history(const int32_t* row_user, const int32_t* user_hist /*[n_u
  * look-up index columns (-1 = column absent at that position) and a live-bit word for token rows. */
 int lego_nrms_decode_rows(const int32_t* row_tok, int R_cap, const int32_t* R_dyn, int32_t* idx_tok,
                           int32_t* idx_special, int32_t* idx_cat, int32_t* tokinfo, void* stream);
+/* Backward of ConcatInputer's two small look-ups (concat_inputer.py:96-114: token + special-id + category embeddings are summed
+ * per position): an item's sequence is [title..., SEP, category, SEP], so rows L-3 and L-1 of each segment add into the [SEP]
+ * row g_sep[width] of the special-id table and row L-2 into row idx_cat[beg+L-2] of g_cat. */
+int lego_nrms_special_grads(const int32_t* seg_off, int n_cap, const int32_t* n_dyn, const int32_t* idx_cat, const float* g,
+                            int ld, int width, float* g_sep /*row SEP of the special table*/, float* g_cat, int ld_cat, int n_cat,
+                            void* stream);
 /* x[r,:] *= live(rowinfo[r]) * dropout-scale: backward of `Transformation`'s Dropout + the inputer mask
  * (loader/embedding_hub.py:96, concat_inputer.py:111) when the producer is not a fused GEMM epilogue */
 int lego_mask_dropout_rows(float* x, int ld, int R_cap, const int32_t* R_dyn, int width, const int32_t* rowinfo,

@@ -32,6 +32,7 @@ SIGNATURES = {
     "lego_plan_dense": [P, I, I, P, P, P, P],
     "lego_gather_rows": [P, I, I, P, I, P, P, I, I, P],
     "lego_nrms_decode_rows": [P, I, P, P, P, P, P, P],
+    "lego_nrms_special_grads": [P, I, P, P, P, I, I, P, P, I, I, P],
     "lego_mask_dropout_rows": [P, I, I, P, I, P, P, P],
     "lego_scatter_add_rows": [P, I, I, I, P, I, P, P, I, P],
     "lego_linear_fwd": [P, I, P, I, P, P, I, I, P, I, I, I, P, P, P, P, P],
@@ -43,7 +44,7 @@ SIGNATURES = {
     "lego_dropout_mask": [P, I, P, I, P, P],
     "lego_plan_pairs": [P, I, P, P, P, P],
     "lego_conv3_wino_pack": [P, P, P, I, I, P],
-    "lego_conv3_wino_unpack_add": [P, P, I, I, P],
+    "lego_conv3_wino_unpack_add": [P, I, P, I, I, P],
     "lego_conv3_wino_fwd": [P, I, P, P, P, I, P, P, I, I, I, P, P],
     "lego_conv3_wino_bwd_data": [P, I, P, P, P, I, P, P, I, I, I, P, P, P],
     "lego_conv3_wino_bwd_weight": [P, I, P, I, P, I, P, P, I, I, P],
@@ -56,17 +57,23 @@ SIGNATURES = {
     "lego_dot_ce_fwd": [P, I, P, I, I, I, I, P, P, P],
     "lego_dot_ce_bwd": [P, I, P, I, P, I, I, I, F, P, I, P, I, P],
     "lego_mhsa_core_fwd": [P, I, P, I, P, I, I, P, I, P, I, P, I, P],
-    "lego_mhsa_core_bwd": [P, I, P, I, P, I, I, P, I, P, I, P, I, P, I, P],
+    "lego_mhsa_core_bwd": [P, I, P, I, P, I, I, P, I, P, I, P, I, P, I, P, P],
     "lego_user_tower_train": [P, I, P, I, P, P, I, I, I, I, I, F, P, P, P, P, I, P, P, P],
     "lego_rowdot_fwd": [P, I, P, I, I, I, P, P],
     "lego_rowdot_bwd": [P, I, P, I, P, I, I, P, I, P, I, P],
     "lego_relu_bwd": [P, I, P, I, I, I, F, P],
     "lego_adam_step": [P, P, P, P, I64, F, F, F, F, I, F, I, P],
+    "lego_adam_step_rows": [P, P, P, P, I, I, P, F, F, F, F, I, F, I, P],
+    "lego_mark_rows": [P, I, P, I, P, P],
     "lego_sample_negatives": [P, P, P, P, I, I, I, I, U64, U32, U32, U32, P, P],
     "lego_gather_history": [P, P, P, I, I, P, P, P],
     "lego_gather_i32": [P, P, I, P, P, P],
     "lego_grouped_metrics": [P, P, P, I, P, I, P, P],
 }
+
+
+# entry points that return a VALUE instead of a status (bound separately; tests/test_abi.py checks them against the header too)
+VALUE_FUNCS = {"lego_conv3_wino_du_slabs": [I, I, I]}
 
 
 class LegoHipError(RuntimeError):
@@ -112,6 +119,9 @@ def lib() -> ctypes.CDLL:
     handle.lego_last_error.restype = ctypes.c_char_p
     handle.lego_last_error.argtypes = []
     handle.lego_abi_version.restype = ctypes.c_int
+    for name, argtypes in VALUE_FUNCS.items():
+        fn = getattr(handle, name)
+        fn.restype, fn.argtypes = ctypes.c_int, argtypes
     for name, argtypes in SIGNATURES.items():
         try:
             fn = getattr(handle, name)

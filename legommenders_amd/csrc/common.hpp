@@ -90,6 +90,20 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 }  // namespace lego
 
+// ---------------------------------------------------------------- in-kernel clock probe (tuning build only: `make tune`)
+// MI355X lowers its clock under MFMA-dense load (MI355X_MICROARCH.md 'DVFS give-back'): the clock a kernel really ran at is
+// delta(s_memtime) / delta(s_memrealtime) x 100 MHz.  The product library compiles these to nothing.
+#ifdef LEGO_TUNING_HOOKS
+namespace lego { extern __device__ unsigned long long g_clock_probe[4]; }
+#define LEGO_CLOCK_BEGIN unsigned long long lego_c0 = __builtin_amdgcn_s_memtime(), lego_r0 = __builtin_amdgcn_s_memrealtime();
+#define LEGO_CLOCK_END(slot) if (threadIdx.x == 0) { \
+        atomicAdd(&::lego::g_clock_probe[2 * (slot)], __builtin_amdgcn_s_memtime() - lego_c0); \
+        atomicAdd(&::lego::g_clock_probe[2 * (slot) + 1], __builtin_amdgcn_s_memrealtime() - lego_r0); }
+#else
+#define LEGO_CLOCK_BEGIN
+#define LEGO_CLOCK_END(slot)
+#endif
+
 // ---------------------------------------------------------------- host-side error plumbing
 extern "C" const char* lego_last_error(void);
 namespace lego {

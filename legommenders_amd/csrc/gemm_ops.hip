@@ -306,27 +306,25 @@ static int pick_split_small(int rows_cap, int M, int N) {
     return s < 1 ? 1 : s;
 }
 
-template <class AL, class BL>
-static int launch_tn(int M, int N, int K_cap, const int* k_dyn, const AL& a, const BL& b, const Epi& e, int taps, hipStream_t st,
-                     const char* what) {
-    static const int mode = getenv("LEGO_TN_MODE") ? atoi(getenv("LEGO_TN_MODE")) : 2;   // EXPERIMENT SWITCH (to be removed)
-    const bool use_new = K_cap >= TN_LONG && (mode == 1 || (mode == 2 && IsDual<AL>::value));
-    if (!use_new) {
-        if (K_cap >= TN_LONG && taps > 1) {      // round-1 configuration of the conv products
-            int s = 512 / (((M + 127) / 128) * ((N + 127) / 128) * taps);
-            GemmDims d{M, N, K_cap, nullptr, k_dyn, s < 1 ? 1 : s};
-            return launch<C128x128, true, true, EpiAtomic>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, taps * d.split_k, st, what);
-        }
-        GemmDims d{M, N, K_cap, nullptr, k_dyn, pick_split_small(K_cap, M, N)};
-        return launch<C64x64, true, true, EpiAtomic>(d, a, b, e, (M + 63) / 64, (N + 63) / 64, taps * d.split_k, st, what);
-    }
+static int tn_split(int M, int N, int K_cap, int taps) {     // k splits of the long-reduction kernel: one round of CUs
     const int tm = (M + TN_BM - 1) / TN_BM, tn = (N + TN_BN - 1) / TN_BN;
     int split = num_cus() / (tm * tn * taps);
     const int max_s = (K_cap + 255) / 256;          // at least 8 k tiles per workgroup
     if (split > max_s) split = max_s;
-    if (split < 1) split = 1;
-    TnDims d{M, N, K_cap, k_dyn, split, taps, 0};
-    auto k = tn_kernel<AL, BL, false>;
+    const int min_s = (K_cap + TN_INFO_CAP - BK - 1) / (TN_INFO_CAP - BK);      // a workgroup's k range fits the LDS pair_info cache
+    if (split < min_s) split = min_s;
+    return split < 1 ? 1 : split;
+}
+
+// SLAB: the partial tile of every k split goes to its own [taps][M][N] slab with plain stores (e.C = slab 0) instead of fp32
+// atomics into one buffer; the caller folds the slabs (conv: lego_conv3_wino_unpack_add)
+template <bool SLAB, class AL, class BL>
+static int launch_tn_long(int M, int N, int K_cap, const int* k_dyn, const AL& a, const BL& b, const Epi& e, int taps, hipStream_t st,
+                          const char* what) {
+    const int tm = (M + TN_BM - 1) / TN_BM, tn = (N + TN_BN - 1) / TN_BN;
+    const int split = tn_split(M, N, K_cap, taps);
+    TnDims d{M, N, K_cap, k_dyn, split, taps, (size_t)taps * e.tap_stride};
+    auto k = tn_kernel<AL, BL, SLAB>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tn_lds_bytes());
@@ -334,6 +332,16 @@ static int launch_tn(int M, int N, int K_cap, const int* k_dyn, const AL& a, con
     }
     hipLaunchKernelGGL(k, dim3(tm, tn, taps * split), dim3(TN_THREADS), tn_lds_bytes(), st, d, a, b, e);
     return check_launch(what);
+}
+
+// plain row operands: 64 x 64 tiles, ~1024 workgroups, fp32 atomics.  Measured against the 128 x 128 kernel above on the
+// path's own shapes (profiles/r02_tn_modes.md): 29.5 us per launch against 56.9 -- four small workgroups per CU hide each
+// other's barriers and load latency better than one large one, and these operands need no index look-up
+template <class AL, class BL>
+static int launch_tn(int M, int N, int K_cap, const int* k_dyn, const AL& a, const BL& b, const Epi& e, int taps, hipStream_t st,
+                     const char* what) {
+    GemmDims d{M, N, K_cap, nullptr, k_dyn, pick_split_small(K_cap, M, N)};
+    return launch<C64x64, true, true, EpiAtomic>(d, a, b, e, (M + 63) / 64, (N + 63) / 64, taps * d.split_k, st, what);
 }
 
 }  // namespace lego
@@ -458,7 +466,7 @@ static int launch_wino(const WinoArgs& w, const Epi& e, hipStream_t st, const ch
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL(k, dim3(num_cus()), dim3(STRIP_THREADS), lds, st, w, e);
+    hipLaunchKernelGGL(k, dim3(num_cus() / 16 * 16), dim3(STRIP_THREADS), lds, st, w, e);   // (strip, half) dealing needs a multiple of 16
     return check_launch(what);
 }
 
@@ -492,6 +500,11 @@ extern "C" int lego_conv3_wino_bwd_data(const float* gy, int ldg, const float* u
     return launch_wino<true>(w, e, (hipStream_t)stream, "lego_conv3_wino_bwd_data");
 }
 
+extern "C" int lego_conv3_wino_du_slabs(int Dout, int Din, int P_cap) {
+    if (P_cap < TN_LONG) return 1;                  // short reductions accumulate with atomics into ONE cleared buffer
+    return tn_split(Dout, Din, P_cap, 4);
+}
+
 extern "C" int lego_conv3_wino_bwd_weight(const float* gy, int ldg, const float* h, int ldh, const int32_t* pair_info,
                                           int P_cap, const int32_t* P_dyn, float* du, int Dout, int Din, void* stream) {
     CHECK4(ldg); CHECK4(ldh); CHECK4(Dout); CHECK4(Din);
@@ -501,10 +514,19 @@ extern "C" int lego_conv3_wino_bwd_weight(const float* gy, int ldg, const float*
     McPair b{h, ldh, Din, P_cap, pair_info, 0, 0};
     Epi e = make_epi(du, Din);
     e.tap_stride = (size_t)Dout * Din;
+    if (lego_conv3_wino_du_slabs(Dout, Din, P_cap) > 1)      // long reduction: one slab per k split, plain stores
+        return launch_tn_long<true>(Dout, Din, P_cap, P_dyn, a, b, e, 4, (hipStream_t)stream, "lego_conv3_wino_bwd_weight");
     return launch_tn(Dout, Din, P_cap, P_dyn, a, b, e, 4, (hipStream_t)stream, "lego_conv3_wino_bwd_weight");
 }
 
 #ifdef LEGO_TUNING_HOOKS   // `make tune` only (liblego_hip_tune.so, tools/*_variants.py): never in the product library
+namespace lego { __device__ unsigned long long g_clock_probe[4]; }
+// accumulated (core cycles, 100 MHz ticks) of slot 0 = Winograd kernel, 1 = row-strip kernel; reset != 0 clears them
+extern "C" int lego_debug_clock(unsigned long long* out4, int reset) {
+    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(lego::g_clock_probe), sizeof(unsigned long long) * 4) != hipSuccess) return set_error("clock probe read");
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(lego::g_clock_probe), z, sizeof(z)); }
+    return 0;
+}
 // ---- internal tuning hook (not part of the public ABI): plain NT product with a selectable tile config
 extern "C" int lego_debug_gemm_nt(int variant, const float* x, const float* W, const float* bias, float* out,
                                   int M, int N, int K, void* stream) {

@@ -137,6 +137,10 @@ __device__ __forceinline__ void strip_pass(const ALoad& la0, const BLoad& lb0, E
         read_frags(A_, B_, 1, fa1, fb1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) mfma_j(fa0, fb0, j);
+        // ONE scheduling pin per tile: left alone, the compiler lifts the zeroing selects of `commit` (and with them the
+        // s_waitcnt vmcnt(0) on the staged global loads) to the TOP of the tile to free registers, which halves the
+        // distance between a tile's loads and their first use and stalls every MFMA behind that wait
+        __builtin_amdgcn_sched_barrier(0);
         commit(An, Bn);                     // unconditional: past the end this writes the unused buffer
         fetch(k0 + 2 * BK);
 #pragma unroll
@@ -178,6 +182,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void strip_kernel(GemmDims dims, ALo
 #pragma unroll
         for (int j = 0; j < 4; ++j) rb[j] = lb.row(n0 + (threadIdx.x >> 3) + 64 * j);
     }
+    LEGO_CLOCK_BEGIN
     for (int m0 = strip0; m0 < strip_end; m0 += sp.sub) {
         const int m_end = min(strip_end, m0 + sp.sub);
         const int nf = (m_end - m0 + 15) >> 4;              // block-uniform
@@ -189,6 +194,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void strip_kernel(GemmDims dims, ALo
             default: strip_pass<8, B_MC>(la, lb, epi, As0, Bs0, rb, m0, m_end, n0, K); break;
         }
     }
+    LEGO_CLOCK_END(1)
 }
 
 }  // namespace lego

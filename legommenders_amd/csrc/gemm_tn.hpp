@@ -18,7 +18,7 @@
 namespace lego {
 
 constexpr int TN_BM = 128, TN_BN = 128, TN_THREADS = 512;
-constexpr int TN_INFO_CAP = 2048;            // pair_info words cached in LDS (k range of one workgroup); longer ranges read global
+constexpr int TN_INFO_CAP = 2048;            // pair_info words cached in LDS = the longest k range of one workgroup (host: tn_split)
 
 struct TnDims {
     int M, N, K;                 // output M x N, static bound of the reduction length
@@ -67,11 +67,11 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(TnDims dims, ALoad la, B
     la.K = kend; lb.K = kend;
     la.prepare(tap); lb.prepare(tap);
     if constexpr (A2 || B2) {
-        const int n_info = min(kend - kbeg, TN_INFO_CAP);
+        const int n_info = kend - kbeg;                  // <= TN_INFO_CAP: the host picks the split accordingly
         const int* src = A2 ? la.info_src() : lb.info_src();
         for (int i = tid; i < n_info; i += NT) s_info[i] = src[kbeg + i];
-        if constexpr (A2) la.cache(s_info, kbeg, n_info);
-        if constexpr (B2) lb.cache(s_info, kbeg, n_info);
+        if constexpr (A2) la.cache(s_info, kbeg);
+        if constexpr (B2) lb.cache(s_info, kbeg);
         __syncthreads();
     }
 
@@ -82,8 +82,8 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(TnDims dims, ALoad la, B
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int kk = k0 + kr + STEP * j;
-            if constexpr (A2) la.load2(kk, m0 + c4, r.a[j], r.pa[j], r.a2[j], r.pa2[j]); else r.a[j] = la.load(kk, m0 + c4, r.pa[j]);
-            if constexpr (B2) lb.load2(kk, n0 + c4, r.b[j], r.pb[j], r.b2[j], r.pb2[j]); else r.b[j] = lb.load(kk, n0 + c4, r.pb[j]);
+            if constexpr (A2) la.template load2<true>(kk, m0 + c4, r.a[j], r.pa[j], r.a2[j], r.pa2[j]); else r.a[j] = la.load(kk, m0 + c4, r.pa[j]);
+            if constexpr (B2) lb.template load2<true>(kk, n0 + c4, r.b[j], r.pb[j], r.b2[j], r.pb2[j]); else r.b[j] = lb.load(kk, n0 + c4, r.pb[j]);
         }
     };
     auto commit = [&](const Regs& r, float* A_, float* B_) {
@@ -102,23 +102,43 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(TnDims dims, ALoad la, B
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[a][v] = 0.f;
-    auto tile_mfma = [&](const float* A_, const float* B_) {
+    // fragments of k group q+1 are read while the MFMAs of group q run (two fragment register sets): read just in time, every
+    // pair of MFMAs waited on its own ds_read (s_waitcnt lgkmcnt before each pair in the round-1 code)
+    auto read_frags = [&](const float* A_, const float* B_, int q, float (&f)[12]) {
 #pragma unroll
-        for (int q = 0; q < BK / 8; ++q) {
-            float fa[2][4], fb[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = 8 * q + 4 * lh + j;        // lane half h takes k = 8q + 4h + j for MFMA j, A and B alike
-                fa[0][j] = A_[k * BM + wm * 64 + li];
-                fa[1][j] = A_[k * BM + wm * 64 + 32 + li];
-                fb[j] = B_[k * BN + wn * 32 + li];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][j], fb[j], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][j], fb[j], acc[1], 0, 0, 0);
-            }
+        for (int j = 0; j < 4; ++j) {
+            const int k = 8 * q + 4 * lh + j;            // lane half h takes k = 8q + 4h + j for MFMA j, A and B alike
+            f[j] = A_[k * BM + wm * 64 + li];
+            f[4 + j] = A_[k * BM + wm * 64 + 32 + li];
+            f[8 + j] = B_[k * BN + wn * 32 + li];
         }
+    };
+    auto mfma8 = [&](const float (&f)[12]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[j], f[8 + j], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[4 + j], f[8 + j], acc[1], 0, 0, 0);
+        }
+    };
+    auto tile_mfma = [&](const float* A_, const float* B_) {
+        float f0[12], f1[12];
+        read_frags(A_, B_, 0, f0);
+        read_frags(A_, B_, 1, f1);
+        mfma8(f0);
+        read_frags(A_, B_, 2, f0);
+        mfma8(f1);
+        read_frags(A_, B_, 3, f1);
+        mfma8(f0);
+        mfma8(f1);
+        // order for the scheduler: the ds_reads of a k group BEFORE the 8 MFMAs of the previous group, not one ds_read in
+        // front of every MFMA (0x100 = DS read, 0x008 = MFMA; a ds_read2st64_b32 carries two of the twelve fragment words)
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
     };
 
     // tile t lives in LDS stage t & 1; its global loads are issued at the top of iteration t - 2 and committed at the bottom of

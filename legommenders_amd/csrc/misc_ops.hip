@@ -161,15 +161,21 @@ __global__ void conv3_wino_pack_kernel(const float* __restrict__ w, float* __res
     }
 }
 // ... and its transpose for the gradient: dw[:, :, 0] += du0 + (du1+du2)/2, [1] += (du1-du2)/2, [2] += (du1+du2)/2 + du3
-__global__ void conv3_wino_unpack_add_kernel(float* __restrict__ du, float* __restrict__ dw, int Dout, int Din) {
+// du holds n_slabs partial [4][Dout][Din] results (one per k split of the weight-gradient launch); a single slab is an
+// atomics accumulator and is handed back clean
+__global__ void conv3_wino_unpack_add_kernel(float* __restrict__ du, int n_slabs, float* __restrict__ dw, int Dout, int Din) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const int per = Dout * Din;
     if (e >= per) return;
-    const float a = du[e], b = du[per + e], c = du[2 * per + e], d = du[3 * per + e];
+    float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+    for (int s = 0; s < n_slabs; ++s) {
+        const float* p = du + (size_t)s * 4 * per;
+        a += p[e]; b += p[per + e]; c += p[2 * per + e]; d += p[3 * per + e];
+    }
     atomicAdd(dw + 3 * e, a + 0.5f * (b + c));
     atomicAdd(dw + 3 * e + 1, 0.5f * (b - c));
     atomicAdd(dw + 3 * e + 2, 0.5f * (b + c) + d);
-    du[e] = 0.f; du[per + e] = 0.f; du[2 * per + e] = 0.f; du[3 * per + e] = 0.f;    // accumulator handed back clean
+    if (n_slabs == 1) { du[e] = 0.f; du[per + e] = 0.f; du[2 * per + e] = 0.f; du[3 * per + e] = 0.f; }
 }
 
 __global__ void plan_dense_kernel(const int* __restrict__ mask, int n, int L, int* counters, int* seg_off, int* rowinfo) {
@@ -236,6 +242,52 @@ __global__ void nrms_decode_rows_kernel(const int* __restrict__ row_tok, int R_c
     tokinfo[r] = v >= 0 ? RI_LIVE : 0;
 }
 
+// Gradients of the two small embedding tables of ConcatInputer (concat_inputer.py:58-114) straight from the segment
+// layout: an item's sequence is [title..., SEP, category, SEP], so of its L rows exactly three feed these tables -- rows
+// L-3 and L-1 the [SEP] row of the special-id table, row L-2 the item's category row.  One workgroup per 32 items, one wave
+// per item at a time, lane = 4 columns; SEP sums stay in registers, category sums in an LDS image of the table; one round of
+// global atomics per workgroup.  (Round 1 ran the generic small-table scatter twice over ALL sequence rows: 2 x 62 us per
+// NRMS step to find the three rows per item.)
+constexpr int kSmallTableRows = 32;          // rows of a table that the LDS-accumulating scatter kernels can hold
+constexpr int kSpecItems = 32;
+__global__ __launch_bounds__(256) void nrms_special_grads_kernel(const int* __restrict__ seg_off, int n_cap, const int* __restrict__ n_dyn,
+                                                                 const int* __restrict__ idx_cat, const float* __restrict__ g, int ld,
+                                                                 int width, float* g_sep, float* g_cat, int ld_cat, int n_cat) {
+    __shared__ float tab[kSmallTableRows][256];
+    __shared__ float sep[4][256];
+    const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
+    const int first = blockIdx.x * kSpecItems;
+    if (first >= n) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.y * 256 + 4 * lane;
+    for (int e = threadIdx.x; e < n_cat * 256; e += 256) (&tab[0][0])[e] = 0.f;
+    __syncthreads();
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int i = first + wave; i < min(first + kSpecItems, n); i += 4) {
+        const int beg = seg_off[i], L = seg_off[i + 1] - beg;
+        if (L < 3 || c >= width) continue;
+        const float* r = g + (size_t)(beg + L - 3) * ld + c;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(r), b = *reinterpret_cast<const f32x4*>(r + ld),
+                    d = *reinterpret_cast<const f32x4*>(r + 2 * (size_t)ld);
+        s += a + d;
+        const int cat = idx_cat[beg + L - 2];
+        if (cat >= 0 && cat < n_cat) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) atomicAdd(&tab[cat][4 * lane + k], b[k]);
+        }
+    }
+    *reinterpret_cast<f32x4*>(&sep[wave][4 * lane]) = s;
+    __syncthreads();
+    const int cc = blockIdx.y * 256 + threadIdx.x;
+    if (cc < width) {
+        atomicAdd(g_sep + cc, (sep[0][threadIdx.x] + sep[1][threadIdx.x]) + (sep[2][threadIdx.x] + sep[3][threadIdx.x]));
+        for (int t = 0; t < n_cat; ++t) {
+            const float v = tab[t][threadIdx.x];
+            if (v != 0.f) atomicAdd(g_cat + (size_t)t * ld_cat + cc, v);
+        }
+    }
+}
+
 // x[r,:] *= live(rowinfo[r]) * dropout scale  (backward of a masked + dropped projection output)
 __global__ void mask_dropout_rows_kernel(float* __restrict__ x, int ld, int R_cap, const int* __restrict__ R_dyn, int width,
                                          const int* __restrict__ rowinfo, Dropout drop) {
@@ -284,7 +336,6 @@ __global__ void scatter_add_rows_kernel(float* grad_table, int ld_table, int wid
 // rows x 256 columns: each wave loads its 4 rows at once (lane = columns lane, lane+64, ...: coalesced, and the LDS
 // adds below are bank-conflict free), adds them into an LDS image of the table (ds_add_f32), then the touched table
 // rows are added to memory ONCE per (workgroup, row, column).
-constexpr int kSmallTableRows = 32;
 constexpr int kSmallChunk = 16;
 __global__ __launch_bounds__(256) void scatter_add_small_kernel(float* grad_table, int ld_table, int width, int table_rows,
                                                                 const int* __restrict__ idx, int rows_cap,
@@ -913,17 +964,73 @@ __global__ __launch_bounds__(kUT_NW * 64) void user_tower_train_fast_kernel(
 }
 
 // ------------------------------------------------------------------ Adam
-__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            long long n, float step_size, float beta1, float beta2, float eps, float inv_sqrt_bc2, float gscale,
-                            int zero_grad) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float gr = g[i] * gscale;
-        if (zero_grad) g[i] = 0.f;            // the next step accumulates into a clean buffer: no separate fill launch
-        const float mi = beta1 * m[i] + (1.f - beta1) * gr;
-        const float vi = beta2 * v[i] + (1.f - beta2) * gr * gr;
+struct AdamCoef { float step_size, beta1, beta2, eps, inv_sqrt_bc2, gscale; int zero_grad; };
+
+__device__ __forceinline__ void adam4(const AdamCoef& a, f32x4& p, f32x4& g, f32x4& m, f32x4& v) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float gr = g[i] * a.gscale;
+        const float mi = a.beta1 * m[i] + (1.f - a.beta1) * gr;
+        const float vi = a.beta2 * v[i] + (1.f - a.beta2) * gr * gr;
         m[i] = mi; v[i] = vi;
-        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
-        p[i] -= step_size * (mi / denom);
+        p[i] -= a.step_size * (mi / (sqrtf(vi) * a.inv_sqrt_bc2 + a.eps));
+        if (a.zero_grad) g[i] = 0.f;          // the next step accumulates into a clean buffer: no separate fill launch
+    }
+}
+
+// 16 B per lane and array: the dense update of an embedding table is pure HBM streaming (4 reads + 4 writes per element)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long n4, AdamCoef a) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        f32x4 pp = reinterpret_cast<f32x4*>(p)[i], gg = reinterpret_cast<f32x4*>(g)[i];
+        f32x4 mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+        adam4(a, pp, gg, mm, vv);
+        reinterpret_cast<f32x4*>(p)[i] = pp; reinterpret_cast<f32x4*>(m)[i] = mm; reinterpret_cast<f32x4*>(v)[i] = vv;
+        if (a.zero_grad) reinterpret_cast<f32x4*>(g)[i] = gg;
+    }
+}
+
+// elements [first, n) one by one: the tail of a buffer whose length is not a multiple of 4, or an unaligned buffer
+__global__ void adam_scalar_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                   long long first, long long n, AdamCoef a) {
+    for (long long i = first + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gr = g[i] * a.gscale;
+        if (a.zero_grad) g[i] = 0.f;
+        const float mi = a.beta1 * m[i] + (1.f - a.beta1) * gr;
+        const float vi = a.beta2 * v[i] + (1.f - a.beta2) * gr * gr;
+        m[i] = mi; v[i] = vi;
+        p[i] -= a.step_size * (mi / (sqrtf(vi) * a.inv_sqrt_bc2 + a.eps));
+    }
+}
+
+// The same update over the rows of a [rows, width] table, SKIPPING rows whose "ever touched" bit is clear.  Exactly the dense
+// result: a row that never received a gradient has g = m = v = 0, for which Adam's update is 0 and m, v stay 0 -- such a row
+// is left alone, bit for bit, until its first gradient arrives; from then on it is updated every step like the dense rule
+// demands (its momentum keeps moving it).  MIND-small titles use a small part of the 400 k GloVe vocabulary, so most of the
+// 410 MB x 4 arrays is never read.  One wave per row.
+__global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, int rows, int width,
+                                                        const uint8_t* __restrict__ touched, AdamCoef a) {
+    const int lane = threadIdx.x & 63;
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4) {
+        if (touched[r] == 0) continue;
+        const size_t base = (size_t)r * width;
+        for (int c = lane * 4; c < width; c += 256) {
+            f32x4 pp = *reinterpret_cast<f32x4*>(p + base + c), gg = *reinterpret_cast<f32x4*>(g + base + c);
+            f32x4 mm = *reinterpret_cast<f32x4*>(m + base + c), vv = *reinterpret_cast<f32x4*>(v + base + c);
+            adam4(a, pp, gg, mm, vv);
+            *reinterpret_cast<f32x4*>(p + base + c) = pp; *reinterpret_cast<f32x4*>(m + base + c) = mm;
+            *reinterpret_cast<f32x4*>(v + base + c) = vv;
+            if (a.zero_grad) *reinterpret_cast<f32x4*>(g + base + c) = gg;
+        }
+    }
+}
+
+__global__ void mark_rows_kernel(const int* __restrict__ idx, int n_cap, const int* __restrict__ n_dyn, int rows, uint8_t* touched) {
+    const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const int i = idx[e];
+        if (i >= 0 && i < rows) touched[i] = 1;             // racing writers store the same value
     }
 }
 
@@ -1010,9 +1117,10 @@ extern "C" int lego_conv3_wino_pack(const float* w, float* u, float* ut, int Dou
     hipLaunchKernelGGL(conv3_wino_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, ST, w, u, ut, Dout, Din);
     return check_launch("lego_conv3_wino_pack");
 }
-extern "C" int lego_conv3_wino_unpack_add(float* du, float* dw, int Dout, int Din, void* stream) {
+extern "C" int lego_conv3_wino_unpack_add(float* du, int n_slabs, float* dw, int Dout, int Din, void* stream) {
+    LEGO_REQUIRE(n_slabs >= 1, "lego_conv3_wino_unpack_add: n_slabs=%d", n_slabs);
     const int n = Dout * Din;
-    hipLaunchKernelGGL(conv3_wino_unpack_add_kernel, dim3((n + 255) / 256), dim3(256), 0, ST, du, dw, Dout, Din);
+    hipLaunchKernelGGL(conv3_wino_unpack_add_kernel, dim3((n + 255) / 256), dim3(256), 0, ST, du, n_slabs, dw, Dout, Din);
     return check_launch("lego_conv3_wino_unpack_add");
 }
 
@@ -1079,6 +1187,17 @@ extern "C" int lego_scatter_add_rows(float* grad_table, int ld_table, int width,
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(blocks), dim3(256), 0, ST, grad_table, ld_table, width, idx, rows_cap, rows_dyn, g, ld_g);
     return check_launch("lego_scatter_add_rows");
+}
+
+extern "C" int lego_nrms_special_grads(const int32_t* seg_off, int n_cap, const int32_t* n_dyn, const int32_t* idx_cat,
+                                       const float* g, int ld, int width, float* g_sep, float* g_cat, int ld_cat, int n_cat,
+                                       void* stream) {
+    LEGO_REQUIRE((width & 3) == 0 && (ld & 3) == 0 && n_cat <= kSmallTableRows, "lego_nrms_special_grads: width=%d ld=%d must be multiples of 4, n_cat=%d <= %d",
+                 width, ld, n_cat, kSmallTableRows);
+    if (n_cap <= 0) return 0;
+    hipLaunchKernelGGL(nrms_special_grads_kernel, dim3((n_cap + kSpecItems - 1) / kSpecItems, (width + 255) / 256), dim3(256), 0, ST,
+                       seg_off, n_cap, n_dyn, idx_cat, g, ld, width, g_sep, g_cat, ld_cat, n_cat);
+    return check_launch("lego_nrms_special_grads");
 }
 
 extern "C" int lego_gather_i32(const int32_t* table, const int32_t* idx, int n_cap, const int32_t* n_dyn, int32_t* out, void* stream) {
@@ -1199,18 +1318,49 @@ extern "C" int lego_relu_bwd(float* g, int ldg, const float* ref, int ldr, int r
     return check_launch("lego_relu_bwd");
 }
 
+static AdamCoef adam_coef(float lr, float beta1, float beta2, float eps, int step, float grad_scale, int zero_grad) {
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    return AdamCoef{(float)((double)lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale, zero_grad};
+}
+
 extern "C" int lego_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                               float eps, int step, float grad_scale, int zero_grad, void* stream) {
     LEGO_REQUIRE(step >= 1, "lego_adam_step: step is 1-based (got %d)", step);
     if (n <= 0) return 0;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    const float step_size = (float)((double)lr / bc1);
-    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, ST, p, g, m, v, (long long)n, step_size, beta1, beta2, eps,
-                       inv_sqrt_bc2, grad_scale, zero_grad);
+    const AdamCoef a = adam_coef(lr, beta1, beta2, eps, step, grad_scale, zero_grad);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                           reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    const long long n4 = aligned ? n / 4 : 0;
+    if (n4 > 0) {
+        const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+        hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, ST, p, g, m, v, n4, a);
+    }
+    if (4 * n4 < n) {
+        const long long rest = n - 4 * n4;
+        const int blocks = (int)((rest + 255) / 256 < 4096 ? (rest + 255) / 256 : 4096);
+        hipLaunchKernelGGL(adam_scalar_kernel, dim3(blocks), dim3(256), 0, ST, p, g, m, v, 4 * n4, (long long)n, a);
+    }
     return check_launch("lego_adam_step");
+}
+
+extern "C" int lego_adam_step_rows(float* p, float* g, float* m, float* v, int rows, int width, const uint8_t* touched,
+                                   float lr, float beta1, float beta2, float eps, int step, float grad_scale, int zero_grad,
+                                   void* stream) {
+    LEGO_REQUIRE(step >= 1, "lego_adam_step_rows: step is 1-based (got %d)", step);
+    LEGO_REQUIRE((width & 3) == 0 && touched != nullptr, "lego_adam_step_rows: width=%d must be a multiple of 4, touched non-null", width);
+    if (rows <= 0) return 0;
+    const int blocks = (rows + 3) / 4 < 16384 ? (rows + 3) / 4 : 16384;
+    hipLaunchKernelGGL(adam_rows_kernel, dim3(blocks), dim3(256), 0, ST, p, g, m, v, rows, width, touched,
+                       adam_coef(lr, beta1, beta2, eps, step, grad_scale, zero_grad));
+    return check_launch("lego_adam_step_rows");
+}
+
+extern "C" int lego_mark_rows(const int32_t* idx, int n_cap, const int32_t* n_dyn, int rows, uint8_t* touched, void* stream) {
+    if (n_cap <= 0) return 0;
+    const int blocks = (n_cap + 255) / 256 < 1024 ? (n_cap + 255) / 256 : 1024;
+    hipLaunchKernelGGL(mark_rows_kernel, dim3(blocks), dim3(256), 0, ST, idx, n_cap, n_dyn, rows, touched);
+    return check_launch("lego_mark_rows");
 }
 
 extern "C" int lego_sample_negatives(const int32_t* row_user, const int32_t* row_item, const int32_t* neg_list,

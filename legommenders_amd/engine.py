@@ -187,6 +187,7 @@ class _Base:
         return self.user[:n].clone()
 
     fused_grads = None      # set by bind_grads(): enables the fused user tower (forward writes its gradient partials)
+    touched_rows = None     # uint8 [V] flags of the trainable token table's rows that have received a gradient (TrainStep)
 
     def bind_grads(self, G):
         """Let training forwards write gradient partials directly (TrainStep binds its flat grad views once)."""
@@ -243,7 +244,8 @@ class NamlEngine(_Base):
         self._slot_mask_step, self._mask_step = {}, -1
         self.wino_u = self._f(4, D, D)
         self.wino_ut = self._f(4, D, D)                   # the same sets transposed (data gradient)
-        self.wino_du = self._f(4, D, D)
+        self.wino_slabs = _lib.lib().lego_conv3_wino_du_slabs(D, D, max(self.Pc, 1)) if self.wino else 1
+        self.wino_du = self._f(self.wino_slabs, 4, D, D)     # one partial result per k split of the weight gradient
         # backward workspace
         self.d_user = self._f(B, D)
         self.d_items = self._f(self.NIc, D)
@@ -501,7 +503,7 @@ class NamlEngine(_Base):
         if self.wino:
             self.kk(m, "conv3_bwd_weight", "lego_conv3_wino_bwd_weight", _ptr(self.dY), D, _ptr(self.H), D,
                     _ptr(self.pair_info), self.Pc, self.cnt(5), _ptr(self.wino_du), D, D)
-            self.kk(m, None, "lego_conv3_wino_unpack_add", _ptr(self.wino_du), _ptr(G["item_op.cnn.weight"]), D, D)
+            self.kk(m, None, "lego_conv3_wino_unpack_add", _ptr(self.wino_du), self.wino_slabs, _ptr(G["item_op.cnn.weight"]), D, D)
         else:
             self.kk(m, "conv3_bwd_weight", "lego_conv3_bwd_weight", _ptr(self.dY), D, _ptr(self.H), D, _ptr(self.rowinfo),
                     _ptr(self.dwt), self.Rc, self.cnt(0), D, D)
@@ -665,13 +667,12 @@ class NrmsEngine(_Base):
              _ptr(ws["d_o"]), D, rows, rows_dyn, D, D, 0, None, 0, 1.0, None, None, None, None, None, st)
         self.kk(torch.cuda.current_stream(), "mhsa_core_bwd_" + pre[:4], "lego_mhsa_core_bwd", _ptr(ws["qkv"]), 3 * D, _ptr(seg_off),
                 n_cap, n_dyn, D, self.heads, _ptr(ws["d_o"]), D, _ptr(ws["probs"]), ws["Lmax"],
-                self.drop(self.p_att, site, training), rows, _ptr(ws["d_qkv"]), 3 * D)
+                self.drop(self.p_att, site, training), rows, _ptr(ws["d_qkv"]), 3 * D,
+                _ptr(G[pre + "multi_head_attention.in_proj_bias"]))      # bias gradient = column sums of d_qkv, fused
         if sw is not m:
             ev[1].record(m)
             sw.wait_event(ev[1])
-        # ---- side, group 2: in-projection bias and weight gradients
-        call("lego_colsum", _ptr(ws["d_qkv"]), 3 * D, rows, rows_dyn, None, 3 * D,
-             _ptr(G[pre + "multi_head_attention.in_proj_bias"]), sp)
+        # ---- side, group 2: in-projection weight gradient (its bias gradient came out of the attention core)
         call("lego_linear_bwd_weight", _ptr(ws["d_qkv"]), 3 * D, x_ptr, D,
              _ptr(G[pre + "multi_head_attention.in_proj_weight"]), D, rows, rows_dyn, 3 * D, D, None, None, sp)
         call("lego_linear_bwd_data", _ptr(ws["d_qkv"]), 3 * D, _ptr(P[pre + "multi_head_attention.in_proj_weight"]), D,
@@ -744,12 +745,11 @@ class NrmsEngine(_Base):
                       self.cnt(3), self.hist_off, B, None, self.d_user, SITE_USER_ATT, training, st, sev[0:2])
         self._att_bwd("item_op.", self.item_ws, G, _ptr(self.E), _ptr(self.dE), self.cnt(0), self.seg_off, self.NIc,
                       self.cnt(1), self.d_items, SITE_ITEM_ATT, training, st, sev[2:4])
-        # embedding tables: the three summed look-ups of ConcatInputer.get_embeddings
-        call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.__cat_inputer_special_ids.weight"]), D, D, 3,
-             _ptr(self.idx_spec), self.Rc, self.cnt(0), _ptr(self.dE), D, st)
-        call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.category.weight"]), D, D,
-             G["embedding_vocab_table.category.weight"].shape[0], _ptr(self.idx_cat),
-             self.Rc, self.cnt(0), _ptr(self.dE), D, st)
+        # embedding tables: the three summed look-ups of ConcatInputer.get_embeddings.  [SEP] (id 2 of the special table) and the
+        # category row come from fixed places of every item's sequence (lego_nrms_special_grads)
+        g_spec, g_cat = G["embedding_vocab_table.__cat_inputer_special_ids.weight"], G["embedding_vocab_table.category.weight"]
+        call("lego_nrms_special_grads", _ptr(self.seg_off), self.NIc, self.cnt(1), _ptr(self.idx_cat), _ptr(self.dE), D, D,
+             _ptr(g_spec, 2 * D), _ptr(g_cat), D, g_cat.shape[0], st)
         if self.glove:
             E0 = self.E0
             call("lego_mask_dropout_rows", _ptr(self.dE), D, self.Rc, self.cnt(0), D, _ptr(self.tokinfo),
@@ -759,9 +759,11 @@ class NrmsEngine(_Base):
             call("lego_linear_bwd_weight", _ptr(self.dE), D, _ptr(self.X), E0,
                  _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Rc, self.cnt(0), D, E0, None, None, st)
         else:
-            call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.glove.weight"]), D, D,
-                 G["embedding_vocab_table.glove.weight"].shape[0], _ptr(self.idx_tok),
+            V = G["embedding_vocab_table.glove.weight"].shape[0]
+            call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.glove.weight"]), D, D, V, _ptr(self.idx_tok),
                  self.Rc, self.cnt(0), _ptr(self.dE), D, st)
+            if self.touched_rows is not None:       # TrainStep: rows that have ever had a gradient (row-skipping dense Adam)
+                call("lego_mark_rows", _ptr(self.idx_tok), self.Rc, self.cnt(0), V, _ptr(self.touched_rows), st)
         if sw is not m:
             sev[4].record(sw)
             m.wait_event(sev[4])                     # every gradient is ordered on the caller's stream again

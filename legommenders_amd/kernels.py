@@ -267,7 +267,7 @@ def mhsa_bwd(ctx, gy):
     go = linear_bwd_data(gyc, ctx.out_w)
     gqkv = torch.empty(R, 3 * D, dtype=torch.float32, device=dev)
     call("lego_mhsa_core_bwd", _ptr(ctx.qkv), 3 * D, _ptr(ctx.seg_off), n, None, D, ctx.heads, _ptr(go), D, _ptr(ctx.probs), L,
-         _drop(ctx.drop), R, _ptr(gqkv), 3 * D, _stream())
+         _drop(ctx.drop), R, _ptr(gqkv), 3 * D, None, _stream())
     gin_w = torch.zeros(3 * D, D, dtype=torch.float32, device=dev)
     gin_b = torch.zeros(3 * D, dtype=torch.float32, device=dev)
     linear_bwd_weight(gqkv, ctx.xc, gin_w)

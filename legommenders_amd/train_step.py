@@ -170,6 +170,16 @@ class TrainStep:
         else:
             raise ValueError(f"unknown model kind {kind!r} (the HIP path covers naml and nrms)")
         self.engines = [self.engine]
+        # trainable token table (embed/null: nn.Embedding(V, D), dense gradient + dense Adam in the reference,
+        # loader/embedding_hub.py:325-335): it sits last in the flat buffers; its Adam step skips rows that have never had a
+        # gradient -- bit-identical to the dense rule (g = m = v = 0 -> zero update), see lego_adam_step_rows
+        self.table = None
+        for k in last:
+            o, (rows, width) = self.fp.offsets[k], params[k].shape
+            assert o == self.fp.split and o + rows * width == self.fp.numel, "the token table must close the flat buffer"
+            self.table = (o, rows, width)
+            self.touched = torch.zeros(rows, dtype=torch.uint8, device=dev)
+            self.engine.touched_rows = self.touched
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         # two batch / plan slots: step N+1 is sampled and planned on `pre` while step N computes
@@ -243,6 +253,8 @@ class TrainStep:
         and the wire time is bounded by bandwidth, not by one serial 410 MB launch."""
         if not (self.world > 1 or self.force_allreduce):
             return
+        if getattr(self, "table", None) is not None:         # a row touched on ANY rank has a gradient everywhere after the sum
+            torch.distributed.all_reduce(self.touched, op=torch.distributed.ReduceOp.MAX, group=self.pg)
         g = self.fp.grad
         per = max(1, self.BUCKET_BYTES // 4)
         if g.numel() <= per:
@@ -297,20 +309,35 @@ class TrainStep:
     def apply_update(self):
         """Adam + linear schedule over the flat buffers (gradient scaled by 1/world, then cleared)"""
         self.step_idx += 1
-        call("lego_adam_step", _ptr(self.fp.flat), _ptr(self.fp.grad), _ptr(self.fp.m), _ptr(self.fp.v),
-             self.fp.numel, self.lr_at(self.step_idx - 1), 0.9, 0.999, 1e-8, self.step_idx, 1.0 / self.world, 1, _stream())
+        fp, lr, st = self.fp, self.lr_at(self.step_idx - 1), _stream()
+        dense = fp.numel if self.table is None else self.table[0]
+        call("lego_adam_step", _ptr(fp.flat), _ptr(fp.grad), _ptr(fp.m), _ptr(fp.v), dense, lr, 0.9, 0.999, 1e-8,
+             self.step_idx, 1.0 / self.world, 1, st)
+        if self.table is not None:
+            o, rows, width = self.table
+            call("lego_adam_step_rows", _ptr(fp.flat, o), _ptr(fp.grad, o), _ptr(fp.m, o), _ptr(fp.v, o), rows, width,
+                 _ptr(self.touched), lr, 0.9, 0.999, 1e-8, self.step_idx, 1.0 / self.world, 1, st)
         self._grad_clean = True                    # Adam cleared the gradient buffer as it consumed it
 
     # ---- optimiser / scheduler state in the shape the reference checkpoints (base_lego.py:257-267)
     def optimizer_state(self):
-        return {"m": self.fp.m.detach().cpu(), "v": self.fp.v.detach().cpu(), "step": self.step_idx, "names": list(self.fp.names),
-                "offsets": dict(self.fp.offsets), "format": "lego_flat_adam"}
+        st = {"m": self.fp.m.detach().cpu(), "v": self.fp.v.detach().cpu(), "step": self.step_idx, "names": list(self.fp.names),
+              "offsets": dict(self.fp.offsets), "format": "lego_flat_adam"}
+        if self.table is not None:
+            st["touched"] = self.touched.detach().cpu()
+        return st
 
     def load_optimizer_state(self, st):
         if st.get("format") != "lego_flat_adam" or st["m"].numel() != self.fp.m.numel():
             raise ValueError("optimizer state is not a flat-Adam state of this parameter layout")
         self.fp.m.copy_(st["m"]); self.fp.v.copy_(st["v"])
         self.step_idx = int(st["step"])
+        if self.table is not None:                  # rows with a non-zero moment have had a gradient, whatever the file says
+            o, rows, width = self.table
+            mv = (self.fp.m[o:].view(rows, width) != 0).any(1) | (self.fp.v[o:].view(rows, width) != 0).any(1)
+            self.touched.copy_(mv.to(torch.uint8))
+            if "touched" in st:
+                self.touched.copy_(torch.maximum(self.touched, st["touched"].to(self.touched.device)))
 
     def scheduler_state(self):
         return {"last_epoch": self.step_idx, "total_steps": self.total_steps, "warmup": self.warmup, "base_lr": self.lr}

@@ -484,6 +484,7 @@ def test_winograd_conv_matches_direct_and_torch(D, n_items):
     ragged plan, and against torch conv1d item by item: forward, data gradient, weight gradient.  Lengths include
     1 (a pair without a second row), odd and even values."""
     import ctypes
+    from legommenders_amd import _lib
     from legommenders_amd._lib import call
     dev = _dev()
     g = torch.Generator().manual_seed(21)
@@ -527,14 +528,16 @@ def test_winograd_conv_matches_direct_and_torch(D, n_items):
     assert torch.equal(ut, u.transpose(1, 2).contiguous())
     _close(d2.cpu(), d0.cpu(), rtol=2e-5, what="wino bwd_data (transposed sets) vs direct")
     _close(c2.cpu(), c0.cpu(), rtol=2e-5, what="wino bwd_data (transposed sets) column sums")
-    dwt = torch.zeros(3, D, D, device=dev); du = torch.zeros(4, D, D, device=dev)
+    S = _lib.lib().lego_conv3_wino_du_slabs(D, D, Pcap)      # 1 for short reductions (atomics), one slab per k split otherwise
+    dwt = torch.zeros(3, D, D, device=dev); du = torch.full((S, 4, D, D), float("nan") if S > 1 else 0.0, device=dev)
     gw0 = torch.zeros(D, D, 3, device=dev); gw1 = torch.zeros(D, D, 3, device=dev)
     call("lego_conv3_bwd_weight", P(gyd), D, P(hd), D, P(rowinfo), P(dwt), R, P(cnt, 0), D, D, None)
     call("lego_conv3_unpack_add", P(dwt), P(gw0), D, D, None)
     call("lego_conv3_wino_bwd_weight", P(gyd), D, P(hd), D, P(pair), Pcap, P(cnt, 5), P(du), D, D, None)
-    call("lego_conv3_wino_unpack_add", P(du), P(gw1), D, D, None)
+    call("lego_conv3_wino_unpack_add", P(du), S, P(gw1), D, D, None)
     torch.cuda.synchronize()
-    assert float(du.abs().max()) == 0.0                      # the accumulator is handed back clean
+    assert S > 1 or float(du.abs().max()) == 0.0             # a single accumulator is handed back clean; slabs are overwritten
+    assert bool(torch.isfinite(du).all())                    # every slab was written whole (they started as NaN)
     _close(y1.cpu(), y0.cpu(), rtol=2e-5, what="wino fwd vs direct")
     _close(d1.cpu(), d0.cpu(), rtol=2e-5, what="wino bwd_data vs direct")
     _close(c1.cpu(), c0.cpu(), rtol=2e-5, what="wino bwd_data column sums")
@@ -810,3 +813,61 @@ def test_colsum_matches_torch(N, ld):
     call("lego_colsum", _ptr(x), ld, M_cap, _ptr(m_dyn), _ptr(off_dyn), N, _ptr(out), _stream())
     ref = 0.5 + x[off:off + M, :N].double().sum(0)
     _close(out.cpu(), ref.cpu().numpy(), rtol=2e-6, atol=1e-4, what=f"colsum N={N}")
+
+
+def test_trainable_token_table_full_vocabulary():
+    """BASELINE config 3 with config/embed/null.yaml at its real size: a trainable nn.Embedding(400 000, 256) token table,
+    dense gradient and dense Adam in the reference (loader/embedding_hub.py:325-335, base_lego.py:201-204).  Three training
+    steps of the engine route against the oracle's gradients + torch.optim.Adam on the host:
+      * rows that received a gradient follow torch's Adam, INCLUDING rows touched in an earlier step only -- their momentum
+        keeps moving them with a zero gradient (the dense rule; a sparse optimiser would freeze them);
+      * rows never touched are bit-identical to their initial values (Adam's update of g = m = v = 0 is exactly 0), which is
+        what lets lego_adam_step_rows skip them."""
+    from oracle import lego_oracle as O
+    from legommenders_amd.synthetic import init_nrms_params, make_world
+    from legommenders_amd.train_step import DeviceData, TrainStep
+    dev = _dev()
+    D, B, V = 256, 8, 400000
+    w = make_world(seed=31, n_items=600, n_users=200, n_rows=400, V=V)
+    P = init_nrms_params(D=D, V=V, n_cat=w["n_cat"], heads=8, glove=None, seed=3)
+    key = "embedding_vocab_table.glove.weight"
+    assert tuple(P[key].shape) == (V, D)
+    ts = TrainStep("nrms", P, DeviceData(w, dev, seed=5), B, seed=5, glove=False, dropout=False, lr=1e-3, total_steps=0, tail="drop")
+    assert ts.table == (ts.fp.offsets[key], V, D) and ts.fp.names[-1] == key
+    ref = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    opt = torch.optim.Adam(list(ref.values()), lr=1e-3)
+    tables = {k: w[k].astype(np.int64) for k in ("title_tok", "title_len", "cat")}
+    touched_by_step = []
+    for step in range(3):
+        ts.step()
+        torch.cuda.synchronize()
+        cand, hist, hl = (t.cpu().numpy().astype(np.int64) for t in (ts.cand, ts.hist, ts.hist_len))
+        _, _, g = O.loss_and_grads("nrms", {k: v.detach().numpy() for k, v in ref.items()}, tables, cand, hist, hl, heads=8, glove=False)
+        for k, v in ref.items():
+            v.grad = torch.tensor(g[k]).reshape(v.shape)
+        touched_by_step.append(set(np.nonzero(np.abs(g[key]).sum(1))[0].tolist()))
+        opt.step()
+    got = ts.fp.P[key].cpu()
+    want = ref[key].detach()
+    ever = set().union(*touched_by_step)
+    flags = ts.touched.cpu().numpy().astype(bool)
+    assert set(np.nonzero(flags)[0].tolist()) >= ever and flags.sum() <= len(ever) + 64      # (+ ids whose gradient is exactly 0)
+    idx = torch.tensor(sorted(ever))
+    assert float((got[idx] - want[idx]).abs().max()) < 5e-6                                 # lr = 1e-3: three updates of <= 1e-3
+    early_only = sorted(touched_by_step[0] - touched_by_step[1] - touched_by_step[2])
+    assert len(early_only) > 10
+    e = torch.tensor(early_only)
+    one_step = P[key][e] - want[e]
+    assert float(one_step.abs().max()) > 1.5e-3          # more than ONE Adam step of 1e-3: the zero-gradient steps moved them too
+    untouched = torch.ones(V, dtype=torch.bool)
+    untouched[idx] = False
+    assert torch.equal(got[untouched], P[key][untouched]) and torch.equal(want[untouched], P[key][untouched])
+    for k in ref:       # every other parameter follows too.  Adam turns a gradient that is pure rounding noise into a full
+        if k == key:    # +-lr step (the key third of in_proj_bias has a zero true gradient: softmax is shift-invariant), so the
+            continue    # bar is on the distance travelled, not on single elements
+        a, b, p0 = ts.fp.P[k].cpu().reshape(-1), ref[k].detach().reshape(-1), P[k].reshape(-1)
+        if k.endswith("in_proj_bias"):
+            keep = torch.ones_like(p0, dtype=torch.bool)
+            keep[D:2 * D] = False
+            a, b, p0 = a[keep], b[keep], p0[keep]
+        assert float((a - b).norm()) <= 5e-2 * float((b - p0).norm()) + 1e-7, k

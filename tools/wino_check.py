@@ -44,12 +44,13 @@ for p in (0.0, 0.1):
     g1 = lambda: call("lego_conv3_wino_bwd_data", P(gy), D, P(u), P(ut) if os.environ.get("WINO_UT") else None, P(pair), pair.numel(), P(cnt, 5), P(d1), D, D, D, dr, None if os.environ.get("NO_COLSUM") else P(c1), None)
     t0, t1 = bench(g0), bench(g1)
     print(f"bwd_data p={p}: direct {t0:.1f} us  wino {t1:.1f} us  maxdiff {(d0 - d1).abs().max().item():.2e} (scale {d0.abs().max().item():.2f}) colsum rel {((c0 - c1).abs().max() / c0.abs().max()).item():.2e}")
-dwt = torch.zeros(3, D, D, device=dev); du = torch.zeros(4, D, D, device=dev)
+S = _lib.lib().lego_conv3_wino_du_slabs(D, D, pair.numel())
+dwt = torch.zeros(3, D, D, device=dev); du = torch.zeros(S, 4, D, D, device=dev)
 gw0 = torch.zeros(D, D, 3, device=dev); gw1 = torch.zeros(D, D, 3, device=dev)
 call("lego_conv3_bwd_weight", P(gy), D, P(h), D, P(rowinfo), P(dwt), R, P(cnt, 0), D, D, None)
 call("lego_conv3_unpack_add", P(dwt), P(gw0), D, D, None)
 call("lego_conv3_wino_bwd_weight", P(gy), D, P(h), D, P(pair), pair.numel(), P(cnt, 5), P(du), D, D, None)
-call("lego_conv3_wino_unpack_add", P(du), P(gw1), D, D, None)
+call("lego_conv3_wino_unpack_add", P(du), S, P(gw1), D, D, None)
 print(f"bwd_weight maxdiff {(gw0 - gw1).abs().max().item():.2e} (scale {gw0.abs().max().item():.2f})")
 t0 = bench(lambda: call("lego_conv3_bwd_weight", P(gy), D, P(h), D, P(rowinfo), P(dwt), R, P(cnt, 0), D, D, None))
 t1 = bench(lambda: call("lego_conv3_wino_bwd_weight", P(gy), D, P(h), D, P(pair), pair.numel(), P(cnt, 5), P(du), D, D, None))
