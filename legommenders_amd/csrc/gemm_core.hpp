@@ -268,19 +268,17 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_kernel(GemmDims dims, ALoa
         if (more && early) commit(As0 + (buf ^ 1) * SA::kLdsFloats, Bs0 + (buf ^ 1) * SB::kLdsFloats);
         const float* A_ = As0 + buf * SA::kLdsFloats;
         const float* B_ = Bs0 + buf * SB::kLdsFloats;
-        // fragments of k group q+1 are read while the MFMAs of group q run (two fragment register sets, and the order is given
-        // to the scheduler explicitly): left alone, the compiler issues each ds_read right in front of the MFMA that needs it
-        // and every MFMA waits out an LDS round trip
-        f32x4 fa[2][TM], fb[2][TN];
-        auto read_q = [&](int q, int s) {
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
+            f32x4 fa[TM], fb[TN];
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
                 const int row = (wm * TM + a) * 32 + li;
                 if constexpr (A_MC) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) fa[s][a][j] = A_[(8 * q + 4 * lh + j) * BM + row];
+                    for (int j = 0; j < 4; ++j) fa[a][j] = A_[(8 * q + 4 * lh + j) * BM + row];
                 } else {
-                    fa[s][a] = *reinterpret_cast<const f32x4*>(A_ + row * KC_LD + 8 * q + 4 * lh);
+                    fa[a] = *reinterpret_cast<const f32x4*>(A_ + row * KC_LD + 8 * q + 4 * lh);
                 }
             }
 #pragma unroll
@@ -288,36 +286,18 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_kernel(GemmDims dims, ALoa
                 const int col = (wn * TN + b) * 32 + li;
                 if constexpr (B_MC) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) fb[s][b][j] = B_[(8 * q + 4 * lh + j) * BN + col];
+                    for (int j = 0; j < 4; ++j) fb[b][j] = B_[(8 * q + 4 * lh + j) * BN + col];
                 } else {
-                    fb[s][b] = *reinterpret_cast<const f32x4*>(B_ + col * KC_LD + 8 * q + 4 * lh);
+                    fb[b] = *reinterpret_cast<const f32x4*>(B_ + col * KC_LD + 8 * q + 4 * lh);
                 }
             }
-        };
-        auto mfma_q = [&](int s) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
                     for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][a][j], fb[s][b][j], acc[a][b], 0, 0, 0);
-        };
-        read_q(0, 0);
-#pragma unroll
-        for (int q = 0; q < BK / 8; ++q) {
-            if (q + 1 < BK / 8) read_q(q + 1, (q + 1) & 1);
-            mfma_q(q & 1);
-        }
-        {   // DS reads of one k group (an M-contiguous operand's four words pair up into two ds_read2 instructions)
-            constexpr int R = (A_MC ? 2 : 1) * TM + (B_MC ? 2 : 1) * TN, MF = 4 * TM * TN;
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * R, 0);
-#pragma unroll
-            for (int q = 0; q + 2 < BK / 8; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, R, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * MF, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
         }
         if (more && !early) commit(As0 + (buf ^ 1) * SA::kLdsFloats, Bs0 + (buf ^ 1) * SB::kLdsFloats);
         __syncthreads();

@@ -282,6 +282,7 @@ __global__ __launch_bounds__(64 * HPB) void mhsa_bwd_kernel(
                 if (r < L) gq[(size_t)r * ldgq + c] = dq[ct][v] * scale;
             }
         }
+        if (colsum != nullptr) col_add<HD>(dq, scale, colsum + hc * HD, li, lh, live);         // in_proj_bias gradient, Q third
     }
     __syncthreads();
     // ---- orientation 2, lane = key j: dP tiles -> dK, dV

@@ -249,7 +249,7 @@ __global__ void nrms_decode_rows_kernel(const int* __restrict__ row_tok, int R_c
 // global atomics per workgroup.  (Round 1 ran the generic small-table scatter twice over ALL sequence rows: 2 x 62 us per
 // NRMS step to find the three rows per item.)
 constexpr int kSmallTableRows = 32;          // rows of a table that the LDS-accumulating scatter kernels can hold
-constexpr int kSpecItems = 32;
+constexpr int kSpecItems = 8;            // items per workgroup (two per wave): ~440 workgroups at the headline batch
 __global__ __launch_bounds__(256) void nrms_special_grads_kernel(const int* __restrict__ seg_off, int n_cap, const int* __restrict__ n_dyn,
                                                                  const int* __restrict__ idx_cat, const float* __restrict__ g, int ld,
                                                                  int width, float* g_sep, float* g_cat, int ld_cat, int n_cat) {
@@ -292,14 +292,21 @@ __global__ __launch_bounds__(256) void nrms_special_grads_kernel(const int* __re
 __global__ void mask_dropout_rows_kernel(float* __restrict__ x, int ld, int R_cap, const int* __restrict__ R_dyn, int width,
                                          const int* __restrict__ rowinfo, Dropout drop) {
     const int R = R_dyn != nullptr ? min(R_cap, *R_dyn) : R_cap;
-    const long long total = (long long)R * width;
+    // one thread = 4 rows x 1 column: ONE Philox call yields the four keep decisions of that group (the element-per-thread form
+    // ran a whole call per element and threw three quarters of it away: 64-71 us per NRMS step)
+    const long long total = (long long)((R + 3) / 4) * width;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const int r = (int)(e / width);
-        const int c = (int)(e - (long long)r * width);
-        float v = x[(size_t)r * ld + c];
-        if (rowinfo != nullptr && !(rowinfo[r] & RI_LIVE)) v = 0.f;
-        else v *= dropout_scale1(drop, r, c, width);
-        x[(size_t)r * ld + c] = v;
+        const int r0 = (int)(e / width) * 4;
+        const int c = (int)(e - (long long)(r0 / 4) * width);
+        float ds[4];
+        dropout_scale4(drop, r0, c, width, ds);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + i;
+            if (r >= R) break;
+            float* p = x + (size_t)r * ld + c;
+            *p = (rowinfo != nullptr && !(rowinfo[r] & RI_LIVE)) ? 0.f : *p * ds[i];
+        }
     }
 }
 

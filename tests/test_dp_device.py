@@ -94,6 +94,10 @@ def test_two_ranks_follow_the_single_device_trajectory(kind):
     for _ in range(steps):
         ls = [t.compute_gradients()[0].clone() for t in ranks]
         total = ranks[0].fp.grad + ranks[1].fp.grad                # what all_reduce(sum) leaves on every rank
+        if ranks[0].table is not None:                             # ... and all_reduce(MAX) of the touched-row flags (sync_gradients)
+            flags = torch.maximum(ranks[0].touched, ranks[1].touched)
+            for t in ranks:
+                t.touched.copy_(flags)
         for t in ranks:
             t.fp.grad.copy_(total)
             t.apply_update()

@@ -870,4 +870,7 @@ def test_trainable_token_table_full_vocabulary():
             keep = torch.ones_like(p0, dtype=torch.bool)
             keep[D:2 * D] = False
             a, b, p0 = a[keep], b[keep], p0[keep]
-        assert float((a - b).norm()) <= 5e-2 * float((b - p0).norm()) + 1e-7, k
+        # a parameter whose true gradient vanishes (here the user tower's additive hidden layer: |g| ~ 1e-10 << eps) barely moves
+        # and what it does move is rounding noise on both sides: its bar is 2 % of the largest possible movement instead
+        floor = 0.02 * 1e-3 * 3 * float(b.numel()) ** 0.5
+        assert float((a - b).norm()) <= 5e-2 * max(float((b - p0).norm()), floor) + 1e-7, k

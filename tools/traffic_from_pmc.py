@@ -17,8 +17,10 @@ def tag_of(name):
         return "conv3_fwd"
     if "wino_kernel<true>" in n:
         return "conv3_bwd_data"
-    if "gemm_kernel" in n and "McPair" in n:
+    if ("gemm_kernel" in n or "tn_kernel" in n) and "McPair" in n:
         return "conv3_bwd_weight"
+    if "conv3_wino_unpack_add_kernel" in n:
+        return "conv3_bwd_weight_unpack"
     if "strip_kernel" in n and "KcConvA" in n and "KcTapW" in n:
         return "conv3_fwd"
     if "strip_kernel" in n and "KcConvA" in n:
