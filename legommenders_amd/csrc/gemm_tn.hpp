@@ -17,7 +17,8 @@
 
 namespace lego {
 
-constexpr int TN_BM = 128, TN_BN = 128, TN_THREADS = 512;
+constexpr int TN_BM = 128, TN_BN = 128, TN_THREADS = 512;     // the long-reduction configuration (2 x 4 waves of 64 x 32)
+constexpr int TN_BM_S = 64, TN_BN_S = 64, TN_THREADS_S = 256;   // plain-row products: 2 x 2 waves of 32 x 32, four workgroups per CU
 constexpr int TN_INFO_CAP = 2048;            // pair_info words cached in LDS = the longest k range of one workgroup (host: tn_split)
 
 struct TnDims {
@@ -27,13 +28,16 @@ struct TnDims {
     size_t slab_stride;          // SLAB: floats between the partial outputs of consecutive k splits (taps * tap_stride)
 };
 
-constexpr size_t tn_lds_bytes() { return (size_t)(2 * 2 * BK * TN_BM + TN_INFO_CAP) * sizeof(float); }
+constexpr size_t tn_lds_bytes(int bm = TN_BM, int bn = TN_BN, bool info = true) {
+    return (size_t)(2 * BK * (bm + bn) + (info ? TN_INFO_CAP : 0)) * sizeof(float);
+}
 
-template <class ALoad, class BLoad, bool SLAB>
-__global__ __launch_bounds__(TN_THREADS) void tn_kernel(TnDims dims, ALoad la, BLoad lb, EpiArgs e) {
-    constexpr int BM = TN_BM, BN = TN_BN, NT = TN_THREADS;
-    constexpr int STAGE = BK * BM;                       // floats per operand stage ([BK][128])
-    constexpr int PER = BM / 4, STEP = NT / PER;         // 32 float4 per k row, 16 k rows per pass of the workgroup
+template <class ALoad, class BLoad, bool SLAB, int WM_ = 2, int WN_ = 4, int TM = 2>
+__global__ __launch_bounds__(WM_ * WN_ * 64) void tn_kernel(TnDims dims, ALoad la, BLoad lb, EpiArgs e) {
+    constexpr int BM = WM_ * TM * 32, BN = WN_ * 32, NT = WM_ * WN_ * 64;
+    static_assert(BM == BN, "square workgroup tiles (one staging pattern for both operands)");
+    constexpr int STAGE = BK * BM;                       // floats per operand stage ([BK][BM])
+    constexpr int PER = BM / 4, STEP = NT / PER;         // float4 per k row, k rows per pass of the workgroup (16)
     constexpr int NJ = BK / STEP;                        // 2 float4 per thread, operand and k tile
     constexpr bool A2 = IsDual<ALoad>::value, B2 = IsDual<BLoad>::value;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -44,7 +48,7 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(TnDims dims, ALoad la, B
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int wm = wave >> 2, wn = wave & 3;             // 2 x 4 waves, wave tile 64 x 32
+    const int wm = wave / WN_, wn = wave % WN_;          // WM_ x WN_ waves, wave tile (TM * 32) x 32
 
     int K = dims.K;
     if (dims.k_dyn != nullptr) K = min(K, *dims.k_dyn);
@@ -97,31 +101,31 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(TnDims dims, ALoad la, B
         }
     };
 
-    f32x16 acc[2];
+    f32x16 acc[TM];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[a][v] = 0.f;
     // fragments of k group q+1 are read while the MFMAs of group q run (two fragment register sets): read just in time, every
     // pair of MFMAs waited on its own ds_read (s_waitcnt lgkmcnt before each pair in the round-1 code)
-    auto read_frags = [&](const float* A_, const float* B_, int q, float (&f)[12]) {
+    constexpr int NFR = 4 * (TM + 1);                    // fragment words of one k group: TM A fragments + one B fragment
+    auto read_frags = [&](const float* A_, const float* B_, int q, float (&f)[NFR]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k = 8 * q + 4 * lh + j;            // lane half h takes k = 8q + 4h + j for MFMA j, A and B alike
-            f[j] = A_[k * BM + wm * 64 + li];
-            f[4 + j] = A_[k * BM + wm * 64 + 32 + li];
-            f[8 + j] = B_[k * BN + wn * 32 + li];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) f[4 * a + j] = A_[k * BM + (wm * TM + a) * 32 + li];
+            f[4 * TM + j] = B_[k * BN + wn * 32 + li];
         }
     };
-    auto mfma8 = [&](const float (&f)[12]) {
+    auto mfma8 = [&](const float (&f)[NFR]) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[j], f[8 + j], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[4 + j], f[8 + j], acc[1], 0, 0, 0);
-        }
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int a = 0; a < TM; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[4 * a + j], f[4 * TM + j], acc[a], 0, 0, 0);
     };
     auto tile_mfma = [&](const float* A_, const float* B_) {
-        float f0[12], f1[12];
+        float f0[NFR], f1[NFR];
         read_frags(A_, B_, 0, f0);
         read_frags(A_, B_, 1, f1);
         mfma8(f0);
@@ -132,13 +136,13 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(TnDims dims, ALoad la, B
         mfma8(f1);
         // order for the scheduler: the ds_reads of a k group BEFORE the 8 MFMAs of the previous group, not one ds_read in
         // front of every MFMA (0x100 = DS read, 0x008 = MFMA; a ds_read2st64_b32 carries two of the twelve fragment words)
-        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + 1), 0);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + 1), 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8 * TM, 0);
     };
 
     // tile t lives in LDS stage t & 1; its global loads are issued at the top of iteration t - 2 and committed at the bottom of
@@ -165,10 +169,10 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(TnDims dims, ALoad la, B
     const int col = n0 + wn * 32 + li;
     if (col < N) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                const int row = m0 + wm * 64 + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+                const int row = m0 + (wm * TM + a) * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
                 if (row < M) {
                     float* dst = C + (size_t)row * e.ldc + col;
                     if constexpr (SLAB) *dst = acc[a][v]; else atomicAdd(dst, acc[a][v]);
