@@ -303,6 +303,7 @@ static int pick_split_small(int rows_cap, int M, int N) {
     int s = 1024 / tiles;
     const int max_s = (rows_cap + 127) / 128;       // at least 128 reduction rows per block
     if (s > max_s) s = max_s;
+    if (s >= 16) s &= ~7;                           // a multiple of 8: the k splits can then be dealt to the 8 XCDs (gemm_tn.hpp)
     return s < 1 ? 1 : s;
 }
 
@@ -323,14 +324,15 @@ static int launch_tn_long(int M, int N, int K_cap, const int* k_dyn, const AL& a
                           const char* what) {
     const int tm = (M + TN_BM - 1) / TN_BM, tn = (N + TN_BN - 1) / TN_BN;
     const int split = tn_split(M, N, K_cap, taps);
-    TnDims d{M, N, K_cap, k_dyn, split, taps, (size_t)taps * e.tap_stride};
+    const int deal = split % 8 == 0;
+    TnDims d{M, N, K_cap, k_dyn, split, taps, (size_t)taps * e.tap_stride, tm, tn, deal};
     auto k = tn_kernel<AL, BL, SLAB>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tn_lds_bytes());
         attr_done = true;
     }
-    hipLaunchKernelGGL(k, dim3(tm, tn, taps * split), dim3(TN_THREADS), tn_lds_bytes(), st, d, a, b, e);
+    hipLaunchKernelGGL(k, deal ? dim3(tm * tn * taps * split) : dim3(tm, tn, taps * split), dim3(TN_THREADS), tn_lds_bytes(), st, d, a, b, e);
     return check_launch(what);
 }
 
@@ -344,10 +346,12 @@ static int launch_tn(int M, int N, int K_cap, const int* k_dyn, const AL& a, con
     if constexpr (!IsDual<AL>::value && !IsDual<BL>::value) {
         // 64 x 64 tiles, loads two k tiles ahead (tn_kernel), four workgroups per CU: 27.7 us per launch against 29.7 for the
         // generic tile kernel (one tile ahead) on the path's shapes
-        TnDims d{M, N, K_cap, k_dyn, split, taps, 0};
+        const int tm = (M + 63) / 64, tn = (N + 63) / 64;
+        const int deal = split % 8 == 0;
+        TnDims d{M, N, K_cap, k_dyn, split, taps, 0, tm, tn, deal};
         auto k = tn_kernel<AL, BL, false, 2, 2, 1>;
         constexpr size_t lds = tn_lds_bytes(TN_BM_S, TN_BN_S, false);
-        hipLaunchKernelGGL(k, dim3((M + 63) / 64, (N + 63) / 64, taps * split), dim3(TN_THREADS_S), lds, st, d, a, b, e);
+        hipLaunchKernelGGL(k, deal ? dim3(tm * tn * taps * split) : dim3(tm, tn, taps * split), dim3(TN_THREADS_S), lds, st, d, a, b, e);
         return check_launch(what);
     }
     GemmDims d{M, N, K_cap, nullptr, k_dyn, split};

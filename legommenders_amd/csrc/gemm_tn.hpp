@@ -26,6 +26,8 @@ struct TnDims {
     const int* k_dyn;            // device scalar overriding K
     int split_k, taps;           // gridDim.z = taps * split_k
     size_t slab_stride;          // SLAB: floats between the partial outputs of consecutive k splits (taps * tap_stride)
+    int tiles_m, tiles_n;        // output tiles
+    int deal;                    // 1: 1-D grid, the workgroups of one k split dealt to ONE XCD (split_k % 8 == 0)
 };
 
 constexpr size_t tn_lds_bytes(int bm = TN_BM, int bn = TN_BN, bool info = true) {
@@ -53,8 +55,22 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void tn_kernel(TnDims dims, ALoad l
     int K = dims.K;
     if (dims.k_dyn != nullptr) K = min(K, *dims.k_dyn);
     const int M = dims.M, N = dims.N;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int z = blockIdx.z % dims.split_k, tap = blockIdx.z / dims.split_k;
+    // XCD-aware dealing: every workgroup of k split z reads the same rows of both operands (its tap / output tile only picks
+    // columns and row combinations).  Dispatch is round-robin over the 8 XCDs, so in (x, y, z) grid order those workgroups land on
+    // 8 different L2s.  Dealt, split z lives on XCD z % 8.  (Measured: FETCH_SIZE of the conv launch stayed at 332 MB either way
+    // -- 430 MB are requested from L2, 16 workgroups x 2 KB per pair, against 54 MB of operands: with every split resident at once
+    // an XCD's share of the operands, 6.7 MB, does not fit its 4 MB L2.  Kept: it costs nothing)
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (dims.deal) {
+        const int per = dims.tiles_m * dims.tiles_n * dims.taps;          // workgroups of one k split
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int zz = xcd + 8 * (j / per), inner = j % per;
+        bx = inner % dims.tiles_m;
+        by = (inner / dims.tiles_m) % dims.tiles_n;
+        bz = (inner / (dims.tiles_m * dims.tiles_n)) * dims.split_k + zz;
+    }
+    const int m0 = bx * BM, n0 = by * BN;
+    const int z = bz % dims.split_k, tap = bz / dims.split_k;
     int chunk = (K + dims.split_k - 1) / dims.split_k;
     chunk = (chunk + BK - 1) / BK * BK;
     const int kbeg = z * chunk, kend = min(K, kbeg + chunk);

@@ -163,19 +163,30 @@ __global__ void conv3_wino_pack_kernel(const float* __restrict__ w, float* __res
 // ... and its transpose for the gradient: dw[:, :, 0] += du0 + (du1+du2)/2, [1] += (du1-du2)/2, [2] += (du1+du2)/2 + du3
 // du holds n_slabs partial [4][Dout][Din] results (one per k split of the weight-gradient launch); a single slab is an
 // atomics accumulator and is handed back clean
-__global__ void conv3_wino_unpack_add_kernel(float* __restrict__ du, int n_slabs, float* __restrict__ dw, int Dout, int Din) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void conv3_wino_unpack_add_kernel(float* __restrict__ du, int n_slabs, float* __restrict__ dw, int Dout, int Din) {
+    const int e4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;       // four consecutive (o, c) entries per thread: 16-B slab loads
     const int per = Dout * Din;
-    if (e >= per) return;
-    float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+    if (e4 >= per) return;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a, c = a, d = a;
     for (int s = 0; s < n_slabs; ++s) {
-        const float* p = du + (size_t)s * 4 * per;
-        a += p[e]; b += p[per + e]; c += p[2 * per + e]; d += p[3 * per + e];
+        const float* p = du + (size_t)s * 4 * per + e4;
+        a += *reinterpret_cast<const f32x4*>(p);
+        b += *reinterpret_cast<const f32x4*>(p + per);
+        c += *reinterpret_cast<const f32x4*>(p + 2 * (size_t)per);
+        d += *reinterpret_cast<const f32x4*>(p + 3 * (size_t)per);
     }
-    atomicAdd(dw + 3 * e, a + 0.5f * (b + c));
-    atomicAdd(dw + 3 * e + 1, 0.5f * (b - c));
-    atomicAdd(dw + 3 * e + 2, 0.5f * (b + c) + d);
-    if (n_slabs == 1) { du[e] = 0.f; du[per + e] = 0.f; du[2 * per + e] = 0.f; du[3 * per + e] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float* w = dw + 3 * (size_t)(e4 + i);
+        atomicAdd(w, a[i] + 0.5f * (b[i] + c[i]));
+        atomicAdd(w + 1, 0.5f * (b[i] - c[i]));
+        atomicAdd(w + 2, 0.5f * (b[i] + c[i]) + d[i]);
+    }
+    if (n_slabs == 1) {                  // a single slab is an atomics accumulator: handed back clean
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(du + (size_t)t * per + e4) = z;
+    }
 }
 
 __global__ void plan_dense_kernel(const int* __restrict__ mask, int n, int L, int* counters, int* seg_off, int* rowinfo) {
@@ -1127,7 +1138,8 @@ extern "C" int lego_conv3_wino_pack(const float* w, float* u, float* ut, int Dou
 extern "C" int lego_conv3_wino_unpack_add(float* du, int n_slabs, float* dw, int Dout, int Din, void* stream) {
     LEGO_REQUIRE(n_slabs >= 1, "lego_conv3_wino_unpack_add: n_slabs=%d", n_slabs);
     const int n = Dout * Din;
-    hipLaunchKernelGGL(conv3_wino_unpack_add_kernel, dim3((n + 255) / 256), dim3(256), 0, ST, du, n_slabs, dw, Dout, Din);
+    LEGO_REQUIRE((n & 3) == 0, "lego_conv3_wino_unpack_add: Dout * Din = %d must be a multiple of 4", n);
+    hipLaunchKernelGGL(conv3_wino_unpack_add_kernel, dim3((n / 4 + 255) / 256), dim3(256), 0, ST, du, n_slabs, dw, Dout, Din);
     return check_launch("lego_conv3_wino_unpack_add");
 }
 

@@ -873,4 +873,4 @@ def test_trainable_token_table_full_vocabulary():
         # a parameter whose true gradient vanishes (here the user tower's additive hidden layer: |g| ~ 1e-10 << eps) barely moves
         # and what it does move is rounding noise on both sides: its bar is 2 % of the largest possible movement instead
         floor = 0.02 * 1e-3 * 3 * float(b.numel()) ** 0.5
-        assert float((a - b).norm()) <= 5e-2 * max(float((b - p0).norm()), floor) + 1e-7, k
+        assert float((a - b).norm()) <= max(5e-2 * float((b - p0).norm()), floor) + 1e-7, k
