@@ -476,8 +476,6 @@ class NamlEngine(_Base):
         self._pool_fold(sb, "item_op.", G, A)
         self.kk(sb, "additive_bwd_weight_user", "lego_linear_bwd_weight", _ptr(self.Tu), self.Au, hist_items, D,
                 _ptr(G["user_op.additive_attention.encoder.0.weight"]), D, B * S, self.cnt(3), self.Au, D, None, None)
-        self.kk(sb, "additive_bwd_weight_item", "lego_linear_bwd_weight", _ptr(self.Tt), A, _ptr(self.Y), D,
-                _ptr(G["item_op.additive_attention.encoder.0.weight"]), D, self.Ryc, self.cnt(2), A, D, None, None)
         self.kk(sb, None, "lego_linear_bwd_data", _ptr(self.Tt), A, w1, D, _ptr(self.dY), D, self.NIc, self.cnt(1), A, D, 1,
                 None, 0, 1.0, None, None, _ptr(G["item_op.linear.bias"]), self.cnt(0), self.cnt(0))
         self.kk(sb, None, "lego_linear_bwd_weight", _ptr(self.dY), D, _ptr(self.cat_emb), D, _ptr(G["item_op.linear.weight"]), D,
@@ -487,6 +485,12 @@ class NamlEngine(_Base):
         self.kk(sb, None, "lego_scatter_add_rows", _ptr(G["embedding_vocab_table.category.weight"]), D, D,
                 G["embedding_vocab_table.category.weight"].shape[0], _ptr(self.inst_cat),
                 self.NIc, self.cnt(1), _ptr(self.d_cat_emb), D)
+        # the one LARGE side-stream product goes last: queued first, its ~1000 workgroups (4 x 32 KB of LDS per CU) took every CU
+        # before the main stream's accumulate strip (123 KB of LDS) could start and left a 44 us hole in the main chain; behind
+        # the small category-branch kernels it arrives when the strip is already running (0.705 -> 0.6985 ms/step, same-box A/B;
+        # on the main stream instead -- after the strip or after the conv data gradient -- 0.72 ms)
+        self.kk(sb, "additive_bwd_weight_item", "lego_linear_bwd_weight", _ptr(self.Tt), A, _ptr(self.Y), D,
+                _ptr(G["item_op.additive_attention.encoder.0.weight"]), D, self.Ryc, self.cnt(2), A, D, None, None)
         # ---- main: token rows: dY = relu'(.)*keep * (dY + dpre.W1); column sums -> conv bias grad
         self.kk(m, "additive_bwd_data", "lego_linear_bwd_data", _ptr(self.Tt), A, w1, D, _ptr(self.dY), D, self.Rc, self.cnt(0), A, D, 1,
                 _ptr(self.Y), D, keep, None, None, _ptr(G["item_op.cnn.bias"]), None, None)
