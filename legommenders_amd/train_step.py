@@ -319,28 +319,54 @@ class TrainStep:
                  _ptr(self.touched), lr, 0.9, 0.999, 1e-8, self.step_idx, 1.0 / self.world, 1, st)
         self._grad_clean = True                    # Adam cleared the gradient buffer as it consumed it
 
-    # ---- optimiser / scheduler state in the shape the reference checkpoints (base_lego.py:257-267)
-    def optimizer_state(self):
-        st = {"m": self.fp.m.detach().cpu(), "v": self.fp.v.detach().cpu(), "step": self.step_idx, "names": list(self.fp.names),
-              "offsets": dict(self.fp.offsets), "format": "lego_flat_adam"}
-        if self.table is not None:
-            st["touched"] = self.touched.detach().cpu()
-        return st
+    # ---- optimiser / scheduler state as the reference checkpoints them (base_lego.py:257-267): a torch.optim.Adam state_dict and
+    # a LambdaLR state_dict, so that `exp.load.model_only: false` works in both directions.  `order` = the trainable parameter
+    # names in the order `filter(requires_grad, legommender.parameters())` yields them (base_lego.py:201-204: one parameter group)
+    def optimizer_state(self, order=None):
+        order = [k for k in (order or self.fp.names) if k in self.fp.offsets]
+        fp = self.fp
+        state = {}
+        for i, k in enumerate(order):
+            o, n, shape = fp.offsets[k], fp.P[k].numel(), fp.P[k].shape
+            state[i] = {"step": torch.tensor(float(self.step_idx)), "exp_avg": fp.m[o:o + n].view(shape).detach().cpu().clone(),
+                        "exp_avg_sq": fp.v[o:o + n].view(shape).detach().cpu().clone()}
+        group = {"lr": self.lr_at(self.step_idx), "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": False,
+                 "initial_lr": self.lr, "params": list(range(len(order)))}
+        return {"state": state if self.step_idx > 0 else {}, "param_groups": [group], "lego_param_names": order}
 
-    def load_optimizer_state(self, st):
-        if st.get("format") != "lego_flat_adam" or st["m"].numel() != self.fp.m.numel():
-            raise ValueError("optimizer state is not a flat-Adam state of this parameter layout")
-        self.fp.m.copy_(st["m"]); self.fp.v.copy_(st["v"])
-        self.step_idx = int(st["step"])
-        if self.table is not None:                  # rows with a non-zero moment have had a gradient, whatever the file says
+    def load_optimizer_state(self, st, order=None):
+        """a torch.optim.Adam state_dict (ours or the reference's).  The parameter order comes from the file when we wrote it,
+        else from `order` (the model's trainable parameters in `parameters()` order)."""
+        if "state" not in st or "param_groups" not in st:
+            raise ValueError("optimizer state is not a torch.optim.Adam state_dict")
+        names = st.get("lego_param_names") or [k for k in (order or self.fp.names) if k in self.fp.offsets]
+        ids = [i for g in st["param_groups"] for i in g["params"]]
+        if len(ids) != len(names):
+            raise ValueError(f"optimizer state holds {len(ids)} parameters, the model trains {len(names)}")
+        fp = self.fp
+        fp.m.zero_(); fp.v.zero_()
+        step = 0
+        for i, k in zip(ids, names):
+            e = st["state"].get(i)
+            if e is None:
+                continue
+            o, n = fp.offsets[k], fp.P[k].numel()
+            if e["exp_avg"].numel() != n:
+                raise ValueError(f"optimizer state of {k}: {tuple(e['exp_avg'].shape)} does not match {tuple(fp.P[k].shape)}")
+            fp.m[o:o + n].copy_(e["exp_avg"].reshape(-1)); fp.v[o:o + n].copy_(e["exp_avg_sq"].reshape(-1))
+            step = max(step, int(float(e["step"])))
+        self.step_idx = step
+        if self.table is not None:                  # rows with a non-zero moment have had a gradient
             o, rows, width = self.table
-            mv = (self.fp.m[o:].view(rows, width) != 0).any(1) | (self.fp.v[o:].view(rows, width) != 0).any(1)
+            mv = (fp.m[o:].view(rows, width) != 0).any(1) | (fp.v[o:].view(rows, width) != 0).any(1)
             self.touched.copy_(mv.to(torch.uint8))
-            if "touched" in st:
-                self.touched.copy_(torch.maximum(self.touched, st["touched"].to(self.touched.device)))
 
     def scheduler_state(self):
-        return {"last_epoch": self.step_idx, "total_steps": self.total_steps, "warmup": self.warmup, "base_lr": self.lr}
+        """torch.optim.lr_scheduler.LambdaLR.state_dict() of HF's get_linear_schedule_with_warmup (base_lego.py:211-223)"""
+        return {"base_lrs": [self.lr], "last_epoch": self.step_idx, "_step_count": self.step_idx + 1, "verbose": False,
+                "_get_lr_called_within_step": False, "_last_lr": [self.lr_at(self.step_idx)], "lr_lambdas": [None],
+                "_is_initial": False}
 
     def load_scheduler_state(self, st):
         self.step_idx = int(st["last_epoch"])

@@ -213,15 +213,20 @@ class Trainer:
                 f.write(" ".join(str(x) for x in a) + "\n")
 
     def save(self):
-        """{model, optimizer, scheduler} as base_lego.py:257-267.  `model` carries the reference's state_dict keys and loads
-        there.  `optimizer` / `scheduler`: the plug-in route stores torch's own state_dicts (interchangeable with the
-        reference); the engine route stores its flat Adam moments (`format: lego_flat_adam`, with the name -> offset map) --
-        not a torch.optim.Adam state_dict, so the reference can load such a checkpoint with `model_only: true` only."""
+        """{model, optimizer, scheduler} as base_lego.py:257-267: `model` with the reference's state_dict keys, `optimizer` a
+        torch.optim.Adam state_dict over the trainable parameters in `legommender.parameters()` order (the engine route builds
+        it from its flat moment buffers), `scheduler` a LambdaLR state_dict -- loadable by the reference with
+        `model_only: false`, and the reference's by us."""
         path = os.path.join(self.ckpt_dir, self.signature + ".pt")
         model = self.legommender.state_dict() if self.kind == "plugin" else self.ts.fp.P
-        torch.save({"model": {k: v.detach().cpu() for k, v in model.items()},
-                    "optimizer": self.ts.optimizer_state(), "scheduler": self.ts.scheduler_state()}, path)
+        opt = self.ts.optimizer_state() if self.kind == "plugin" else self.ts.optimizer_state(self._trainable_order())
+        torch.save({"model": {k: v.detach().cpu() for k, v in model.items()}, "optimizer": opt,
+                    "scheduler": self.ts.scheduler_state()}, path)
         self.log("save model to", path)
+
+    def _trainable_order(self):
+        """trainable parameter names in `parameters()` order (what torch.optim.Adam indexes its state by)"""
+        return [n for n, p in self.legommender.named_parameters() if p.requires_grad]
 
     def load(self, sign, model_only=None):
         """base_lego.py:240-253: model always; optimizer + scheduler unless `exp.load.model_only`."""
@@ -239,7 +244,10 @@ class Trainer:
         if not model_only:
             if "optimizer" not in state or "scheduler" not in state:
                 raise KeyError(f"{path} holds no optimizer / scheduler state (set exp.load.model_only: true)")
-            self.ts.load_optimizer_state(state["optimizer"])
+            if self.kind == "plugin":
+                self.ts.load_optimizer_state(state["optimizer"])
+            else:
+                self.ts.load_optimizer_state(state["optimizer"], self._trainable_order())
             self.ts.load_scheduler_state(state["scheduler"])
         self.log("load model from", path, "(model only)" if model_only else "(model + optimizer + scheduler)")
 

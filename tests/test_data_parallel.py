@@ -155,3 +155,36 @@ def test_eval_cache_shards_gather_to_the_whole_table():
             assert all(hi - lo <= per for lo, hi, per in b) and len({per for _, _, per in b}) == 1
     world, port = 2, _free_port()
     mp.spawn(_eval_shard_worker, args=(world, port, ""), nprocs=world, join=True)
+
+
+def test_optimizer_and_scheduler_state_are_torch_state_dicts():
+    """the engine route's checkpoint blobs load into torch.optim.Adam / LambdaLR (base_lego.py:251-253,257-267) and back"""
+    from legommenders_amd.train_step import FlatParams, TrainStep
+    P = {"w": torch.randn(4, 3), "b": torch.randn(5), "frozen": torch.randn(2, 2)}
+    ts = TrainStep.__new__(TrainStep)
+    ts.fp = FlatParams(P, ("frozen",), "cpu")
+    ts.lr, ts.total_steps, ts.warmup, ts.step_idx, ts.table = 1e-3, 100, 10, 7, None
+    ts.fp.m.copy_(torch.randn(ts.fp.numel)); ts.fp.v.copy_(torch.rand(ts.fp.numel))
+    order = ["b", "w"]                                        # parameters() order of some model
+    sd = ts.optimizer_state(order)
+    params = [torch.nn.Parameter(P[k].clone()) for k in order]
+    opt = torch.optim.Adam(params, lr=1e-3)
+    opt.load_state_dict(sd)                                    # torch accepts it
+    for i, k in enumerate(order):
+        o, n = ts.fp.offsets[k], P[k].numel()
+        assert torch.equal(opt.state[params[i]]["exp_avg"].reshape(-1), ts.fp.m[o:o + n])
+        assert int(opt.state[params[i]]["step"]) == 7
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: 1.0)
+    sched.load_state_dict(ts.scheduler_state())
+    assert sched.last_epoch == 7
+    # ... and a state_dict written by torch (the reference's checkpoint) loads into the flat buffers
+    ref = opt.state_dict()
+    ts2 = TrainStep.__new__(TrainStep)
+    ts2.fp = FlatParams(P, ("frozen",), "cpu")
+    ts2.lr, ts2.total_steps, ts2.warmup, ts2.step_idx, ts2.table = 1e-3, 100, 10, 0, None
+    ts2.load_optimizer_state(ref, order)
+    ts2.load_scheduler_state(sched.state_dict())
+    for k in order:                                            # (the alignment padding between tensors is not state)
+        o, n = ts.fp.offsets[k], P[k].numel()
+        assert torch.equal(ts2.fp.m[o:o + n], ts.fp.m[o:o + n]) and torch.equal(ts2.fp.v[o:o + n], ts.fp.v[o:o + n])
+    assert ts2.step_idx == 7

@@ -89,6 +89,36 @@ def test_short_training_run_end_to_end(model, embed, tmp_path, monkeypatch):
     assert set(state["model"]) == set(tr.legommender.state_dict())      # checkpoint carries the reference's keys
 
 
+@pytest.mark.gpu
+def test_resume_restores_optimizer_and_scheduler(tmp_path, monkeypatch):
+    """`--load_sign <sig>` with `exp.load.model_only: false` (base_lego.py:240-253): parameters, Adam moments, step counter and the
+    schedule position come back, and the optimizer blob is a torch.optim.Adam state_dict over `parameters()` order (so the
+    reference can read it: loaded into a torch Adam over the model's own parameters here)."""
+    import torch
+    from legommenders_amd.trainer import Trainer
+    monkeypatch.chdir(tmp_path)
+    kw = dict(data="config/data/synthetic.yaml", model="config/model/naml.yaml", embed="config/embed/glove.yaml", batch_size=32,
+              hidden_size=64, lr=0.001, cuda=0, world="small", epoch=1, patience=2, interval=0)
+    tr = Trainer(get_configurations(dict(kw)))
+    for _ in range(7):
+        tr.ts.step()
+    tr.save()
+    ck = torch.load(os.path.join("checkpoints", "synthetic", tr.config.model.name, tr.signature + ".pt"), weights_only=False)
+    params = [p for p in tr.legommender.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=0.001)
+    opt.load_state_dict(ck["optimizer"])                                   # what the reference does (base_lego.py:252)
+    assert len(ck["optimizer"]["state"]) == len(params) and ck["scheduler"]["last_epoch"] == 7
+    cfg2 = get_configurations(dict(kw, load_sign=tr.signature))
+    cfg2.exp.load.model_only = False
+    tr2 = Trainer(cfg2)
+    assert tr2.ts.step_idx == 7
+    for k in tr.ts.fp.names:
+        o, n = tr.ts.fp.offsets[k], tr.ts.fp.P[k].numel()
+        assert torch.equal(tr2.ts.fp.m[o:o + n], tr.ts.fp.m[o:o + n]) and torch.equal(tr2.ts.fp.v[o:o + n], tr.ts.fp.v[o:o + n])
+        assert torch.equal(tr2.ts.fp.P[k], tr.ts.fp.P[k])
+    assert abs(tr2.ts.lr_at(tr2.ts.step_idx) - tr.ts.lr_at(7)) < 1e-12
+
+
 def test_bert_naml_yaml_resolves():
     c = get_configurations(dict(data="config/data/synthetic-bert.yaml", model="config/model/bert-naml.yaml",
                                 embed="config/embed/bertbase.yaml", batch_size=8, hidden_size=64))
