@@ -874,3 +874,55 @@ def test_trainable_token_table_full_vocabulary():
         # and what it does move is rounding noise on both sides: its bar is 2 % of the largest possible movement instead
         floor = 0.02 * 1e-3 * 3 * float(b.numel()) ** 0.5
         assert float((a - b).norm()) <= max(5e-2 * float((b - p0).norm()), floor) + 1e-7, k
+
+
+@pytest.mark.parametrize("hd,heads,p", [(32, 8, 0.0), (32, 8, 0.2), (16, 4, 0.1), (8, 2, 0.0), (64, 2, 0.3)])
+def test_mhsa_core_ragged_segments_with_dropout(hd, heads, p):
+    """lego_mhsa_core_fwd / _bwd against float64 autograd on ragged segments of 1..64 rows (both tile instantiations, empty segments,
+    the 32/33-row boundary).  With dropout on, the keep decisions are read back from the sign bits of the saved probabilities:
+    the forward output and all three gradients must be those of softmax(QK^T/sqrt(hd)) * keep / (1-p) @ V with exactly that mask,
+    and the keep rate must be 1-p.  The fused in_proj_bias gradient (`colsum`) is the column sum of d(qkv)."""
+    from legommenders_amd._lib import call
+    from legommenders_amd.kernels import _ptr, _stream, _drop
+    dev = _dev()
+    D = hd * heads
+    rs = np.random.RandomState(hd + heads)
+    lens = [1, 2, 31, 32, 33, 64, 0, 17, 48, 5, 40, 32, 0, 64, 9] + rs.randint(1, 65, size=25).tolist()
+    n, Lmax, R = len(lens), 64, int(sum(lens))
+    seg = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device=dev)
+    qkv = torch.tensor(rs.randn(R, 3 * D) * 0.7, dtype=torch.float32, device=dev)
+    go = torch.tensor(rs.randn(R, D), dtype=torch.float32, device=dev)
+    out = torch.full((R, D), float("nan"), device=dev)
+    probs = torch.zeros(R, heads, Lmax, device=dev)
+    drop = (p, 99, 3) if p > 0 else None
+    call("lego_mhsa_core_fwd", _ptr(qkv), 3 * D, _ptr(seg), n, None, D, heads, _ptr(out), D, _ptr(probs), Lmax, _drop(drop), R, _stream())
+    gqkv = torch.full((R, 3 * D), float("nan"), device=dev)
+    colsum = torch.zeros(3 * D, device=dev)
+    call("lego_mhsa_core_bwd", _ptr(qkv), 3 * D, _ptr(seg), n, None, D, heads, _ptr(go), D, _ptr(probs), Lmax, _drop(drop), R,
+         _ptr(gqkv), 3 * D, _ptr(colsum), _stream())
+    torch.cuda.synchronize()
+    pr, q64, g64 = probs.cpu().double().reshape(-1), qkv.cpu().double(), go.cpu().double()
+    kept = total = 0
+    exp_out, exp_g = torch.zeros(R, D, dtype=torch.float64), torch.zeros(R, 3 * D, dtype=torch.float64)
+    for s, L in enumerate(lens):
+        if L == 0:
+            continue
+        b = int(seg[s])
+        x = q64[b:b + L].clone().requires_grad_(True)
+        o_rows = []
+        for h in range(heads):
+            tile = pr[(b * heads + h * L) * Lmax:][: L * L].reshape(L, L).t()          # saved as [key j][query i]
+            keep = (torch.signbit(tile) == 0) & (tile != 0) if p > 0 else torch.ones(L, L, dtype=torch.bool)
+            kept += int(keep.sum()); total += L * L
+            Q, K, V = (x[:, t * D + h * hd: t * D + (h + 1) * hd] for t in range(3))
+            P = torch.softmax(Q @ K.t() / hd ** 0.5, dim=1)
+            np.testing.assert_allclose(tile.abs().numpy(), P.detach().numpy(), rtol=2e-5, atol=2e-6)
+            o_rows.append((P * keep / (1.0 - p)) @ V)
+        o = torch.cat(o_rows, 1)
+        o.backward(g64[b:b + L])
+        exp_out[b:b + L], exp_g[b:b + L] = o.detach(), x.grad
+    _close(out.cpu(), exp_out, rtol=2e-5, what="core out")
+    _close(gqkv.cpu(), exp_g, rtol=5e-5, what="core d(qkv)")
+    _close(colsum.cpu(), exp_g.sum(0), rtol=5e-5, what="fused in_proj_bias gradient")
+    if p > 0:
+        assert abs(kept / total - (1 - p)) < 0.01, kept / total
