@@ -144,13 +144,16 @@ def mind_like_world(world):
     return w
 
 
-def timed_steps(ts, steps, warmup, barrier, time_every=0):
-    """`warmup` untimed steps, then exactly `steps` steps between two barriers; returns (seconds, timers, loss)"""
+def timed_steps(ts, steps, warmup, barrier, time_every=0, tags=None):
+    """`warmup` untimed steps, then exactly `steps` steps between two barriers; returns (seconds, timers, loss).  On every
+    `time_every`-th timed step the kernels tagged `tags` (None = all tagged kernels) are bracketed with HIP events on their
+    launch stream."""
     for _ in range(warmup):
         ts.step()
     barrier()
     ts.counter_sum.zero_()
     timers = {}
+    ts.engine.timer_tags = tags
     t0 = time.perf_counter()
     loss = None
     for i in range(steps):
@@ -160,8 +163,24 @@ def timed_steps(ts, steps, warmup, barrier, time_every=0):
     timed_steps.host_s = time.perf_counter() - t0      # the host has enqueued everything; the device is still working
     barrier()
     dt = time.perf_counter() - t0
-    ts.engine.timers = None
+    ts.engine.timers, ts.engine.timer_tags = None, None
     return dt, timers, loss
+
+
+def tagged_steps(ts, steps, barrier):
+    """`steps` untimed steps with EVERY tagged kernel bracketed by HIP events: the per-kernel table.  Bracketing all ~12
+    kernels costs a step ~90 us (tools/step_profile.py), so it is kept out of the timed region, which brackets only the roofline
+    kernel and the in-step gather.  Returns (timers, live token rows per step, item instances per step)."""
+    barrier()
+    ts.counter_sum.zero_()
+    timers = {}
+    ts.engine.timers, ts.engine.timer_tags = timers, None
+    for _ in range(steps):
+        ts.step()
+    barrier()
+    ts.engine.timers = None
+    cs = ts.counter_sum.tolist()
+    return timers, cs[0] / steps, cs[1] / steps
 
 
 def kernel_table(timers):
@@ -210,7 +229,8 @@ def main():
         torch.cuda.synchronize()
 
     ts = make_ts(args.model, data, force=args.force_dist, embed=args.embed)
-    dt, timers, loss = timed_steps(ts, args.steps, args.warmup, barrier, args.time_every)
+    in_region = {"naml": {"conv3_fwd", "gather_rows_in_step"}, "nrms": {"qkv_fwd_item"}}[args.model]
+    dt, timers, loss = timed_steps(ts, args.steps, args.warmup, barrier, args.time_every, tags=in_region)
     host_ms = timed_steps.host_s / args.steps * 1e3
     if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -219,7 +239,10 @@ def main():
     final_loss = float(loss.item())
     cs = ts.counter_sum.tolist()
     rows_per_launch, inst_per_launch = cs[0] / max(1, args.steps), cs[1] / max(1, args.steps)
-    kern = kernel_table(timers)
+    # every tagged kernel on a few extra steps AFTER the timed region; the kernels bracketed inside it keep their in-region figures
+    tm_all, rows_tab, inst_tab = tagged_steps(ts, 8, barrier)
+    kern = kernel_table(tm_all)
+    kern_in = kernel_table(timers)
 
     # ---- the token-row gather back to back, on its own (cache-assisted: repeat launches of the same plan)
     eng = ts.engine
@@ -241,24 +264,33 @@ def main():
         gather_ms = a.elapsed_time(b) / 20
         gather_rows = int(eng.counters[0].item())
 
-    # ---- per-kernel roofline from the HIP events recorded inside the timed region
-    yrows = rows_per_launch + inst_per_launch
+    # ---- per-kernel roofline: algorithmic flops per launch over the HIP-event durations
+    def flops_for(rows, inst):
+        yrows = rows + inst
+        if args.model == "naml":
+            return {"proj_fwd": 2.0 * rows * D * E0,
+                    "conv3_fwd": 2.0 * rows * D * 3 * D,
+                    "conv3_bwd_data": 2.0 * rows * D * 3 * D,
+                    "conv3_bwd_weight": 2.0 * rows * D * 3 * D,
+                    "proj_bwd_weight": 2.0 * rows * D * E0,
+                    "additive_fwd_item": 2.0 * yrows * D * 256,
+                    "additive_bwd_data": 2.0 * rows * D * 256,
+                    "additive_bwd_weight_item": 2.0 * yrows * D * 256}
+        return nrms_flops(rows, D, E0)
+
     if args.model == "naml":
-        flops = {                                      # algorithmic flops per launch
-            "proj_fwd": 2.0 * rows_per_launch * D * E0,
-            "conv3_fwd": 2.0 * rows_per_launch * D * 3 * D,
-            "conv3_bwd_data": 2.0 * rows_per_launch * D * 3 * D,
-            "conv3_bwd_weight": 2.0 * rows_per_launch * D * 3 * D,
-            "proj_bwd_weight": 2.0 * rows_per_launch * D * E0,
-            "additive_fwd_item": 2.0 * yrows * D * 256,
-            "additive_bwd_data": 2.0 * rows_per_launch * D * 256,
-            "additive_bwd_weight_item": 2.0 * yrows * D * 256,
-        }
         solo = ("conv3_fwd", "proj_fwd", "additive_fwd_item")
         wino = ("conv3_fwd", "conv3_bwd_data", "conv3_bwd_weight") if getattr(eng, "wino", False) else ()
     else:
-        flops, solo, wino = nrms_flops(rows_per_launch, D, E0), ("qkv_fwd_item", "out_proj_fwd_item", "linear_fwd_item", "additive_fwd_item"), ()
-    price(kern, flops, wino)
+        solo, wino = ("qkv_fwd_item", "out_proj_fwd_item", "linear_fwd_item", "outlin_fwd_item", "additive_fwd_item"), ()
+    price(kern, flops_for(rows_tab, inst_tab), wino)
+    flops = flops_for(rows_per_launch, inst_per_launch)
+    price(kern_in, flops, wino)
+    for k in kern:
+        kern[k]["timed"] = "8 steps after the timed region, every tagged kernel bracketed"
+    for k, v in kern_in.items():                   # the kernels bracketed inside the timed region keep those figures
+        v["timed"] = "inside the timed region"
+        kern[k] = v
     for k in kern:
         kern[k]["overlapped"] = k not in solo and not k.startswith("gather_rows")
     traffic = pmc_traffic()
@@ -306,10 +338,11 @@ def main():
         # config 3: NRMS (MHSA news / user encoders), same world, GloVe variant
         other = "nrms" if args.model == "naml" else "naml"
         t2 = make_ts(other, data)
-        d2, tm2, _ = timed_steps(t2, 60, 10, barrier, 6)
+        d2, _, _ = timed_steps(t2, 60, 10, barrier)
         c2 = t2.counter_sum.tolist()
+        tm2, r2, _ = tagged_steps(t2, 8, barrier)            # per-kernel table on 8 steps after the timed ones
         k2 = kernel_table(tm2)
-        f2 = nrms_flops(c2[0] / 60, D, E0) if other == "nrms" else {}
+        f2 = nrms_flops(r2, D, E0) if other == "nrms" else {}
         price(k2, f2, ())
         sec[f"{other}_hidden{D}_bs{B}"] = {
             "workload": f"MIND-small-shaped {other.upper()} hidden={D} bs={B} GloVe, full train step (BASELINE config 3)",
@@ -322,7 +355,7 @@ def main():
         # worst case for the ragged plan: nothing to skip
         dd = DeviceData(dense_world(world), dev, seed=2023)
         t3 = make_ts("naml", dd)
-        d3, tm3, _ = timed_steps(t3, 40, 10, barrier, 8)
+        d3, tm3, _ = timed_steps(t3, 40, 10, barrier, 8, tags={"conv3_fwd"})
         c3 = t3.counter_sum.tolist()
         k3 = kernel_table(tm3)
         r3 = c3[0] / 40
@@ -383,6 +416,7 @@ def main():
 def nrms_flops(rows, D, E0):
     """algorithmic flops per launch of the NRMS item-side products (rows = live sequence rows incl. SEP / category)"""
     return {"qkv_fwd_item": 2.0 * rows * D * 3 * D, "out_proj_fwd_item": 2.0 * rows * D * D, "linear_fwd_item": 2.0 * rows * D * D,
+            "outlin_fwd_item": 2.0 * rows * D * D,       # out-projection and Linear folded into one product (engine.py, fold_linear)
             "additive_fwd_item": 2.0 * rows * D * 256,
             # attention core: QK^T and PV, 2 * L * hd MACs per (row, head) with L ~ the segment length (<= 33): priced with L = 21
             "mhsa_core_fwd_item": 2.0 * rows * 2 * 21 * D}

@@ -239,9 +239,11 @@ int lego_nrms_special_grads(const int32_t* seg_off, int n_cap, const int32_t* n_
                             int ld, int width, float* g_sep /*row SEP of the special table*/, float* g_cat, int ld_cat, int n_cat,
                             void* stream);
 /* x[r,:] *= live(rowinfo[r]) * dropout-scale: backward of `Transformation`'s Dropout + the inputer mask
- * (loader/embedding_hub.py:96, concat_inputer.py:111) when the producer is not a fused GEMM epilogue */
+ * (loader/embedding_hub.py:96, concat_inputer.py:111) when the producer is not a fused GEMM epilogue.
+ * colsum (nullable, [width], +=): column sums of the masked result in the same pass -- the bias gradient of the
+ * projection (`Transformation.linear.bias`). */
 int lego_mask_dropout_rows(float* x, int ld, int R_cap, const int32_t* R_dyn, int width, const int32_t* rowinfo,
-                           const lego_dropout* drop, void* stream);
+                           const lego_dropout* drop, float* colsum, void* stream);
 
 /* ---- a14: grouped ranking metrics of the evaluation path -- MetricPool.calculate's per-group loop
  * (utils/metrics.py:313-369; pandas groupby + Pool(5) of Python metric calls) as one launch.

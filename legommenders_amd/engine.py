@@ -117,12 +117,13 @@ class _Base:
         return self.tb.title_tok, self.tb.title_len, self.T
 
     timers = None   # set to a dict to time tagged kernels with HIP events on the launch stream (bench.py)
+    timer_tags = None   # optional set: only these tags are bracketed (every event pair costs the step a few microseconds)
 
     def k(self, tag, name, *args):
         """call() with optional per-kernel HIP-event timing (events on torch's current stream, which is
         the stream every kernel of the step is launched on)."""
         t = self.timers
-        if t is None:
+        if t is None or (self.timer_tags is not None and tag not in self.timer_tags):
             return call(name, *args)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -137,7 +138,7 @@ class _Base:
     def kk(self, stream, tag, name, *args):
         """launch on `stream`; with timers on, bracket the launch with HIP events on that same stream"""
         t = self.timers
-        if t is None or tag is None:
+        if t is None or tag is None or (self.timer_tags is not None and tag not in self.timer_tags):
             return call(name, *args, self._sp(stream))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
@@ -547,10 +548,15 @@ class NrmsEngine(_Base):
     (config/embed/null.yaml, dense-gradient semantics)."""
 
     def __init__(self, params, tables, B, C=5, S=50, heads=8, glove=False, seed=2023, p_proj=0.1, p_att=0.1,
-                 token_rows=True):
+                 token_rows=True, fold_linear=True):
         super().__init__(params, tables, B, C, S, seed)
         P = params
         self.glove, self.heads = glove, heads
+        # AttentionOperator applies Linear straight after the attention's out-projection (attention_operator.py:49-56, nothing
+        # between them): lin = (o Wo^T + bo) Wl^T + bl = o (Wl Wo)^T + (Wl bo + bl).  With fold_linear the two products over all
+        # sequence rows become ONE in the forward pass, ONE data-gradient product and ONE weight-gradient product (T = d_lin^T o);
+        # the four parameter gradients follow from T by D x D products (see _att_bwd).  Same function, one rounding fewer.
+        self.fold = bool(fold_linear)
         self.frozen = ("embedding_vocab_table.glove.embedding.weight",) if glove else ()
         self.D = P["item_op.linear.weight"].shape[1]
         self.A = P["item_op.additive_attention.encoder.0.weight"].shape[0]
@@ -597,7 +603,8 @@ class NrmsEngine(_Base):
         D, A, H = self.D, self.A, self.heads
         return dict(rows=rows, Lmax=Lmax, qkv=self._f(rows, 3 * D), o=self._f(rows, D), att=self._f(rows, D),
                     lin=self._f(rows, D), t=self._f(rows, A), wrow=self._f(rows), probs=self._f(rows, H, Lmax),
-                    d_lin=self._f(rows, D), d_att=self._f(rows, D), d_o=self._f(rows, D), d_qkv=self._f(rows, 3 * D))
+                    d_lin=self._f(rows, D), d_att=self._f(rows, D), d_o=self._f(rows, D), d_qkv=self._f(rows, 3 * D),
+                    Wc=self._f(D, D), bc=self._f(D), T=self._f(D, D), U=self._f(D, D), s=self._f(D))
 
     # AttentionOperator.forward over ragged segments
     def _att_fwd(self, pre, ws, x_ptr, rows_dyn, seg_off, n_cap, n_dyn, out, site, training, st):
@@ -605,16 +612,26 @@ class NrmsEngine(_Base):
         rows = ws["rows"]
         m = torch.cuda.current_stream()          # == st; tagged launches are HIP-event timed on it when bench.py asks
         tg = pre[:4]
+        if self.fold:                            # Wc = Wl Wo, bc = Wl bo + bl: two D x D launches per step and operator
+            call("lego_linear_bwd_data", _ptr(P[pre + "linear.weight"]), D, _ptr(P[pre + "multi_head_attention.out_proj.weight"]), D,
+                 _ptr(ws["Wc"]), D, D, None, D, D, 0, None, 0, 1.0, None, None, None, None, None, st)
+            call("lego_linear_fwd", _ptr(P[pre + "multi_head_attention.out_proj.bias"]), D, _ptr(P[pre + "linear.weight"]), D,
+                 _ptr(P[pre + "linear.bias"]), _ptr(ws["bc"]), D, 1, None, D, D, 0, None, None, None, None, st)
         self.kk(m, "qkv_fwd_" + tg, "lego_linear_fwd", x_ptr, D, _ptr(P[pre + "multi_head_attention.in_proj_weight"]), D,
                 _ptr(P[pre + "multi_head_attention.in_proj_bias"]), _ptr(ws["qkv"]), 3 * D, rows, rows_dyn, 3 * D, D, 0,
                 None, None, None, None)
         self.kk(m, "mhsa_core_fwd_" + tg, "lego_mhsa_core_fwd", _ptr(ws["qkv"]), 3 * D, _ptr(seg_off), n_cap, n_dyn, D, self.heads,
                 _ptr(ws["o"]), D, _ptr(ws["probs"]), ws["Lmax"], self.drop(self.p_att, site, training), rows)
-        self.kk(m, "out_proj_fwd_" + tg, "lego_linear_fwd", _ptr(ws["o"]), D, _ptr(P[pre + "multi_head_attention.out_proj.weight"]), D,
-                _ptr(P[pre + "multi_head_attention.out_proj.bias"]), _ptr(ws["att"]), D, rows, rows_dyn, D, D, 0,
-                None, None, None, None)
-        self.kk(m, "linear_fwd_" + tg, "lego_linear_fwd", _ptr(ws["att"]), D, _ptr(P[pre + "linear.weight"]), D, _ptr(P[pre + "linear.bias"]),
-                _ptr(ws["lin"]), D, rows, rows_dyn, D, D, 0, None, None, None, None)
+        Wo, bo = P[pre + "multi_head_attention.out_proj.weight"], P[pre + "multi_head_attention.out_proj.bias"]
+        Wl, bl = P[pre + "linear.weight"], P[pre + "linear.bias"]
+        if self.fold:
+            self.kk(m, "outlin_fwd_" + tg, "lego_linear_fwd", _ptr(ws["o"]), D, _ptr(ws["Wc"]), D, _ptr(ws["bc"]), _ptr(ws["lin"]), D,
+                    rows, rows_dyn, D, D, 0, None, None, None, None)
+        else:
+            self.kk(m, "out_proj_fwd_" + tg, "lego_linear_fwd", _ptr(ws["o"]), D, _ptr(Wo), D, _ptr(bo), _ptr(ws["att"]), D,
+                    rows, rows_dyn, D, D, 0, None, None, None, None)
+            self.kk(m, "linear_fwd_" + tg, "lego_linear_fwd", _ptr(ws["att"]), D, _ptr(Wl), D, _ptr(bl), _ptr(ws["lin"]), D,
+                    rows, rows_dyn, D, D, 0, None, None, None, None)
         self.kk(m, "additive_fwd_" + tg, "lego_linear_fwd", _ptr(ws["lin"]), D, _ptr(P[pre + "additive_attention.encoder.0.weight"]), D,
                 _ptr(P[pre + "additive_attention.encoder.0.bias"]), _ptr(ws["t"]), A, rows, rows_dyn, A, D, 2,
                 None, None, None, None)
@@ -650,11 +667,17 @@ class NrmsEngine(_Base):
              _ptr(gout), D, _ptr(ws["wrow"]), _ptr(ws["d_lin"]), D,
              _ptr(G[pre + "additive_attention.encoder.2.weight"]), _ptr(G[pre + "additive_attention.encoder.0.bias"]),
              _ptr(self._pool_scratch(A, pre)), st)
-        # d_lin += dpre . W1 ; its column sums are the gradient of linear.bias
+        Wo, bo = P[pre + "multi_head_attention.out_proj.weight"], P[pre + "multi_head_attention.out_proj.bias"]
+        Wl = P[pre + "linear.weight"]
+        if self.fold:
+            ws["s"].zero_()
+        # d_lin += dpre . W1 ; its column sums s are the gradient of linear.bias
         call("lego_linear_bwd_data", _ptr(ws["t"]), A, _ptr(P[pre + "additive_attention.encoder.0.weight"]), D,
-             _ptr(ws["d_lin"]), D, rows, rows_dyn, A, D, 1, None, 0, 1.0, None, None, _ptr(G[pre + "linear.bias"]), None, None, st)
-        call("lego_linear_bwd_data", _ptr(ws["d_lin"]), D, _ptr(P[pre + "linear.weight"]), D, _ptr(ws["d_att"]), D,
-             rows, rows_dyn, D, D, 0, None, 0, 1.0, None, None, _ptr(G[pre + "multi_head_attention.out_proj.bias"]), None, None, st)
+             _ptr(ws["d_lin"]), D, rows, rows_dyn, A, D, 1, None, 0, 1.0, None, None,
+             _ptr(ws["s"] if self.fold else G[pre + "linear.bias"]), None, None, st)
+        if not self.fold:
+            call("lego_linear_bwd_data", _ptr(ws["d_lin"]), D, _ptr(Wl), D, _ptr(ws["d_att"]), D,
+                 rows, rows_dyn, D, D, 0, None, 0, 1.0, None, None, _ptr(G[pre + "multi_head_attention.out_proj.bias"]), None, None, st)
         if sw is not m:
             ev[0].record(m)
             sw.wait_event(ev[0])
@@ -663,13 +686,33 @@ class NrmsEngine(_Base):
              _ptr(G[pre + "additive_attention.encoder.2.weight"]), _ptr(G[pre + "additive_attention.encoder.0.bias"]), sp)
         call("lego_linear_bwd_weight", _ptr(ws["t"]), A, _ptr(ws["lin"]), D,
              _ptr(G[pre + "additive_attention.encoder.0.weight"]), D, rows, rows_dyn, A, D, None, None, sp)
-        call("lego_linear_bwd_weight", _ptr(ws["d_lin"]), D, _ptr(ws["att"]), D, _ptr(G[pre + "linear.weight"]), D,
-             rows, rows_dyn, D, D, None, None, sp)
-        call("lego_linear_bwd_weight", _ptr(ws["d_att"]), D, _ptr(ws["o"]), D,
-             _ptr(G[pre + "multi_head_attention.out_proj.weight"]), D, rows, rows_dyn, D, D, None, None, sp)
-        # ---- main: out-projection data gradient, attention core
-        call("lego_linear_bwd_data", _ptr(ws["d_att"]), D, _ptr(P[pre + "multi_head_attention.out_proj.weight"]), D,
-             _ptr(ws["d_o"]), D, rows, rows_dyn, D, D, 0, None, 0, 1.0, None, None, None, None, None, st)
+        if self.fold:
+            # T = d_lin^T o is the only product over the sequence rows; with att = o Wo^T + bo and d_att = d_lin Wl:
+            #   d Wl = d_lin^T att = T Wo^T + s (x) bo      d bl = s
+            #   d Wo = d_att^T o   = Wl^T T                 d bo = colsum(d_att) = s Wl
+            with torch.cuda.stream(sw):
+                ws["T"].zero_()
+            call("lego_linear_bwd_weight", _ptr(ws["d_lin"]), D, _ptr(ws["o"]), D, _ptr(ws["T"]), D, rows, rows_dyn, D, D, None, None, sp)
+            call("lego_linear_fwd", _ptr(ws["T"]), D, _ptr(Wo), D, None, _ptr(ws["U"]), D, D, None, D, D, 0, None, None, None, None, sp)
+            call("lego_linear_bwd_weight", _ptr(ws["s"]), D, _ptr(bo), D, _ptr(G[pre + "linear.weight"]), D, 1, None, D, D, None, None, sp)
+            call("lego_linear_bwd_weight", _ptr(Wl), D, _ptr(ws["T"]), D, _ptr(G[pre + "multi_head_attention.out_proj.weight"]), D,
+                 D, None, D, D, None, None, sp)
+            call("lego_linear_bwd_data", _ptr(ws["s"]), D, _ptr(Wl), D, _ptr(G[pre + "multi_head_attention.out_proj.bias"]), D,
+                 1, None, D, D, 1, None, 0, 1.0, None, None, None, None, None, sp)
+            with torch.cuda.stream(sw):
+                G[pre + "linear.weight"].add_(ws["U"])
+                G[pre + "linear.bias"].add_(ws["s"])
+            # ---- main: data gradient through both layers at once
+            call("lego_linear_bwd_data", _ptr(ws["d_lin"]), D, _ptr(ws["Wc"]), D, _ptr(ws["d_o"]), D,
+                 rows, rows_dyn, D, D, 0, None, 0, 1.0, None, None, None, None, None, st)
+        else:
+            call("lego_linear_bwd_weight", _ptr(ws["d_lin"]), D, _ptr(ws["att"]), D, _ptr(G[pre + "linear.weight"]), D,
+                 rows, rows_dyn, D, D, None, None, sp)
+            call("lego_linear_bwd_weight", _ptr(ws["d_att"]), D, _ptr(ws["o"]), D,
+                 _ptr(G[pre + "multi_head_attention.out_proj.weight"]), D, rows, rows_dyn, D, D, None, None, sp)
+            # ---- main: out-projection data gradient, attention core
+            call("lego_linear_bwd_data", _ptr(ws["d_att"]), D, _ptr(Wo), D,
+                 _ptr(ws["d_o"]), D, rows, rows_dyn, D, D, 0, None, 0, 1.0, None, None, None, None, None, st)
         self.kk(torch.cuda.current_stream(), "mhsa_core_bwd_" + pre[:4], "lego_mhsa_core_bwd", _ptr(ws["qkv"]), 3 * D, _ptr(seg_off),
                 n_cap, n_dyn, D, self.heads, _ptr(ws["d_o"]), D, _ptr(ws["probs"]), ws["Lmax"],
                 self.drop(self.p_att, site, training), rows, _ptr(ws["d_qkv"]), 3 * D,
@@ -758,9 +801,7 @@ class NrmsEngine(_Base):
         if self.glove:
             E0 = self.E0
             call("lego_mask_dropout_rows", _ptr(self.dE), D, self.Rc, self.cnt(0), D, _ptr(self.tokinfo),
-                 self.drop(self.p_proj, SITE_PROJ, training), st)
-            call("lego_colsum", _ptr(self.dE), D, self.Rc, self.cnt(0), None, D,
-                 _ptr(G["embedding_vocab_table.glove.linear.bias"]), st)
+                 self.drop(self.p_proj, SITE_PROJ, training), _ptr(G["embedding_vocab_table.glove.linear.bias"]), st)
             call("lego_linear_bwd_weight", _ptr(self.dE), D, _ptr(self.X), E0,
                  _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Rc, self.cnt(0), D, E0, None, None, st)
         else:

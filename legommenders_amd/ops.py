@@ -147,7 +147,7 @@ def glove_project_bwd(gH: torch.Tensor, X: torch.Tensor, ids: torch.Tensor, W: t
     flat = ids.to(torch.int32).contiguous()
     rowinfo = torch.where(flat >= 0, torch.full_like(flat, 4), torch.zeros_like(flat))
     g = _f(gH).clone()
-    call("lego_mask_dropout_rows", K._ptr(g), D, g.shape[0], None, D, K._ptr(rowinfo), K._drop(_drop(p, seed, site)), K._stream())
+    call("lego_mask_dropout_rows", K._ptr(g), D, g.shape[0], None, D, K._ptr(rowinfo), K._drop(_drop(p, seed, site)), None, K._stream())
     gW = torch.zeros(W.shape, dtype=torch.float32, device=W.device)
     K.linear_bwd_weight(g, _f(X), gW)
     gb = torch.zeros(D, dtype=torch.float32, device=W.device)

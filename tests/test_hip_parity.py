@@ -853,7 +853,7 @@ def test_trainable_token_table_full_vocabulary():
     flags = ts.touched.cpu().numpy().astype(bool)
     assert set(np.nonzero(flags)[0].tolist()) >= ever and flags.sum() <= len(ever) + 64      # (+ ids whose gradient is exactly 0)
     idx = torch.tensor(sorted(ever))
-    assert float((got[idx] - want[idx]).abs().max()) < 5e-6                                 # lr = 1e-3: three updates of <= 1e-3
+    assert float((got[idx] - want[idx]).abs().max()) < 2e-5      # lr = 1e-3: three updates of <= 1e-3 each; < 1 % of the travel
     early_only = sorted(touched_by_step[0] - touched_by_step[1] - touched_by_step[2])
     assert len(early_only) > 10
     e = torch.tensor(early_only)
