@@ -240,8 +240,8 @@ int lego_nrms_special_grads(const int32_t* seg_off, int n_cap, const int32_t* n_
                             void* stream);
 /* x[r,:] *= live(rowinfo[r]) * dropout-scale: backward of `Transformation`'s Dropout + the inputer mask
  * (loader/embedding_hub.py:96, concat_inputer.py:111) when the producer is not a fused GEMM epilogue.
- * colsum (nullable, [width], +=): column sums of the masked result in the same pass -- the bias gradient of the
- * projection (`Transformation.linear.bias`). */
+ * colsum (nullable, [width], +=): column sums of the masked result -- the bias gradient of the projection
+ * (`Transformation.linear.bias`), as lego_colsum on the masked rows. */
 int lego_mask_dropout_rows(float* x, int ld, int R_cap, const int32_t* R_dyn, int width, const int32_t* rowinfo,
                            const lego_dropout* drop, float* colsum, void* stream);
 

@@ -299,35 +299,26 @@ __global__ __launch_bounds__(256) void nrms_special_grads_kernel(const int* __re
     }
 }
 
-// x[r,:] *= live(rowinfo[r]) * dropout scale  (backward of a masked + dropped projection output); optionally colsum[c] += the
-// column sums of the result (the producer layer's bias gradient) in the same pass.  COLSUM needs a grid stride that is a multiple
-// of `width`, so that a thread keeps its column: its partial sum stays in a register and costs one atomic per thread.
-template <bool COLSUM>
+// x[r,:] *= live(rowinfo[r]) * dropout scale  (backward of a masked + dropped projection output)
 __global__ void mask_dropout_rows_kernel(float* __restrict__ x, int ld, int R_cap, const int* __restrict__ R_dyn, int width,
-                                         const int* __restrict__ rowinfo, Dropout drop, float* colsum) {
+                                         const int* __restrict__ rowinfo, Dropout drop) {
     const int R = R_dyn != nullptr ? min(R_cap, *R_dyn) : R_cap;
     // one thread = 4 rows x 1 column: ONE Philox call yields the four keep decisions of that group (the element-per-thread form
     // ran a whole call per element and threw three quarters of it away: 64-71 us per NRMS step)
     const long long total = (long long)((R + 3) / 4) * width;
-    float acc = 0.f;
-    int col = -1;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int r0 = (int)(e / width) * 4;
         const int c = (int)(e - (long long)(r0 / 4) * width);
         float ds[4];
         dropout_scale4(drop, r0, c, width, ds);
-        col = c;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = r0 + i;
             if (r >= R) break;
             float* p = x + (size_t)r * ld + c;
-            const float v = (rowinfo != nullptr && !(rowinfo[r] & RI_LIVE)) ? 0.f : *p * ds[i];
-            *p = v;
-            if (COLSUM) acc += v;
+            *p = (rowinfo != nullptr && !(rowinfo[r] & RI_LIVE)) ? 0.f : *p * ds[i];
         }
     }
-    if (COLSUM && col >= 0) atomicAdd(colsum + col, acc);
 }
 
 // keep bits of one dropout site for rows [0, rows): byte [(row / 4) * cols + col], bit i = row % 4 -- exactly the
@@ -1184,19 +1175,12 @@ extern "C" int lego_mask_dropout_rows(float* x, int ld, int R_cap, const int32_t
     if (R_cap <= 0) return 0;
     Dropout d = make_dropout(drop);
     const long long total = (long long)((R_cap + 3) / 4) * width;
-    if (colsum != nullptr) {
-        // ~1024 workgroups whose stride (blocks * 256 threads) is a multiple of width: round the block count to a multiple of width / gcd(256, width)
-        int g = 256, w = width;
-        while (w != 0) { const int t = g % w; g = w; w = t; }
-        const int unit = width / g;
-        long long blocks = (total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024;
-        blocks = (blocks + unit - 1) / unit * unit;
-        hipLaunchKernelGGL(mask_dropout_rows_kernel<true>, dim3((int)blocks), dim3(256), 0, ST, x, ld, R_cap, R_dyn, width, rowinfo, d, colsum);
-        return check_launch("lego_mask_dropout_rows");
-    }
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(mask_dropout_rows_kernel<false>, dim3(blocks), dim3(256), 0, ST, x, ld, R_cap, R_dyn, width, rowinfo, d, colsum);
-    return check_launch("lego_mask_dropout_rows");
+    hipLaunchKernelGGL(mask_dropout_rows_kernel, dim3(blocks), dim3(256), 0, ST, x, ld, R_cap, R_dyn, width, rowinfo, d);
+    if (check_launch("lego_mask_dropout_rows") != 0) return 1;
+    // the column sums are a second launch on purpose: folded into the mask pass they need one fp32 atomic per column and workgroup
+    // on the same 1 KB of sums, and enough workgroups to feed HBM queue up on them (46-60 us against 20 + 18 us for the pair)
+    return colsum != nullptr ? lego_colsum(x, ld, R_cap, R_dyn, nullptr, width, colsum, stream) : 0;
 }
 
 extern "C" int lego_dropout_mask(const lego_dropout* drop, int rows_cap, const int32_t* rows_dyn, int cols, uint8_t* mask,

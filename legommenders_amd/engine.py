@@ -669,9 +669,8 @@ class NrmsEngine(_Base):
              _ptr(self._pool_scratch(A, pre)), st)
         Wo, bo = P[pre + "multi_head_attention.out_proj.weight"], P[pre + "multi_head_attention.out_proj.bias"]
         Wl = P[pre + "linear.weight"]
-        if self.fold:
-            ws["s"].zero_()
-        # d_lin += dpre . W1 ; its column sums s are the gradient of linear.bias
+        # d_lin += dpre . W1 ; its column sums s are the gradient of linear.bias (ws["s"] is zero here: cleared on the side stream
+        # after its last use, which the end-of-backward join orders before the next step)
         call("lego_linear_bwd_data", _ptr(ws["t"]), A, _ptr(P[pre + "additive_attention.encoder.0.weight"]), D,
              _ptr(ws["d_lin"]), D, rows, rows_dyn, A, D, 1, None, 0, 1.0, None, None,
              _ptr(ws["s"] if self.fold else G[pre + "linear.bias"]), None, None, st)
@@ -702,6 +701,7 @@ class NrmsEngine(_Base):
             with torch.cuda.stream(sw):
                 G[pre + "linear.weight"].add_(ws["U"])
                 G[pre + "linear.bias"].add_(ws["s"])
+                ws["s"].zero_()
             # ---- main: data gradient through both layers at once
             call("lego_linear_bwd_data", _ptr(ws["d_lin"]), D, _ptr(ws["Wc"]), D, _ptr(ws["d_o"]), D,
                  rows, rows_dyn, D, D, 0, None, 0, 1.0, None, None, None, None, None, st)

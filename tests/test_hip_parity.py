@@ -926,3 +926,23 @@ def test_mhsa_core_ragged_segments_with_dropout(hd, heads, p):
     _close(colsum.cpu(), exp_g.sum(0), rtol=5e-5, what="fused in_proj_bias gradient")
     if p > 0:
         assert abs(kept / total - (1 - p)) < 0.01, kept / total
+
+
+@pytest.mark.parametrize("R,W", [(1003, 256), (37, 64), (4096, 300), (5, 256)])
+def test_mask_dropout_rows_fused_colsum(R, W):
+    """lego_mask_dropout_rows with `colsum`: x is masked exactly as without it (same Philox draws, bit-identical) and colsum += the
+    column sums of the masked rows (the projection's bias gradient)."""
+    from legommenders_amd._lib import call
+    from legommenders_amd.kernels import _ptr, _stream, _drop
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(R + W)
+    x0 = torch.randn(R, W, generator=g).to(dev)
+    info = (torch.rand(R, generator=g) < 0.8).to(torch.int32).mul(4).to(dev)          # RI_LIVE = 4
+    a, b = x0.clone(), x0.clone()
+    cs = torch.full((W,), 0.5, device=dev)
+    call("lego_mask_dropout_rows", _ptr(a), W, R, None, W, _ptr(info), _drop((0.1, 77, 5)), None, _stream())
+    call("lego_mask_dropout_rows", _ptr(b), W, R, None, W, _ptr(info), _drop((0.1, 77, 5)), _ptr(cs), _stream())
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert bool((a[info == 0] == 0).all()) and 0.85 < float((a[info != 0] != 0).float().mean()) < 0.95
+    _close(cs.cpu(), 0.5 + a.double().sum(0).cpu(), rtol=1e-5, what="fused column sums")
