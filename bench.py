@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the long run and the secondary configurations")
     ap.add_argument("--cpu-steps", type=int, default=12)
-    ap.add_argument("--time-every", type=int, default=8, help="bracket the tagged kernels with HIP events every N-th timed step")
+    ap.add_argument("--time-every", type=int, default=4, help="bracket the roofline kernel and the in-step gather with HIP events every N-th timed step")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even at world size 1 (path check)")
     ap.add_argument("--small", action="store_true", help="shrunken world for quick checks (NOT the metric config)")
     return ap.parse_args()
