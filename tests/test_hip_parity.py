@@ -946,3 +946,44 @@ def test_mask_dropout_rows_fused_colsum(R, W):
     assert torch.equal(a, b)
     assert bool((a[info == 0] == 0).all()) and 0.85 < float((a[info != 0] != 0).float().mean()) < 0.95
     _close(cs.cpu(), 0.5 + a.double().sum(0).cpu(), rtol=1e-5, what="fused column sums")
+
+
+@pytest.mark.parametrize("glove", [False, True])
+def test_nrms_folded_linear_equals_unfolded(glove):
+    """NrmsEngine(fold_linear=True) -- the attention out-projection folded into AttentionOperator's Linear (attention_operator.py:49-56:
+    nothing sits between them) -- computes the same scores, loss and parameter gradients as the two-product form, with dropout on (the
+    dropout sites and counters do not depend on the fold).  Also with gradients ACCUMULATED over two backward passes: the fold's
+    scratch sums (T, s) must not leak from one pass into the next."""
+    from legommenders_amd import engine as E
+    from legommenders_amd.synthetic import glove_like, init_nrms_params, make_world
+    dev = _dev()
+    D, B, C, S, V = 128, 16, 5, 50, 3000
+    w = make_world(seed=9, n_items=700, n_users=300, n_rows=400, V=V)
+    P = init_nrms_params(D=D, V=V, n_cat=w["n_cat"], heads=8, glove=glove_like(V, 300, seed=4, device=dev) if glove else None, seed=6)
+    for k in P:                                   # non-zero biases so that the bias terms of the fold are exercised
+        if k.endswith("bias"):
+            P[k] = torch.randn_like(P[k]) * 0.1
+    Pd = {k: v.to(dev).contiguous() for k, v in P.items()}
+    tb = E.ItemTables(w["title_tok"], w["title_len"], w["cat"], dev)
+    rs = np.random.RandomState(3)
+    users = rs.randint(0, 300, size=B)
+    ids = [torch.tensor(np.ascontiguousarray(a)).int().to(dev).contiguous() for a in
+           (rs.randint(0, w["n_items"], size=(B, C)), w["user_hist"][users], np.maximum(w["user_hist_len"][users], 1))]
+    out = {}
+    for fold in (False, True):
+        eng = E.NrmsEngine(Pd, tb, B, C, S, heads=8, glove=glove, seed=77, fold_linear=fold)
+        G = eng.grads_like()
+        for _ in range(2):                        # dropout sites are keyed on (seed, step): the same draws with and without the fold
+            scores, loss = eng.forward(*ids, training=True)
+            eng.backward(G)
+        torch.cuda.synchronize()
+        out[fold] = (scores.clone(), float(loss), {k: v.clone() for k, v in G.items()})
+    (s0, l0, g0), (s1, l1, g1) = out[False], out[True]
+    _close(s1.cpu(), s0.cpu(), rtol=2e-5, what="scores")
+    assert abs(l0 - l1) < 2e-6
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    for k in g0:
+        if glove and k == "embedding_vocab_table.glove.embedding.weight":
+            continue
+        d = float((g1[k] - g0[k]).abs().max())
+        assert d <= 2e-5 * gmax + 2e-5 * float(g0[k].abs().max()), (k, d, gmax)
