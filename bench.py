@@ -28,6 +28,10 @@ steps / ms so the driver's wall clock still bounds them):
 """
 from __future__ import annotations
 
+import os
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before HIP initialises: see legommenders_amd/__init__.py
+
 import argparse
 import json
 import os
