@@ -421,7 +421,7 @@ def nrms_flops(rows, D, E0):
     """algorithmic flops per launch of the NRMS item-side products (rows = live sequence rows incl. SEP / category)"""
     return {"qkv_fwd_item": 2.0 * rows * D * 3 * D, "out_proj_fwd_item": 2.0 * rows * D * D, "linear_fwd_item": 2.0 * rows * D * D,
             "outlin_fwd_item": 2.0 * rows * D * D,       # out-projection and Linear folded into one product (engine.py, fold_linear)
-            "additive_fwd_item": 2.0 * rows * D * 256,
+            "additive_fwd_item": 2.0 * rows * D * 256,      # fold level 2: the only product over the rows between the core and the pool
             # attention core: QK^T and PV, 2 * L * hd MACs per (row, head) with L ~ the segment length (<= 33): priced with L = 21
             "mhsa_core_fwd_item": 2.0 * rows * 2 * 21 * D}
 

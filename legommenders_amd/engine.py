@@ -556,7 +556,14 @@ class NrmsEngine(_Base):
         # between them): lin = (o Wo^T + bo) Wl^T + bl = o (Wl Wo)^T + (Wl bo + bl).  With fold_linear the two products over all
         # sequence rows become ONE in the forward pass, ONE data-gradient product and ONE weight-gradient product (T = d_lin^T o);
         # the four parameter gradients follow from T by D x D products (see _att_bwd).  Same function, one rounding fewer.
-        self.fold = bool(fold_linear)
+        # fold_linear = 2 (True) goes one step further: the additive attention reads `lin` only through a product (its hidden layer)
+        # and a weighted sum (the pooled vector), so `lin` is never formed:
+        #     t = tanh(o (W1 Wc)^T + (W1 bc + b1)),   out_i = (sum_r w_r o_r) Wc^T + bc
+        # -- ONE product over the sequence rows in the forward pass (K = D, N = A) instead of three, one data-gradient product
+        # instead of three, one weight-gradient product (Tp = dpre^T o) instead of three; every parameter gradient follows from
+        # Tp, d_out^T pooled and two column sums by D x D / A x D products on the side stream.  The bias term uses sum_r w_r = 1;
+        # AdditiveAttention's sum is S / (S + 2^-23) (attention.py:36), a relative deviation of 2^-23 / S in that term only.
+        self.fold = 2 if fold_linear is True else int(fold_linear)
         self.frozen = ("embedding_vocab_table.glove.embedding.weight",) if glove else ()
         self.D = P["item_op.linear.weight"].shape[1]
         self.A = P["item_op.additive_attention.encoder.0.weight"].shape[0]
@@ -596,15 +603,17 @@ class NrmsEngine(_Base):
         self.d_items = self._f(self.NIc, D)
         self.user = self._f(B, D)
         self.d_user = self._f(B, D)
-        self.item_ws = self._att_ws(self.Rc, self.L)
-        self.user_ws = self._att_ws(B * S, S)
+        self.item_ws = self._att_ws(self.Rc, self.L, max(self.NIc, 1))
+        self.user_ws = self._att_ws(B * S, S, B)
 
-    def _att_ws(self, rows, Lmax):
+    def _att_ws(self, rows, Lmax, n_seg):
         D, A, H = self.D, self.A, self.heads
         return dict(rows=rows, Lmax=Lmax, qkv=self._f(rows, 3 * D), o=self._f(rows, D), att=self._f(rows, D),
                     lin=self._f(rows, D), t=self._f(rows, A), wrow=self._f(rows), probs=self._f(rows, H, Lmax),
                     d_lin=self._f(rows, D), d_att=self._f(rows, D), d_o=self._f(rows, D), d_qkv=self._f(rows, 3 * D),
-                    Wc=self._f(D, D), bc=self._f(D), T=self._f(D, D), U=self._f(D, D), s=self._f(D))
+                    Wc=self._f(D, D), bc=self._f(D), T=self._f(D, D), U=self._f(D, D), s=self._f(D),
+                    W2=self._f(A, D), b2=self._f(A), Tp=self._f(A, D), U2=self._f(A, D), sp=self._f(A),
+                    pooled=self._f(n_seg, D), d_pooled=self._f(n_seg, D))
 
     # AttentionOperator.forward over ragged segments
     def _att_fwd(self, pre, ws, x_ptr, rows_dyn, seg_off, n_cap, n_dyn, out, site, training, st):
@@ -612,18 +621,26 @@ class NrmsEngine(_Base):
         rows = ws["rows"]
         m = torch.cuda.current_stream()          # == st; tagged launches are HIP-event timed on it when bench.py asks
         tg = pre[:4]
-        if self.fold:                            # Wc = Wl Wo, bc = Wl bo + bl: two D x D launches per step and operator
-            call("lego_linear_bwd_data", _ptr(P[pre + "linear.weight"]), D, _ptr(P[pre + "multi_head_attention.out_proj.weight"]), D,
-                 _ptr(ws["Wc"]), D, D, None, D, D, 0, None, 0, 1.0, None, None, None, None, None, st)
-            call("lego_linear_fwd", _ptr(P[pre + "multi_head_attention.out_proj.bias"]), D, _ptr(P[pre + "linear.weight"]), D,
-                 _ptr(P[pre + "linear.bias"]), _ptr(ws["bc"]), D, 1, None, D, D, 0, None, None, None, None, st)
+        W1, b1 = P[pre + "additive_attention.encoder.0.weight"], P[pre + "additive_attention.encoder.0.bias"]
+        Wo, bo = P[pre + "multi_head_attention.out_proj.weight"], P[pre + "multi_head_attention.out_proj.bias"]
+        Wl, bl = P[pre + "linear.weight"], P[pre + "linear.bias"]
+        w2 = P[pre + "additive_attention.encoder.2.weight"]
         self.kk(m, "qkv_fwd_" + tg, "lego_linear_fwd", x_ptr, D, _ptr(P[pre + "multi_head_attention.in_proj_weight"]), D,
                 _ptr(P[pre + "multi_head_attention.in_proj_bias"]), _ptr(ws["qkv"]), 3 * D, rows, rows_dyn, 3 * D, D, 0,
                 None, None, None, None)
         self.kk(m, "mhsa_core_fwd_" + tg, "lego_mhsa_core_fwd", _ptr(ws["qkv"]), 3 * D, _ptr(seg_off), n_cap, n_dyn, D, self.heads,
                 _ptr(ws["o"]), D, _ptr(ws["probs"]), ws["Lmax"], self.drop(self.p_att, site, training), rows)
-        Wo, bo = P[pre + "multi_head_attention.out_proj.weight"], P[pre + "multi_head_attention.out_proj.bias"]
-        Wl, bl = P[pre + "linear.weight"], P[pre + "linear.bias"]
+        if self.fold and self._fold_ev is not None:          # the folded weights come from the side stream (_prepare_folds)
+            m.wait_event(self._fold_ev)
+            self._fold_ev = None
+        if self.fold == 2:
+            self.kk(m, "additive_fwd_" + tg, "lego_linear_fwd", _ptr(ws["o"]), D, _ptr(ws["W2"]), D, _ptr(ws["b2"]), _ptr(ws["t"]), A,
+                    rows, rows_dyn, A, D, 2, None, None, None, None)
+            call("lego_additive_pool_fwd", _ptr(ws["t"]), A, _ptr(ws["o"]), D, _ptr(w2), _ptr(seg_off), None, None, n_cap, n_dyn, D, A,
+                 _ptr(ws["pooled"]), D, _ptr(ws["wrow"]), st)
+            call("lego_linear_fwd", _ptr(ws["pooled"]), D, _ptr(ws["Wc"]), D, _ptr(ws["bc"]), _ptr(out), D, n_cap, n_dyn, D, D, 0,
+                 None, None, None, None, st)
+            return
         if self.fold:
             self.kk(m, "outlin_fwd_" + tg, "lego_linear_fwd", _ptr(ws["o"]), D, _ptr(ws["Wc"]), D, _ptr(ws["bc"]), _ptr(ws["lin"]), D,
                     rows, rows_dyn, D, D, 0, None, None, None, None)
@@ -632,12 +649,40 @@ class NrmsEngine(_Base):
                     rows, rows_dyn, D, D, 0, None, None, None, None)
             self.kk(m, "linear_fwd_" + tg, "lego_linear_fwd", _ptr(ws["att"]), D, _ptr(Wl), D, _ptr(bl), _ptr(ws["lin"]), D,
                     rows, rows_dyn, D, D, 0, None, None, None, None)
-        self.kk(m, "additive_fwd_" + tg, "lego_linear_fwd", _ptr(ws["lin"]), D, _ptr(P[pre + "additive_attention.encoder.0.weight"]), D,
-                _ptr(P[pre + "additive_attention.encoder.0.bias"]), _ptr(ws["t"]), A, rows, rows_dyn, A, D, 2,
+        self.kk(m, "additive_fwd_" + tg, "lego_linear_fwd", _ptr(ws["lin"]), D, _ptr(W1), D, _ptr(b1), _ptr(ws["t"]), A, rows, rows_dyn, A, D, 2,
                 None, None, None, None)
-        call("lego_additive_pool_fwd", _ptr(ws["t"]), A, _ptr(ws["lin"]), D,
-             _ptr(P[pre + "additive_attention.encoder.2.weight"]), _ptr(seg_off), None, None, n_cap, n_dyn, D, A,
+        call("lego_additive_pool_fwd", _ptr(ws["t"]), A, _ptr(ws["lin"]), D, _ptr(w2), _ptr(seg_off), None, None, n_cap, n_dyn, D, A,
              _ptr(out), D, _ptr(ws["wrow"]), st)
+
+    _fold_ev = None
+
+    def _prepare_folds(self):
+        """Wc = Wl Wo, bc = Wl bo + bl (and, level 2, W2 = W1 Wc, b2 = W1 bc + b1) of both operators: D x D work that only needs the
+        parameters, so it runs on the side stream beside the in-projection and the attention core; the main stream waits for it
+        once, in front of the first product that uses a folded weight."""
+        if not self.fold:
+            return
+        P, D, A = self.P, self.D, self.A
+        m, sw = self._side()
+        if sw is not m:
+            self._sev[5].record(m)                       # the parameters are final on the main stream (Adam of the last step)
+            sw.wait_event(self._sev[5])
+        sp = ctypes.c_void_p(sw.cuda_stream)
+        for pre, ws in (("item_op.", self.item_ws), ("user_op.", self.user_ws)):
+            Wo, bo = P[pre + "multi_head_attention.out_proj.weight"], P[pre + "multi_head_attention.out_proj.bias"]
+            Wl, bl = P[pre + "linear.weight"], P[pre + "linear.bias"]
+            W1, b1 = P[pre + "additive_attention.encoder.0.weight"], P[pre + "additive_attention.encoder.0.bias"]
+            call("lego_linear_bwd_data", _ptr(Wl), D, _ptr(Wo), D, _ptr(ws["Wc"]), D, D, None, D, D, 0, None, 0, 1.0,
+                 None, None, None, None, None, sp)
+            call("lego_linear_fwd", _ptr(bo), D, _ptr(Wl), D, _ptr(bl), _ptr(ws["bc"]), D, 1, None, D, D, 0, None, None, None, None, sp)
+            if self.fold == 2:
+                call("lego_linear_bwd_data", _ptr(W1), D, _ptr(ws["Wc"]), D, _ptr(ws["W2"]), D, A, None, D, D, 0, None, 0, 1.0,
+                     None, None, None, None, None, sp)
+                call("lego_linear_fwd", _ptr(ws["bc"]), D, _ptr(W1), D, _ptr(b1), _ptr(ws["b2"]), A, 1, None, A, D, 0,
+                     None, None, None, None, sp)
+        if sw is not m:
+            self._fold_ev = self._sev[6]
+            self._fold_ev.record(sw)
 
     def _pool_scratch(self, A, key):
         d = self.__dict__.setdefault("_pscr", {})
@@ -650,7 +695,7 @@ class NrmsEngine(_Base):
         data-gradient chain (LEGO_SERIAL=1: everything on the current stream)"""
         if getattr(self, "_sw", None) is None:
             self._sw = torch.cuda.Stream(self.dev)
-            self._sev = [torch.cuda.Event() for _ in range(6)]
+            self._sev = [torch.cuda.Event() for _ in range(8)]
         m = torch.cuda.current_stream()
         return m, (m if os.environ.get("LEGO_SERIAL") == "1" else self._sw)
 
@@ -662,6 +707,94 @@ class NrmsEngine(_Base):
         rows = ws["rows"]
         m, sw = self._side()
         sp = ctypes.c_void_p(sw.cuda_stream)
+        if self.fold == 2:
+            self._att_bwd_folded(pre, ws, G, rows_dyn, seg_off, n_cap, n_dyn, gout, st, ev, m, sw, sp)
+        else:
+            self._att_bwd_head(pre, ws, G, rows_dyn, seg_off, n_cap, n_dyn, gout, st, ev, m, sw, sp)
+        self.kk(torch.cuda.current_stream(), "mhsa_core_bwd_" + pre[:4], "lego_mhsa_core_bwd", _ptr(ws["qkv"]), 3 * D, _ptr(seg_off),
+                n_cap, n_dyn, D, self.heads, _ptr(ws["d_o"]), D, _ptr(ws["probs"]), ws["Lmax"],
+                self.drop(self.p_att, site, training), rows, _ptr(ws["d_qkv"]), 3 * D,
+                _ptr(G[pre + "multi_head_attention.in_proj_bias"]))      # bias gradient = column sums of d_qkv, fused
+        if sw is not m:
+            ev[1].record(m)
+
+        def side2():
+            # ---- side, group 2: in-projection weight gradient (its bias gradient came out of the attention core)
+            if sw is not m:
+                sw.wait_event(ev[1])
+            call("lego_linear_bwd_weight", _ptr(ws["d_qkv"]), 3 * D, x_ptr, D,
+                 _ptr(G[pre + "multi_head_attention.in_proj_weight"]), D, rows, rows_dyn, 3 * D, D, None, None, sp)
+        if self.fold == 2:
+            self._deferred.append(side2)
+        else:
+            side2()
+        call("lego_linear_bwd_data", _ptr(ws["d_qkv"]), 3 * D, _ptr(P[pre + "multi_head_attention.in_proj_weight"]), D,
+             dx_ptr, D, rows, rows_dyn, 3 * D, D, 0, None, 0, 1.0, None, None, None, None, None, st)
+
+    _deferred = ()
+
+    def _side_fold_tail(self, pre, ws, G, sw, sp, extra=()):
+        """side stream: from T = dL/dWc and s = dL/dbc to the four parameters of the two folded layers (att = o Wo^T + bo, lin = att Wl^T + bl):
+            d Wl = T Wo^T + s (x) bo      d bl = s      d Wo = Wl^T T      d bo = s Wl
+        `extra`: further (gradient, scratch) pairs to add in the same multi-tensor launch"""
+        P, D = self.P, self.D
+        Wo, bo = P[pre + "multi_head_attention.out_proj.weight"], P[pre + "multi_head_attention.out_proj.bias"]
+        Wl = P[pre + "linear.weight"]
+        call("lego_linear_fwd", _ptr(ws["T"]), D, _ptr(Wo), D, None, _ptr(ws["U"]), D, D, None, D, D, 0, None, None, None, None, sp)
+        call("lego_linear_bwd_weight", _ptr(ws["s"]), D, _ptr(bo), D, _ptr(G[pre + "linear.weight"]), D, 1, None, D, D, None, None, sp)
+        call("lego_linear_bwd_weight", _ptr(Wl), D, _ptr(ws["T"]), D, _ptr(G[pre + "multi_head_attention.out_proj.weight"]), D,
+             D, None, D, D, None, None, sp)
+        call("lego_linear_bwd_data", _ptr(ws["s"]), D, _ptr(Wl), D, _ptr(G[pre + "multi_head_attention.out_proj.bias"]), D,
+             1, None, D, D, 1, None, 0, 1.0, None, None, None, None, None, sp)
+        acc = [G[pre + "linear.weight"], G[pre + "linear.bias"]] + [a for a, _ in extra]
+        src = [ws["U"], ws["s"]] + [b for _, b in extra]
+        with torch.cuda.stream(sw):                      # one multi-tensor launch each instead of one per tensor
+            torch._foreach_add_(acc, src)
+            torch._foreach_zero_([ws["s"], ws["sp"]])
+
+    def _att_bwd_folded(self, pre, ws, G, rows_dyn, seg_off, n_cap, n_dyn, gout, st, ev, m, sw, sp):
+        """fold level 2 (see __init__): with W2 = W1 Wc, pre = o W2^T + b2, out_i = pooled_i Wc^T + bc, pooled_i = sum_r w_r o_r:
+            d pooled = d_out Wc;   pool backward on (t, o) gives dpre (in t) and d_o = w (x) d pooled;   d_o += dpre W2
+            Tp = dpre^T o,  sp = colsum(dpre):   d W1 = Tp Wc^T + sp (x) bc,   d b1 = sp
+            T  = d_out^T pooled + W1^T Tp,       s = colsum(d_out) + sp W1     (gradients of Wc and bc; then _side_fold_tail)"""
+        P, D, A = self.P, self.D, self.A
+        rows = ws["rows"]
+        W1 = P[pre + "additive_attention.encoder.0.weight"]
+        gw2, gW1, gb1 = (G[pre + "additive_attention.encoder." + k] for k in ("2.weight", "0.weight", "0.bias"))
+        call("lego_linear_bwd_data", _ptr(gout), D, _ptr(ws["Wc"]), D, _ptr(ws["d_pooled"]), D, n_cap, n_dyn, D, D, 0,
+             None, 0, 1.0, None, None, None, None, None, st)
+        call("lego_additive_pool_bwd", _ptr(ws["t"]), A, _ptr(ws["o"]), D, _ptr(P[pre + "additive_attention.encoder.2.weight"]),
+             _ptr(seg_off), None, n_cap, n_dyn, D, A, _ptr(ws["d_pooled"]), D, _ptr(ws["wrow"]), _ptr(ws["d_o"]), D,
+             _ptr(gw2), _ptr(ws["sp"]), _ptr(self._pool_scratch(A, pre)), st)
+        call("lego_linear_bwd_data", _ptr(ws["t"]), A, _ptr(ws["W2"]), D, _ptr(ws["d_o"]), D, rows, rows_dyn, A, D, 1,
+             None, 0, 1.0, None, None, None, None, None, st)
+        if sw is not m:
+            ev[0].record(m)
+
+        def side():
+            # ---- side stream: everything that ends in a parameter gradient.  Enqueued by backward() AFTER the main chain of both
+            # operators: ~15 small launches here would otherwise sit between the host and the attention-core launch that the
+            # main stream is waiting for
+            if sw is not m:
+                sw.wait_event(ev[0])
+            call("lego_additive_pool_bwd_fold", _ptr(self._pool_scratch(A, pre)), A, _ptr(gw2), _ptr(ws["sp"]), sp)
+            with torch.cuda.stream(sw):
+                torch._foreach_zero_([ws["Tp"], ws["T"]])
+            call("lego_linear_bwd_weight", _ptr(ws["t"]), A, _ptr(ws["o"]), D, _ptr(ws["Tp"]), D, rows, rows_dyn, A, D, None, None, sp)
+            call("lego_linear_bwd_weight", _ptr(gout), D, _ptr(ws["pooled"]), D, _ptr(ws["T"]), D, n_cap, n_dyn, D, D, None, None, sp)
+            call("lego_linear_bwd_weight", _ptr(W1), D, _ptr(ws["Tp"]), D, _ptr(ws["T"]), D, A, None, D, D, None, None, sp)
+            call("lego_colsum", _ptr(gout), D, n_cap, n_dyn, None, D, _ptr(ws["s"]), sp)
+            call("lego_linear_bwd_data", _ptr(ws["sp"]), A, _ptr(W1), D, _ptr(ws["s"]), D, 1, None, A, D, 1,
+                 None, 0, 1.0, None, None, None, None, None, sp)
+            call("lego_linear_fwd", _ptr(ws["Tp"]), D, _ptr(ws["Wc"]), D, None, _ptr(ws["U2"]), D, A, None, D, D, 0, None, None, None, None, sp)
+            call("lego_linear_bwd_weight", _ptr(ws["sp"]), A, _ptr(ws["bc"]), D, _ptr(gW1), D, 1, None, A, D, None, None, sp)
+            self._side_fold_tail(pre, ws, G, sw, sp, extra=((gW1, ws["U2"]), (gb1, ws["sp"])))
+        self._deferred.append(side)
+
+    def _att_bwd_head(self, pre, ws, G, rows_dyn, seg_off, n_cap, n_dyn, gout, st, ev, m, sw, sp):
+        """the additive attention and the two affine layers behind the attention core, fold levels 0 and 1"""
+        P, D, A = self.P, self.D, self.A
+        rows = ws["rows"]
         call("lego_additive_pool_bwd", _ptr(ws["t"]), A, _ptr(ws["lin"]), D,
              _ptr(P[pre + "additive_attention.encoder.2.weight"]), _ptr(seg_off), None, n_cap, n_dyn, D, A,
              _ptr(gout), D, _ptr(ws["wrow"]), _ptr(ws["d_lin"]), D,
@@ -692,16 +825,7 @@ class NrmsEngine(_Base):
             with torch.cuda.stream(sw):
                 ws["T"].zero_()
             call("lego_linear_bwd_weight", _ptr(ws["d_lin"]), D, _ptr(ws["o"]), D, _ptr(ws["T"]), D, rows, rows_dyn, D, D, None, None, sp)
-            call("lego_linear_fwd", _ptr(ws["T"]), D, _ptr(Wo), D, None, _ptr(ws["U"]), D, D, None, D, D, 0, None, None, None, None, sp)
-            call("lego_linear_bwd_weight", _ptr(ws["s"]), D, _ptr(bo), D, _ptr(G[pre + "linear.weight"]), D, 1, None, D, D, None, None, sp)
-            call("lego_linear_bwd_weight", _ptr(Wl), D, _ptr(ws["T"]), D, _ptr(G[pre + "multi_head_attention.out_proj.weight"]), D,
-                 D, None, D, D, None, None, sp)
-            call("lego_linear_bwd_data", _ptr(ws["s"]), D, _ptr(Wl), D, _ptr(G[pre + "multi_head_attention.out_proj.bias"]), D,
-                 1, None, D, D, 1, None, 0, 1.0, None, None, None, None, None, sp)
-            with torch.cuda.stream(sw):
-                G[pre + "linear.weight"].add_(ws["U"])
-                G[pre + "linear.bias"].add_(ws["s"])
-                ws["s"].zero_()
+            self._side_fold_tail(pre, ws, G, sw, sp)
             # ---- main: data gradient through both layers at once
             call("lego_linear_bwd_data", _ptr(ws["d_lin"]), D, _ptr(ws["Wc"]), D, _ptr(ws["d_o"]), D,
                  rows, rows_dyn, D, D, 0, None, 0, 1.0, None, None, None, None, None, st)
@@ -713,18 +837,6 @@ class NrmsEngine(_Base):
             # ---- main: out-projection data gradient, attention core
             call("lego_linear_bwd_data", _ptr(ws["d_att"]), D, _ptr(Wo), D,
                  _ptr(ws["d_o"]), D, rows, rows_dyn, D, D, 0, None, 0, 1.0, None, None, None, None, None, st)
-        self.kk(torch.cuda.current_stream(), "mhsa_core_bwd_" + pre[:4], "lego_mhsa_core_bwd", _ptr(ws["qkv"]), 3 * D, _ptr(seg_off),
-                n_cap, n_dyn, D, self.heads, _ptr(ws["d_o"]), D, _ptr(ws["probs"]), ws["Lmax"],
-                self.drop(self.p_att, site, training), rows, _ptr(ws["d_qkv"]), 3 * D,
-                _ptr(G[pre + "multi_head_attention.in_proj_bias"]))      # bias gradient = column sums of d_qkv, fused
-        if sw is not m:
-            ev[1].record(m)
-            sw.wait_event(ev[1])
-        # ---- side, group 2: in-projection weight gradient (its bias gradient came out of the attention core)
-        call("lego_linear_bwd_weight", _ptr(ws["d_qkv"]), 3 * D, x_ptr, D,
-             _ptr(G[pre + "multi_head_attention.in_proj_weight"]), D, rows, rows_dyn, 3 * D, D, None, None, sp)
-        call("lego_linear_bwd_data", _ptr(ws["d_qkv"]), 3 * D, _ptr(P[pre + "multi_head_attention.in_proj_weight"]), D,
-             dx_ptr, D, rows, rows_dyn, 3 * D, D, 0, None, 0, 1.0, None, None, None, None, None, st)
 
     def _plan_tables(self):
         return self.seq_tok, self.seq_len, self.L
@@ -752,9 +864,13 @@ class NrmsEngine(_Base):
              _ptr(self.counters), _ptr(self.inst_item), _ptr(self.seg_off), _ptr(self.hist_off),
              _ptr(self.rowinfo), _ptr(self.row_tok), _stream())
 
+    _folds_fresh = False
+
     def _forward_items(self, training):
         P, D = self.P, self.D
         st = _stream()
+        self._prepare_folds()
+        self._folds_fresh = True
         call("lego_nrms_decode_rows", _ptr(self.row_tok), self.Rc, self.cnt(0), _ptr(self.idx_tok), _ptr(self.idx_spec),
              _ptr(self.idx_cat), _ptr(self.tokinfo), st)
         if self.glove:
@@ -775,6 +891,9 @@ class NrmsEngine(_Base):
                       self.items, SITE_ITEM_ATT, training, st)
 
     def _forward_users(self, training):
+        if not self._folds_fresh:                # evaluation caches call this without a preceding _forward_items
+            self._prepare_folds()
+        self._folds_fresh = False
         self._att_fwd("user_op.", self.user_ws, _ptr(self.items, self.BC * self.D), self.cnt(3), self.hist_off, self.nb, None,
                       self.user, SITE_USER_ATT, training, _stream())
 
@@ -789,6 +908,7 @@ class NrmsEngine(_Base):
              float(gloss) / B, _ptr(self.d_user), D, _ptr(self.d_items), D, st)
         m, sw = self._side()
         sev = self._sev if sw is not m else [None] * 6
+        self._deferred = []
         self._att_bwd("user_op.", self.user_ws, G, _ptr(self.items, self.BC * D), _ptr(self.d_items, self.BC * D),
                       self.cnt(3), self.hist_off, B, None, self.d_user, SITE_USER_ATT, training, st, sev[0:2])
         self._att_bwd("item_op.", self.item_ws, G, _ptr(self.E), _ptr(self.dE), self.cnt(0), self.seg_off, self.NIc,
@@ -810,6 +930,9 @@ class NrmsEngine(_Base):
                  self.Rc, self.cnt(0), _ptr(self.dE), D, st)
             if self.touched_rows is not None:       # TrainStep: rows that have ever had a gradient (row-skipping dense Adam)
                 call("lego_mark_rows", _ptr(self.idx_tok), self.Rc, self.cnt(0), V, _ptr(self.touched_rows), st)
+        for side in self._deferred:                  # the side-stream launches of both operators, behind the whole main chain
+            side()
+        self._deferred = ()
         if sw is not m:
             sev[4].record(sw)
             m.wait_event(sev[4])                     # every gradient is ordered on the caller's stream again

@@ -950,8 +950,9 @@ def test_mask_dropout_rows_fused_colsum(R, W):
 
 @pytest.mark.parametrize("glove", [False, True])
 def test_nrms_folded_linear_equals_unfolded(glove):
-    """NrmsEngine(fold_linear=True) -- the attention out-projection folded into AttentionOperator's Linear (attention_operator.py:49-56:
-    nothing sits between them) -- computes the same scores, loss and parameter gradients as the two-product form, with dropout on (the
+    """NrmsEngine(fold_linear=1 / 2) -- the attention out-projection folded into AttentionOperator's Linear (attention_operator.py:49-56:
+    nothing sits between them), and at level 2 the additive attention's hidden layer and pooled sum taken straight from the attention
+    output -- computes the same scores, loss and parameter gradients as the layer-by-layer form, with dropout on (the
     dropout sites and counters do not depend on the fold).  Also with gradients ACCUMULATED over two backward passes: the fold's
     scratch sums (T, s) must not leak from one pass into the next."""
     from legommenders_amd import engine as E
@@ -970,7 +971,7 @@ def test_nrms_folded_linear_equals_unfolded(glove):
     ids = [torch.tensor(np.ascontiguousarray(a)).int().to(dev).contiguous() for a in
            (rs.randint(0, w["n_items"], size=(B, C)), w["user_hist"][users], np.maximum(w["user_hist_len"][users], 1))]
     out = {}
-    for fold in (False, True):
+    for fold in (0, 1, 2):
         eng = E.NrmsEngine(Pd, tb, B, C, S, heads=8, glove=glove, seed=77, fold_linear=fold)
         G = eng.grads_like()
         for _ in range(2):                        # dropout sites are keyed on (seed, step): the same draws with and without the fold
@@ -978,12 +979,14 @@ def test_nrms_folded_linear_equals_unfolded(glove):
             eng.backward(G)
         torch.cuda.synchronize()
         out[fold] = (scores.clone(), float(loss), {k: v.clone() for k, v in G.items()})
-    (s0, l0, g0), (s1, l1, g1) = out[False], out[True]
-    _close(s1.cpu(), s0.cpu(), rtol=2e-5, what="scores")
-    assert abs(l0 - l1) < 2e-6
+    s0, l0, g0 = out[0]
     gmax = max(float(v.abs().max()) for v in g0.values())
-    for k in g0:
-        if glove and k == "embedding_vocab_table.glove.embedding.weight":
-            continue
-        d = float((g1[k] - g0[k]).abs().max())
-        assert d <= 2e-5 * gmax + 2e-5 * float(g0[k].abs().max()), (k, d, gmax)
+    for level in (1, 2):      # 1: out-projection folded into Linear; 2: the additive hidden layer folded in as well
+        s1, l1, g1 = out[level]
+        _close(s1.cpu(), s0.cpu(), rtol=2e-5, what=f"scores, fold level {level}")
+        assert abs(l0 - l1) < 2e-6
+        for k in g0:
+            if glove and k == "embedding_vocab_table.glove.embedding.weight":
+                continue
+            d = float((g1[k] - g0[k]).abs().max())
+            assert d <= 2e-5 * gmax + 2e-5 * float(g0[k].abs().max()), (level, k, d, gmax)
