@@ -163,25 +163,48 @@ __global__ void conv3_wino_pack_kernel(const float* __restrict__ w, float* __res
 // ... and its transpose for the gradient: dw[:, :, 0] += du0 + (du1+du2)/2, [1] += (du1-du2)/2, [2] += (du1+du2)/2 + du3
 // du holds n_slabs partial [4][Dout][Din] results (one per k split of the weight-gradient launch); a single slab is an
 // atomics accumulator and is handed back clean
+// Workgroup = 64 entry quads x 4 slab lanes: lane y sums slabs y, y + 4, ... (all of a lane's loads are independent: with 16
+// slabs that is 16 x 16 B in flight per thread, where the one-thread-per-quad form walked the slabs with 4 loads in flight and only
+// 64 workgroups: 18 us serial, 30 us at the end of the step's critical path); the lanes fold through LDS and lane 0 updates dw with
+// plain 16-byte read-modify-writes (the 12 floats of an entry quad are contiguous and nobody else writes them).
 __global__ __launch_bounds__(256) void conv3_wino_unpack_add_kernel(float* __restrict__ du, int n_slabs, float* __restrict__ dw, int Dout, int Din) {
-    const int e4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;       // four consecutive (o, c) entries per thread: 16-B slab loads
+    __shared__ f32x4 part[4][4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int per = Dout * Din;
-    if (e4 >= per) return;
-    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a, c = a, d = a;
-    for (int s = 0; s < n_slabs; ++s) {
-        const float* p = du + (size_t)s * 4 * per + e4;
-        a += *reinterpret_cast<const f32x4*>(p);
-        b += *reinterpret_cast<const f32x4*>(p + per);
-        c += *reinterpret_cast<const f32x4*>(p + 2 * (size_t)per);
-        d += *reinterpret_cast<const f32x4*>(p + 3 * (size_t)per);
+    const int e4 = (blockIdx.x * 64 + tx) * 4;       // four consecutive (o, c) entries per thread: 16-B slab loads
+    const bool in = e4 < per;
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (in) {
+#pragma unroll 4
+        for (int s = ty; s < n_slabs; s += 4) {
+            const float* p = du + (size_t)s * 4 * per + e4;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] += *reinterpret_cast<const f32x4*>(p + (size_t)t * per);
+        }
     }
 #pragma unroll
+    for (int t = 0; t < 4; ++t) part[ty][t][tx] = acc[t];
+    __syncthreads();
+    if (ty != 0 || !in) return;
+    f32x4 a, b, c, d;
+    a = (part[0][0][tx] + part[1][0][tx]) + (part[2][0][tx] + part[3][0][tx]);
+    b = (part[0][1][tx] + part[1][1][tx]) + (part[2][1][tx] + part[3][1][tx]);
+    c = (part[0][2][tx] + part[1][2][tx]) + (part[2][2][tx] + part[3][2][tx]);
+    d = (part[0][3][tx] + part[1][3][tx]) + (part[2][3][tx] + part[3][3][tx]);
+    float* w = dw + 3 * (size_t)e4;                  // 12 contiguous floats: entries e4 .. e4 + 3, three taps each
+    f32x4 w0 = *reinterpret_cast<f32x4*>(w), w1 = *reinterpret_cast<f32x4*>(w + 4), w2 = *reinterpret_cast<f32x4*>(w + 8);
+    float o[12];
+#pragma unroll
     for (int i = 0; i < 4; ++i) {
-        float* w = dw + 3 * (size_t)(e4 + i);
-        atomicAdd(w, a[i] + 0.5f * (b[i] + c[i]));
-        atomicAdd(w + 1, 0.5f * (b[i] - c[i]));
-        atomicAdd(w + 2, 0.5f * (b[i] + c[i]) + d[i]);
+        o[3 * i] = a[i] + 0.5f * (b[i] + c[i]);
+        o[3 * i + 1] = 0.5f * (b[i] - c[i]);
+        o[3 * i + 2] = 0.5f * (b[i] + c[i]) + d[i];
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { w0[j] += o[j]; w1[j] += o[4 + j]; w2[j] += o[8 + j]; }
+    *reinterpret_cast<f32x4*>(w) = w0; *reinterpret_cast<f32x4*>(w + 4) = w1; *reinterpret_cast<f32x4*>(w + 8) = w2;
     if (n_slabs == 1) {                  // a single slab is an atomics accumulator: handed back clean
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1139,7 +1162,8 @@ extern "C" int lego_conv3_wino_unpack_add(float* du, int n_slabs, float* dw, int
     LEGO_REQUIRE(n_slabs >= 1, "lego_conv3_wino_unpack_add: n_slabs=%d", n_slabs);
     const int n = Dout * Din;
     LEGO_REQUIRE((n & 3) == 0, "lego_conv3_wino_unpack_add: Dout * Din = %d must be a multiple of 4", n);
-    hipLaunchKernelGGL(conv3_wino_unpack_add_kernel, dim3((n / 4 + 255) / 256), dim3(256), 0, ST, du, n_slabs, dw, Dout, Din);
+    LEGO_REQUIRE((reinterpret_cast<uintptr_t>(dw) & 15) == 0 && (reinterpret_cast<uintptr_t>(du) & 15) == 0, "lego_conv3_wino_unpack_add: du / dw must be 16-byte aligned");
+    hipLaunchKernelGGL(conv3_wino_unpack_add_kernel, dim3((n / 4 + 63) / 64), dim3(256), 0, ST, du, n_slabs, dw, Dout, Din);
     return check_launch("lego_conv3_wino_unpack_add");
 }
 
