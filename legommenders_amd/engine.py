@@ -57,6 +57,22 @@ class ItemTables:
         self.n_items, self.T = self.title_tok.shape
 
 
+_STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}
+
+
+def shared_stream(dev, role: str):
+    """The process-wide HIP stream of a role ("side0", "side1", "prefetch") on a device.  Every engine / TrainStep of the
+    process uses the same few streams: the runtime maps streams onto a handful of hardware queues in creation order, and a
+    second TrainStep with fresh streams (bench.py's secondary lines) was seen to get a side stream on the SAME queue as the
+    main stream -- its NRMS step took 2.70 ms instead of 1.31.  Streams created once, first, keep the queues the stand-alone
+    run has."""
+    d = torch.device(dev)
+    key = (d.index if d.index is not None else torch.cuda.current_device(), role)
+    if key not in _STREAMS:
+        _STREAMS[key] = torch.cuda.Stream(d)
+    return _STREAMS[key]
+
+
 class _Base:
     def __init__(self, params: Dict[str, torch.Tensor], tables: ItemTables, B: int, C: int, S: int,
                  seed: int = 2023):
@@ -312,7 +328,7 @@ class NamlEngine(_Base):
     # and the weight-gradient GEMMs fill the CUs the big token-row GEMMs leave idle in their last wave.
     def _lanes(self):
         if getattr(self, "_side", None) is None:
-            self._side = [torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)]
+            self._side = [shared_stream(self.dev, "side0"), shared_stream(self.dev, "side1")]
             self._evs = [torch.cuda.Event() for _ in range(10)]
         m = torch.cuda.current_stream()
         if os.environ.get("LEGO_SERIAL") == "1":     # profiling aid: one stream, so per-kernel times do not overlap
@@ -694,7 +710,7 @@ class NrmsEngine(_Base):
         """side HIP stream for the weight-gradient products: they overlap the latency-bound attention-core kernels of the
         data-gradient chain (LEGO_SERIAL=1: everything on the current stream)"""
         if getattr(self, "_sw", None) is None:
-            self._sw = torch.cuda.Stream(self.dev)
+            self._sw = shared_stream(self.dev, "side0")
             self._sev = [torch.cuda.Event() for _ in range(8)]
         m = torch.cuda.current_stream()
         return m, (m if os.environ.get("LEGO_SERIAL") == "1" else self._sw)

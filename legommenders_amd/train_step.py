@@ -19,7 +19,7 @@ from typing import Dict, Optional
 import torch
 
 from ._lib import call
-from .engine import ItemTables, NamlEngine, NrmsEngine, _ptr, _stream
+from .engine import ItemTables, NamlEngine, NrmsEngine, _ptr, _stream, shared_stream
 
 
 class FlatParams:
@@ -190,7 +190,7 @@ class TrainStep:
         self.prefetch = str(dev) != "cpu"
         if self.prefetch:
             self.engine.enable_plan_slots()
-            self.pre = torch.cuda.Stream(dev)
+            self.pre = shared_stream(dev, "prefetch")
             self._ready = [torch.cuda.Event(), torch.cuda.Event()]
             self._go = torch.cuda.Event()
             self._neck = torch.cuda.Event()
