@@ -38,22 +38,39 @@ struct Dropout {
                            // byte [(row / 4) * ncols + col], bit i = row % 4 -- the epilogues then skip the RNG
 };
 
+// The keep decisions of a dropout site: ONE Philox4x32-10 call per (group of 8 rows, column) -- counter (row / 8) * ncols + col --
+// yields eight 16-bit fields; row 8 * (row / 8) + f takes the low (f < 4) or high (f >= 4) half of word f & 3 and is kept iff that
+// field >= floor(p * 65536) (P(drop) = p to within 1.5e-5; the kept values are scaled by 1 / (1 - p) as nn.Dropout does).  Round 1
+// spent a whole call on 4 rows and compared 32-bit words: the keep-bit kernels of the prefetch stream were 2 x 17 us of VALU work
+// per NAML step.
+__device__ __forceinline__ uint32_t dropout_draw8(const Dropout& d, int g8, int c, int ncols) {      // bit f = row 8 * g8 + f kept
+    const uint64_t ctr = (uint64_t)g8 * (uint64_t)ncols + (uint64_t)c;
+    const Philox4 r = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), d.site, 0u, d.seed_lo, d.seed_hi);
+    const uint32_t thr = (uint32_t)(d.p * 65536.0f);
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+    uint32_t bits = 0u;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) bits |= (((w[f & 3] >> (16 * (f >> 2))) & 0xFFFFu) >= thr ? 1u : 0u) << f;
+    return bits;
+}
+// the four decisions of rows r0 .. r0 + 3 (r0 % 4 == 0): the same call, one half of every word (a shift, no select: the Winograd
+// epilogue has no registers to spare)
+__device__ __forceinline__ uint32_t dropout_draw4(const Dropout& d, int r0, int c, int ncols) {     // bit i = row r0 + i kept
+    const uint64_t ctr = (uint64_t)(r0 >> 3) * (uint64_t)ncols + (uint64_t)c;
+    const Philox4 r = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), d.site, 0u, d.seed_lo, d.seed_hi);
+    const uint32_t thr = (uint32_t)(d.p * 65536.0f);
+    const uint32_t sh = (uint32_t)(r0 & 4) << 2;          // 0 or 16
+    return (((r.x >> sh) & 0xFFFFu) >= thr ? 1u : 0u) | (((r.y >> sh) & 0xFFFFu) >= thr ? 2u : 0u) |
+           (((r.z >> sh) & 0xFFFFu) >= thr ? 4u : 0u) | (((r.w >> sh) & 0xFFFFu) >= thr ? 8u : 0u);
+}
+
 // keep-scales for the 4 elements (rows r0..r0+3, r0 % 4 == 0, column c) of a [*, ncols] matrix
 __device__ __forceinline__ void dropout_scale4(const Dropout& d, int r0, int c, int ncols, float (&s)[4]) {
     if (d.p <= 0.f) { s[0] = s[1] = s[2] = s[3] = 1.f; return; }
-    const uint64_t ctr = (uint64_t)(r0 >> 2) * (uint64_t)ncols + (uint64_t)c;
-    if (d.mask != nullptr) {
-        const uint32_t bits = d.mask[ctr];
-        const float inv = 1.f / (1.f - d.p);
-        s[0] = (bits & 1u) ? inv : 0.f; s[1] = (bits & 2u) ? inv : 0.f;
-        s[2] = (bits & 4u) ? inv : 0.f; s[3] = (bits & 8u) ? inv : 0.f;
-        return;
-    }
-    const Philox4 r = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), d.site, 0u, d.seed_lo, d.seed_hi);
-    const uint32_t thr = (uint32_t)(d.p * 4294967296.0f);
+    const uint32_t bits = d.mask != nullptr ? (uint32_t)d.mask[(uint64_t)(r0 >> 2) * (uint64_t)ncols + (uint64_t)c] : dropout_draw4(d, r0, c, ncols);
     const float inv = 1.f / (1.f - d.p);
-    s[0] = r.x >= thr ? inv : 0.f; s[1] = r.y >= thr ? inv : 0.f;
-    s[2] = r.z >= thr ? inv : 0.f; s[3] = r.w >= thr ? inv : 0.f;
+    s[0] = (bits & 1u) ? inv : 0.f; s[1] = (bits & 2u) ? inv : 0.f;
+    s[2] = (bits & 4u) ? inv : 0.f; s[3] = (bits & 8u) ? inv : 0.f;
 }
 
 // the same decisions as 4 keep bits (bit i = row r0 + i); with a precomputed mask this is ONE byte load, which the
@@ -61,11 +78,8 @@ __device__ __forceinline__ void dropout_scale4(const Dropout& d, int r0, int c, 
 // the compiler and would pay a full memory latency per fragment)
 __device__ __forceinline__ uint32_t dropout_bits4(const Dropout& d, int r0, int c, int ncols) {
     if (d.p <= 0.f) return 15u;
-    const uint64_t ctr = (uint64_t)(r0 >> 2) * (uint64_t)ncols + (uint64_t)c;
-    if (d.mask != nullptr) return d.mask[ctr];
-    const Philox4 r = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), d.site, 0u, d.seed_lo, d.seed_hi);
-    const uint32_t thr = (uint32_t)(d.p * 4294967296.0f);
-    return (r.x >= thr ? 1u : 0u) | (r.y >= thr ? 2u : 0u) | (r.z >= thr ? 4u : 0u) | (r.w >= thr ? 8u : 0u);
+    if (d.mask != nullptr) return d.mask[(uint64_t)(r0 >> 2) * (uint64_t)ncols + (uint64_t)c];
+    return dropout_draw4(d, r0, c, ncols);
 }
 
 __device__ __forceinline__ float dropout_scale1(const Dropout& d, int r, int c, int ncols) {

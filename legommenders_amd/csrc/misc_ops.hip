@@ -349,14 +349,15 @@ __global__ void mask_dropout_rows_kernel(float* __restrict__ x, int ld, int R_ca
 // epilogues read one byte instead of running Philox (a wave64 Philox call is ~500 cycles of VALU)
 __global__ void dropout_mask_kernel(Dropout d, int rows_cap, const int* __restrict__ rows_dyn, int cols, uint8_t* __restrict__ mask) {
     const int rows = rows_dyn != nullptr ? min(rows_cap, *rows_dyn) : rows_cap;
-    const long long total = (long long)((rows + 3) >> 2) * cols;
+    const int groups4 = (rows + 3) >> 2;
+    const long long total = (long long)((rows + 7) >> 3) * cols;          // one thread (one Philox call) per 8 rows x column
     d.mask = nullptr;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const int g = (int)(e / cols);
-        const int c = (int)(e - (long long)g * cols);
-        float s[4];
-        dropout_scale4(d, g << 2, c, cols, s);
-        mask[e] = (uint8_t)((s[0] != 0.f ? 1 : 0) | (s[1] != 0.f ? 2 : 0) | (s[2] != 0.f ? 4 : 0) | (s[3] != 0.f ? 8 : 0));
+        const int g8 = (int)(e / cols);
+        const int c = (int)(e - (long long)g8 * cols);
+        const uint32_t bits = dropout_draw8(d, g8, c, cols);
+        mask[(size_t)(2 * g8) * cols + c] = (uint8_t)(bits & 15u);
+        if (2 * g8 + 1 < groups4) mask[(size_t)(2 * g8 + 1) * cols + c] = (uint8_t)(bits >> 4);
     }
 }
 
@@ -1211,7 +1212,7 @@ extern "C" int lego_dropout_mask(const lego_dropout* drop, int rows_cap, const i
                                  void* stream) {
     LEGO_REQUIRE(drop != nullptr && drop->p > 0.f && drop->p < 1.f, "lego_dropout_mask: needs 0 < p < 1");
     if (rows_cap <= 0) return 0;
-    const long long total = (long long)((rows_cap + 3) / 4) * cols;
+    const long long total = (long long)((rows_cap + 7) / 8) * cols;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks), dim3(256), 0, ST, make_dropout(drop), rows_cap, rows_dyn, cols, mask);
     return check_launch("lego_dropout_mask");
