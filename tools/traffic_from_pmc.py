@@ -21,6 +21,9 @@ def tag_of(name):
         return "conv3_bwd_weight"
     if "conv3_wino_unpack_add_kernel" in n:
         return "conv3_bwd_weight_unpack"
+    m = re.match(r"(?:void )?(mhsa_(?:fwd|bwd)_kernel)<(\d+), (\d+)>", n)
+    if m:
+        return f"{m.group(1)}<{m.group(2)},{m.group(3)}>"
     if "strip_kernel" in n and "KcConvA" in n and "KcTapW" in n:
         return "conv3_fwd"
     if "strip_kernel" in n and "KcConvA" in n:
