@@ -199,6 +199,23 @@ int lego_mhsa_core_bwd(const float* qkv, int ldq, const int32_t* seg_off, int n_
                        const lego_dropout* drop, int rows_cap, float* gqkv, int ldgq,
                        float* colsum /*nullable [3*D]: += column sums of gqkv = the in_proj_bias gradient*/, void* stream);
 
+/* ---- a8 (engine route): the two affine layers behind the attention core -- nn.MultiheadAttention's out_proj and
+ * AttentionOperator.linear (attention_operator.py:49-56, nothing between them) -- and the hidden layer of the additive attention
+ * that reads their output (model/common/attention.py:31-34) folded into ONE weight each:
+ *   Wc = Wl Wo [D,D], bc = Wl bo + bl [D];   W2 = W1 Wc [A,D], b2 = W1 bc + b1 [A]   (W2 / b2 / W1 / b1 nullable: first fold only).
+ * lego_attn_fold_grads is the backward of that parameter map, given
+ *   Tp = dpre^T o [A,D], sp = colsum(dpre) [A]           (W1 nullable: skipped)
+ *   T  = d(loss)/dWc so far (d_out^T pooled, or d_lin^T o for the first fold) [D,D],  s = d(loss)/dbc so far [D]:
+ *   gW1 += Tp Wc^T + sp (x) bc, gb1 += sp, T += W1^T Tp, s += sp W1;
+ *   gWl += T Wo^T + s (x) bo, gbl += s, gWo += Wl^T T, gbo += s Wl.      T and s are updated in place.
+ * One launch per dependency level (two each), 32 x 32 output tiles on the vector ALU. */
+int lego_attn_fold_prepare(const float* Wo, const float* bo, const float* Wl, const float* bl, const float* W1,
+                           const float* b1, float* Wc, float* bc, float* W2, float* b2, int D, int A, void* stream);
+int lego_attn_fold_grads(const float* Wo, const float* bo, const float* Wl, const float* W1, const float* Wc,
+                         const float* bc, const float* Tp, const float* sp, float* T, float* s,
+                         float* gWo, float* gbo, float* gWl, float* gbl, float* gW1, float* gb1,
+                         int D, int A, void* stream);
+
 /* ---- a13: torch.optim.Adam (defaults, base_lego.py:201-204) over one flat fp32 buffer;
  * grad is multiplied by grad_scale first (1/world after the RCCL all-reduce). step is 1-based.
  * zero_grad != 0: g is cleared as it is consumed (optimizer.zero_grad() of the next step, trainer.py:199). */

@@ -34,6 +34,8 @@ SIGNATURES = {
     "lego_nrms_decode_rows": [P, I, P, P, P, P, P, P],
     "lego_nrms_special_grads": [P, I, P, P, P, I, I, P, P, I, I, P],
     "lego_mask_dropout_rows": [P, I, I, P, I, P, P, P, P],
+    "lego_attn_fold_prepare": [P, P, P, P, P, P, P, P, P, P, I, I, P],
+    "lego_attn_fold_grads": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P],
     "lego_scatter_add_rows": [P, I, I, I, P, I, P, P, I, P],
     "lego_linear_fwd": [P, I, P, I, P, P, I, I, P, I, I, I, P, P, P, P, P],
     "lego_linear_bwd_data": [P, I, P, I, P, I, I, P, I, I, I, P, I, F, P, P, P, P, P, P],

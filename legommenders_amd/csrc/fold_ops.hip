@@ -1,0 +1,156 @@
+// Parameter-space products of the folded AttentionOperator block (engine.py, NrmsEngine fold_linear): everything here is D x D /
+// A x D work on WEIGHTS -- no sequence row is touched -- so launch latency, not throughput, is what it costs.  The first version
+// issued these products one launch each through the generic GEMM entry points (13 launches + 3 multi-tensor torch ops per operator
+// and backward pass, all on the side stream) and the NRMS step lost 100 us to them (1.31 -> 1.21 ms with the launches removed).
+// Here each dependency level is ONE launch: a grid of 32 x 32 output tiles over all products of the level (the vector terms are
+// 1 x N products); fp32 FMAs on the vector ALU (a level is ~2 x 17 M MACs spread over ~140 workgroups).
+// Reference: AttentionOperator.forward, model/operators/attention_operator.py:49-56 (the out-projection inside
+// nn.MultiheadAttention, then self.linear, then AdditiveAttention, model/common/attention.py:31-38) and its autograd backward.
+#include "../../include/lego_hip.h"
+#include "common.hpp"
+
+namespace lego {
+
+constexpr int FT = 32;          // output tile edge; 256 threads: thread (ty, tx) owns rows 4 ty .. 4 ty + 3 of column tx
+
+// C[M,N] (+)= sum_k A(m,k) B(k,n) + u[m] v[n] + addv[n]; element strides express NN / NT / TN on row-major operands (one of the two
+// strides of an operand is 1).  The vector terms of a level are products with M = 1 (K = 0: a plain add), so that they get a tile's
+// 256 threads per 32 outputs instead of one thread per output walking K on its own (40 us for two 256 x 256 vector terms)
+struct FoldGemm {
+    const float* A; int a_sm, a_sk;
+    const float* B; int b_sk, b_sn;
+    float* C; int ldc;
+    const float* u; const float* v;   // nullable rank-1 term
+    const float* addv;                 // nullable: + addv[n] on every row
+    int M, N, K;
+    int overwrite;                     // 1: C = ..., 0: C += ...
+};
+constexpr int kMaxGemm = 4;
+struct FoldLevel {
+    FoldGemm g[kMaxGemm];
+    int n_gemm;
+    int tiles[kMaxGemm + 1];           // prefix sums of the products' tile counts
+};
+
+constexpr int KC = 128;         // reduction chunk staged per round trip: every thread has its 2 x 16 loads of a chunk in flight at once
+                                // (a 32-wide chunk per barrier made a K = 256 tile eight dependent round trips: 40 us per launch)
+
+__device__ __forceinline__ void fold_tile(const FoldGemm& p, int tile, float (&As)[FT][KC + 1], float (&Bs)[KC][FT + 1]) {
+    const int tn = (p.N + FT - 1) / FT;
+    const int m0 = (tile / tn) * FT, n0 = (tile % tn) * FT;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < p.K; k0 += KC) {
+        float ra[FT * KC / 256], rb[FT * KC / 256];
+#pragma unroll
+        for (int i = 0; i < FT * KC / 256; ++i) {
+            const int e = threadIdx.x + 256 * i;
+            // consecutive threads run along whichever index is contiguous in memory
+            const int am = p.a_sk == 1 ? e / KC : e % FT, ak = p.a_sk == 1 ? e % KC : e / FT;
+            // out-of-range elements: clamped address, multiplied by 0 (a conditional load here becomes one branch + full wait per
+            // element -- 32 serial round trips, 26 us per launch; weights are finite)
+            const int gm = min(m0 + am, p.M - 1), gk = min(k0 + ak, p.K - 1);
+            ra[i] = p.A[(size_t)gm * p.a_sm + (size_t)gk * p.a_sk] * ((m0 + am < p.M && k0 + ak < p.K) ? 1.f : 0.f);
+            const int bn = p.b_sn == 1 ? e % FT : e / KC, bk = p.b_sn == 1 ? e / FT : e % KC;
+            const int hk = min(k0 + bk, p.K - 1), hn = min(n0 + bn, p.N - 1);
+            rb[i] = p.B[(size_t)hk * p.b_sk + (size_t)hn * p.b_sn] * ((k0 + bk < p.K && n0 + bn < p.N) ? 1.f : 0.f);
+        }
+        __syncthreads();                                    // the previous chunk's readers are done
+#pragma unroll
+        for (int i = 0; i < FT * KC / 256; ++i) {
+            const int e = threadIdx.x + 256 * i;
+            const int am = p.a_sk == 1 ? e / KC : e % FT, ak = p.a_sk == 1 ? e % KC : e / FT;
+            const int bn = p.b_sn == 1 ? e % FT : e / KC, bk = p.b_sn == 1 ? e / FT : e % KC;
+            As[am][ak] = ra[i];
+            Bs[bk][bn] = rb[i];
+        }
+        __syncthreads();
+        const int kn = min(KC, p.K - k0);
+        for (int k = 0; k < kn; ++k) {
+            const float b = Bs[k][tx];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] += As[ty * 4 + i][k] * b;
+        }
+    }
+    const int n = n0 + tx;
+    if (n >= p.N) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty * 4 + i;
+        if (m >= p.M) continue;
+        float x = acc[i];
+        if (p.u != nullptr) x += p.u[m] * p.v[n];
+        if (p.addv != nullptr) x += p.addv[n];
+        float* c = p.C + (size_t)m * p.ldc + n;
+        *c = p.overwrite ? x : *c + x;
+    }
+}
+
+__global__ __launch_bounds__(256) void fold_level_kernel(FoldLevel L) {
+    __shared__ float As[FT][KC + 1], Bs[KC][FT + 1];        // As[m][k], Bs[k][n]
+    const int b = blockIdx.x;
+    int i = 0;
+    while (i + 1 < L.n_gemm && b >= L.tiles[i + 1]) ++i;
+    fold_tile(L.g[i], b - L.tiles[i], As, Bs);
+}
+
+static int launch_level(FoldLevel& L, hipStream_t st, const char* what) {
+    L.tiles[0] = 0;
+    for (int i = 0; i < L.n_gemm; ++i)
+        L.tiles[i + 1] = L.tiles[i] + ((L.g[i].M + FT - 1) / FT) * ((L.g[i].N + FT - 1) / FT);
+    hipLaunchKernelGGL(fold_level_kernel, dim3(L.tiles[L.n_gemm]), dim3(256), 0, st, L);
+    return check_launch(what);
+}
+
+// y[N] (+)= x[K] . W(k,n) + add   as a 1 x N product
+static FoldGemm vec_term(const float* x, const float* W, int w_sk, int w_sn, const float* add, float* y, int N, int K, int overwrite) {
+    return FoldGemm{x, 0, 1, W, w_sk, w_sn, y, N, nullptr, nullptr, add, 1, N, x != nullptr ? K : 0, overwrite};
+}
+
+}  // namespace lego
+
+using namespace lego;
+
+extern "C" int lego_attn_fold_prepare(const float* Wo, const float* bo, const float* Wl, const float* bl, const float* W1,
+                                      const float* b1, float* Wc, float* bc, float* W2, float* b2, int D, int A, void* stream) {
+    LEGO_REQUIRE(D > 0 && A >= 0, "lego_attn_fold_prepare: D=%d A=%d", D, A);
+    hipStream_t st = (hipStream_t)stream;
+    FoldLevel L{};
+    L.n_gemm = 2;
+    L.g[0] = FoldGemm{Wl, D, 1, Wo, D, 1, Wc, D, nullptr, nullptr, nullptr, D, D, D, 1};      // Wc = Wl Wo
+    L.g[1] = vec_term(bo, Wl, 1, D, bl, bc, D, D, 1);                                            // bc = Wl bo + bl
+    if (launch_level(L, st, "lego_attn_fold_prepare") != 0) return 1;
+    if (W2 == nullptr || A == 0) return 0;
+    FoldLevel M{};
+    M.n_gemm = 2;
+    M.g[0] = FoldGemm{W1, D, 1, Wc, D, 1, W2, D, nullptr, nullptr, nullptr, A, D, D, 1};      // W2 = W1 Wc
+    M.g[1] = vec_term(bc, W1, 1, D, b1, b2, A, D, 1);                                            // b2 = W1 bc + b1
+    return launch_level(M, st, "lego_attn_fold_prepare");
+}
+
+extern "C" int lego_attn_fold_grads(const float* Wo, const float* bo, const float* Wl, const float* W1, const float* Wc,
+                                    const float* bc, const float* Tp, const float* sp, float* T, float* s,
+                                    float* gWo, float* gbo, float* gWl, float* gbl, float* gW1, float* gb1,
+                                    int D, int A, void* stream) {
+    LEGO_REQUIRE(D > 0 && A >= 0, "lego_attn_fold_grads: D=%d A=%d", D, A);
+    hipStream_t st = (hipStream_t)stream;
+    if (W1 != nullptr && A > 0) {
+        // level 1 (fold level 2 only): from Tp = dpre^T o and sp = colsum(dpre) to the additive hidden layer's gradients, and the
+        // rest of dL/dWc, dL/dbc on top of what T / s already hold (d_out^T pooled, colsum(d_out))
+        FoldLevel L{};
+        L.n_gemm = 4;
+        L.g[0] = FoldGemm{Tp, D, 1, Wc, 1, D, gW1, D, sp, bc, nullptr, A, D, D, 0};           // gW1 += Tp Wc^T + sp (x) bc
+        L.g[1] = FoldGemm{W1, 1, D, Tp, D, 1, T, D, nullptr, nullptr, nullptr, D, D, A, 0};   // T   += W1^T Tp
+        L.g[2] = vec_term(sp, W1, D, 1, nullptr, s, D, A, 0);                                   // s   += sp W1
+        L.g[3] = vec_term(nullptr, nullptr, 0, 1, sp, gb1, A, 0, 0);                            // gb1 += sp
+        if (launch_level(L, st, "lego_attn_fold_grads") != 0) return 1;
+    }
+    // level 2: T = dL/dWc, s = dL/dbc -> the two affine layers att = o Wo^T + bo, lin = att Wl^T + bl
+    FoldLevel M{};
+    M.n_gemm = 4;
+    M.g[0] = FoldGemm{T, D, 1, Wo, 1, D, gWl, D, s, bo, nullptr, D, D, D, 0};                  // gWl += T Wo^T + s (x) bo
+    M.g[1] = FoldGemm{Wl, 1, D, T, D, 1, gWo, D, nullptr, nullptr, nullptr, D, D, D, 0};      // gWo += Wl^T T
+    M.g[2] = vec_term(s, Wl, D, 1, nullptr, gbo, D, D, 0);                                      // gbo += s Wl
+    M.g[3] = vec_term(nullptr, nullptr, 0, 1, s, gbl, D, 0, 0);                                 // gbl += s
+    return launch_level(M, st, "lego_attn_fold_grads");
+}

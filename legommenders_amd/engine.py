@@ -688,14 +688,9 @@ class NrmsEngine(_Base):
             Wo, bo = P[pre + "multi_head_attention.out_proj.weight"], P[pre + "multi_head_attention.out_proj.bias"]
             Wl, bl = P[pre + "linear.weight"], P[pre + "linear.bias"]
             W1, b1 = P[pre + "additive_attention.encoder.0.weight"], P[pre + "additive_attention.encoder.0.bias"]
-            call("lego_linear_bwd_data", _ptr(Wl), D, _ptr(Wo), D, _ptr(ws["Wc"]), D, D, None, D, D, 0, None, 0, 1.0,
-                 None, None, None, None, None, sp)
-            call("lego_linear_fwd", _ptr(bo), D, _ptr(Wl), D, _ptr(bl), _ptr(ws["bc"]), D, 1, None, D, D, 0, None, None, None, None, sp)
-            if self.fold == 2:
-                call("lego_linear_bwd_data", _ptr(W1), D, _ptr(ws["Wc"]), D, _ptr(ws["W2"]), D, A, None, D, D, 0, None, 0, 1.0,
-                     None, None, None, None, None, sp)
-                call("lego_linear_fwd", _ptr(ws["bc"]), D, _ptr(W1), D, _ptr(b1), _ptr(ws["b2"]), A, 1, None, A, D, 0,
-                     None, None, None, None, sp)
+            two = self.fold == 2
+            call("lego_attn_fold_prepare", _ptr(Wo), _ptr(bo), _ptr(Wl), _ptr(bl), _ptr(W1) if two else None, _ptr(b1) if two else None,
+                 _ptr(ws["Wc"]), _ptr(ws["bc"]), _ptr(ws["W2"]) if two else None, _ptr(ws["b2"]) if two else None, D, A if two else 0, sp)
         if sw is not m:
             self._fold_ev = self._sev[6]
             self._fold_ev.record(sw)
@@ -749,30 +744,23 @@ class NrmsEngine(_Base):
 
     _deferred = ()
 
-    def _side_fold_tail(self, pre, ws, G, sw, sp, extra=()):
-        """side stream: from T = dL/dWc and s = dL/dbc to the four parameters of the two folded layers (att = o Wo^T + bo, lin = att Wl^T + bl):
-            d Wl = T Wo^T + s (x) bo      d bl = s      d Wo = Wl^T T      d bo = s Wl
-        `extra`: further (gradient, scratch) pairs to add in the same multi-tensor launch"""
-        P, D = self.P, self.D
-        Wo, bo = P[pre + "multi_head_attention.out_proj.weight"], P[pre + "multi_head_attention.out_proj.bias"]
-        Wl = P[pre + "linear.weight"]
-        call("lego_linear_fwd", _ptr(ws["T"]), D, _ptr(Wo), D, None, _ptr(ws["U"]), D, D, None, D, D, 0, None, None, None, None, sp)
-        call("lego_linear_bwd_weight", _ptr(ws["s"]), D, _ptr(bo), D, _ptr(G[pre + "linear.weight"]), D, 1, None, D, D, None, None, sp)
-        call("lego_linear_bwd_weight", _ptr(Wl), D, _ptr(ws["T"]), D, _ptr(G[pre + "multi_head_attention.out_proj.weight"]), D,
-             D, None, D, D, None, None, sp)
-        call("lego_linear_bwd_data", _ptr(ws["s"]), D, _ptr(Wl), D, _ptr(G[pre + "multi_head_attention.out_proj.bias"]), D,
-             1, None, D, D, 1, None, 0, 1.0, None, None, None, None, None, sp)
-        acc = [G[pre + "linear.weight"], G[pre + "linear.bias"]] + [a for a, _ in extra]
-        src = [ws["U"], ws["s"]] + [b for _, b in extra]
-        with torch.cuda.stream(sw):                      # one multi-tensor launch each instead of one per tensor
-            torch._foreach_add_(acc, src)
-            torch._foreach_zero_([ws["s"], ws["sp"]])
+    def _side_fold_grads(self, pre, ws, G, sp, two):
+        """side stream: lego_attn_fold_grads -- from T = dL/dWc, s = dL/dbc (and, fold level 2, Tp = dpre^T o, sp = colsum(dpre)) to the
+        gradients of out_proj, Linear (and the additive hidden layer): two launches"""
+        P, D, A = self.P, self.D, self.A
+        g = lambda k: _ptr(G[pre + k])
+        call("lego_attn_fold_grads", _ptr(P[pre + "multi_head_attention.out_proj.weight"]), _ptr(P[pre + "multi_head_attention.out_proj.bias"]),
+             _ptr(P[pre + "linear.weight"]), _ptr(P[pre + "additive_attention.encoder.0.weight"]) if two else None,
+             _ptr(ws["Wc"]), _ptr(ws["bc"]), _ptr(ws["Tp"]) if two else None, _ptr(ws["sp"]) if two else None, _ptr(ws["T"]), _ptr(ws["s"]),
+             g("multi_head_attention.out_proj.weight"), g("multi_head_attention.out_proj.bias"), g("linear.weight"), g("linear.bias"),
+             g("additive_attention.encoder.0.weight") if two else None, g("additive_attention.encoder.0.bias") if two else None,
+             D, A if two else 0, sp)
 
     def _att_bwd_folded(self, pre, ws, G, rows_dyn, seg_off, n_cap, n_dyn, gout, st, ev, m, sw, sp):
         """fold level 2 (see __init__): with W2 = W1 Wc, pre = o W2^T + b2, out_i = pooled_i Wc^T + bc, pooled_i = sum_r w_r o_r:
             d pooled = d_out Wc;   pool backward on (t, o) gives dpre (in t) and d_o = w (x) d pooled;   d_o += dpre W2
             Tp = dpre^T o,  sp = colsum(dpre):   d W1 = Tp Wc^T + sp (x) bc,   d b1 = sp
-            T  = d_out^T pooled + W1^T Tp,       s = colsum(d_out) + sp W1     (gradients of Wc and bc; then _side_fold_tail)"""
+            T  = d_out^T pooled + W1^T Tp,       s = colsum(d_out) + sp W1     (gradients of Wc and bc; then lego_attn_fold_grads)"""
         P, D, A = self.P, self.D, self.A
         rows = ws["rows"]
         W1 = P[pre + "additive_attention.encoder.0.weight"]
@@ -787,25 +775,24 @@ class NrmsEngine(_Base):
         if sw is not m:
             ev[0].record(m)
 
-        def side():
-            # ---- side stream: everything that ends in a parameter gradient.  Enqueued by backward() AFTER the main chain of both
-            # operators: ~15 small launches here would otherwise sit between the host and the attention-core launch that the
-            # main stream is waiting for
+        # ---- side stream: everything that ends in a parameter gradient.  Enqueued by backward() AFTER the main chain of both operators
+        # (the host would otherwise be busy with these launches while the main stream waits for its attention-core launch).  Order on
+        # the side stream: this operator's row product, its parameter-space launches, then (side2) the in-projection weight gradient --
+        # the longest launch goes last so that the short ones run beside the main stream's attention core, not after everything
+        def side_rows():
             if sw is not m:
                 sw.wait_event(ev[0])
-            call("lego_additive_pool_bwd_fold", _ptr(self._pool_scratch(A, pre)), A, _ptr(gw2), _ptr(ws["sp"]), sp)
-            with torch.cuda.stream(sw):
-                torch._foreach_zero_([ws["Tp"], ws["T"]])
+            with torch.cuda.stream(sw):                  # the four sums of this pass start from zero (one multi-tensor launch)
+                torch._foreach_zero_([ws["Tp"], ws["T"], ws["s"], ws["sp"]])
             call("lego_linear_bwd_weight", _ptr(ws["t"]), A, _ptr(ws["o"]), D, _ptr(ws["Tp"]), D, rows, rows_dyn, A, D, None, None, sp)
+
+        def side_params():
+            call("lego_additive_pool_bwd_fold", _ptr(self._pool_scratch(A, pre)), A, _ptr(gw2), _ptr(ws["sp"]), sp)
             call("lego_linear_bwd_weight", _ptr(gout), D, _ptr(ws["pooled"]), D, _ptr(ws["T"]), D, n_cap, n_dyn, D, D, None, None, sp)
-            call("lego_linear_bwd_weight", _ptr(W1), D, _ptr(ws["Tp"]), D, _ptr(ws["T"]), D, A, None, D, D, None, None, sp)
             call("lego_colsum", _ptr(gout), D, n_cap, n_dyn, None, D, _ptr(ws["s"]), sp)
-            call("lego_linear_bwd_data", _ptr(ws["sp"]), A, _ptr(W1), D, _ptr(ws["s"]), D, 1, None, A, D, 1,
-                 None, 0, 1.0, None, None, None, None, None, sp)
-            call("lego_linear_fwd", _ptr(ws["Tp"]), D, _ptr(ws["Wc"]), D, None, _ptr(ws["U2"]), D, A, None, D, D, 0, None, None, None, None, sp)
-            call("lego_linear_bwd_weight", _ptr(ws["sp"]), A, _ptr(ws["bc"]), D, _ptr(gW1), D, 1, None, A, D, None, None, sp)
-            self._side_fold_tail(pre, ws, G, sw, sp, extra=((gW1, ws["U2"]), (gb1, ws["sp"])))
-        self._deferred.append(side)
+            self._side_fold_grads(pre, ws, G, sp, True)
+        self._deferred.append(side_rows)
+        self._deferred.append(side_params)
 
     def _att_bwd_head(self, pre, ws, G, rows_dyn, seg_off, n_cap, n_dyn, gout, st, ev, m, sw, sp):
         """the additive attention and the two affine layers behind the attention core, fold levels 0 and 1"""
@@ -841,7 +828,9 @@ class NrmsEngine(_Base):
             with torch.cuda.stream(sw):
                 ws["T"].zero_()
             call("lego_linear_bwd_weight", _ptr(ws["d_lin"]), D, _ptr(ws["o"]), D, _ptr(ws["T"]), D, rows, rows_dyn, D, D, None, None, sp)
-            self._side_fold_tail(pre, ws, G, sw, sp)
+            self._side_fold_grads(pre, ws, G, sp, False)
+            with torch.cuda.stream(sw):
+                ws["s"].zero_()                          # the next pass's column sums (main stream epilogue) start from zero
             # ---- main: data gradient through both layers at once
             call("lego_linear_bwd_data", _ptr(ws["d_lin"]), D, _ptr(ws["Wc"]), D, _ptr(ws["d_o"]), D,
                  rows, rows_dyn, D, D, 0, None, 0, 1.0, None, None, None, None, None, st)
@@ -927,6 +916,9 @@ class NrmsEngine(_Base):
         self._deferred = []
         self._att_bwd("user_op.", self.user_ws, G, _ptr(self.items, self.BC * D), _ptr(self.d_items, self.BC * D),
                       self.cnt(3), self.hist_off, B, None, self.d_user, SITE_USER_ATT, training, st, sev[0:2])
+        for side in self._deferred:                  # the user operator's side-stream launches: its main chain is enqueued
+            side()
+        self._deferred = []
         self._att_bwd("item_op.", self.item_ws, G, _ptr(self.E), _ptr(self.dE), self.cnt(0), self.seg_off, self.NIc,
                       self.cnt(1), self.d_items, SITE_ITEM_ATT, training, st, sev[2:4])
         # embedding tables: the three summed look-ups of ConcatInputer.get_embeddings.  [SEP] (id 2 of the special table) and the
@@ -946,7 +938,7 @@ class NrmsEngine(_Base):
                  self.Rc, self.cnt(0), _ptr(self.dE), D, st)
             if self.touched_rows is not None:       # TrainStep: rows that have ever had a gradient (row-skipping dense Adam)
                 call("lego_mark_rows", _ptr(self.idx_tok), self.Rc, self.cnt(0), V, _ptr(self.touched_rows), st)
-        for side in self._deferred:                  # the side-stream launches of both operators, behind the whole main chain
+        for side in self._deferred:                  # the item operator's side-stream launches, behind its whole main chain
             side()
         self._deferred = ()
         if sw is not m:

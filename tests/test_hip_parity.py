@@ -990,3 +990,46 @@ def test_nrms_folded_linear_equals_unfolded(glove):
                 continue
             d = float((g1[k] - g0[k]).abs().max())
             assert d <= 2e-5 * gmax + 2e-5 * float(g0[k].abs().max()), (level, k, d, gmax)
+
+
+@pytest.mark.parametrize("D,A", [(256, 256), (96, 40), (32, 0)])
+def test_attn_fold_entry_points(D, A):
+    """lego_attn_fold_prepare / lego_attn_fold_grads against float64 autograd of the parameter map they implement:
+    (Wo, bo, Wl, bl, W1, b1) -> Wc = Wl Wo, bc = Wl bo + bl, W2 = W1 Wc, b2 = W1 bc + b1, with upstream gradients Tp = dL/dW2,
+    sp = dL/db2 and T0 = direct dL/dWc, s0 = direct dL/dbc.  A = 0: the first fold only (no W1)."""
+    from legommenders_amd._lib import call
+    from legommenders_amd.kernels import _ptr, _stream
+    dev = _dev()
+    g = torch.Generator().manual_seed(D + A)
+    r = lambda *s: (torch.randn(*s, generator=g, dtype=torch.float64) * 0.3)
+    Wo, bo, Wl, bl = r(D, D), r(D), r(D, D), r(D)
+    W1, b1 = (r(A, D), r(A)) if A else (None, None)
+    Tp, sp_ = (r(A, D), r(A)) if A else (None, None)
+    T0, s0 = r(D, D), r(D)
+    leaves = [t.clone().requires_grad_(True) for t in (Wo, bo, Wl, bl)] + ([W1.clone().requires_grad_(True), b1.clone().requires_grad_(True)] if A else [])
+    Wc = leaves[2] @ leaves[0]
+    bc = leaves[2] @ leaves[1] + leaves[3]
+    loss = (Wc * T0).sum() + (bc * s0).sum()
+    if A:
+        W2, b2 = leaves[4] @ Wc, leaves[4] @ bc + leaves[5]
+        loss = loss + (W2 * Tp).sum() + (b2 * sp_).sum()
+    loss.backward()
+    f = lambda t: None if t is None else t.float().to(dev).contiguous()
+    dWc, dbc = torch.empty(D, D, device=dev), torch.empty(D, device=dev)
+    dW2, db2 = (torch.empty(A, D, device=dev), torch.empty(A, device=dev)) if A else (None, None)
+    P = [f(t) for t in (Wo, bo, Wl, bl, W1, b1)]
+    call("lego_attn_fold_prepare", *[_ptr(t) for t in P], _ptr(dWc), _ptr(dbc), _ptr(dW2), _ptr(db2), D, A, _stream())
+    _close(dWc.cpu(), Wc.detach(), rtol=2e-6, what="Wc")
+    _close(dbc.cpu(), bc.detach(), rtol=2e-6, what="bc")
+    if A:
+        _close(dW2.cpu(), W2.detach(), rtol=2e-6, what="W2")
+        _close(db2.cpu(), b2.detach(), rtol=2e-6, what="b2")
+    init = [torch.full_like(f(t), 0.25) for t in leaves]              # the gradients ACCUMULATE
+    gWo, gbo, gWl, gbl = init[:4]
+    gW1, gb1 = (init[4], init[5]) if A else (None, None)
+    T, s = f(T0), f(s0)
+    call("lego_attn_fold_grads", _ptr(P[0]), _ptr(P[1]), _ptr(P[2]), _ptr(P[4]), _ptr(dWc), _ptr(dbc), _ptr(f(Tp)), _ptr(f(sp_)), _ptr(T), _ptr(s),
+         _ptr(gWo), _ptr(gbo), _ptr(gWl), _ptr(gbl), _ptr(gW1), _ptr(gb1), D, A, _stream())
+    torch.cuda.synchronize()
+    for got, leaf, name in zip(init, leaves, ("Wo", "bo", "Wl", "bl", "W1", "b1")):
+        _close(got.cpu() - 0.25, leaf.grad, rtol=5e-6, what="d" + name)
