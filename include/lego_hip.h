@@ -208,13 +208,20 @@ int lego_mhsa_core_bwd(const float* qkv, int ldq, const int32_t* seg_off, int n_
  *   T  = d(loss)/dWc so far (d_out^T pooled, or d_lin^T o for the first fold) [D,D],  s = d(loss)/dbc so far [D]:
  *   gW1 += Tp Wc^T + sp (x) bc, gb1 += sp, T += W1^T Tp, s += sp W1;
  *   gWl += T Wo^T + s (x) bo, gbl += s, gWo += Wl^T T, gbo += s Wl.      T and s are updated in place.
- * One launch per dependency level (two each), 32 x 32 output tiles on the vector ALU. */
+ * One launch per dependency level (two each): one wave per 16 x 16 output tile, operands straight from L2. */
 int lego_attn_fold_prepare(const float* Wo, const float* bo, const float* Wl, const float* bl, const float* W1,
                            const float* b1, float* Wc, float* bc, float* W2, float* b2, int D, int A, void* stream);
 int lego_attn_fold_grads(const float* Wo, const float* bo, const float* Wl, const float* W1, const float* Wc,
                          const float* bc, const float* Tp, const float* sp, float* T, float* s,
                          float* gWo, float* gbo, float* gWl, float* gbl, float* gW1, float* gb1,
                          int D, int A, void* stream);
+
+/* out_a[rows_a, N] += S_a[rows_a, K] . W[K, N] and out_b[rows_b, N] += S_b[rows_b, K] . W[K, N] (row-major, W with leading
+ * dimension N, S with K) in ONE launch: a few rows through a weight matrix.  Engine use: the [SEP] / category gradients of
+ * ConcatInputer's small tables (concat_inputer.py:96-114) from the row sums of d(qkv) that lego_nrms_special_grads produces when it
+ * is run on d(qkv) instead of d(E): sum_r dE[r] = (sum_r dqkv[r]) . W_in. */
+int lego_small_rows_matmul_add(const float* S_a, int rows_a, float* out_a, int ld_a, const float* S_b, int rows_b, float* out_b,
+                               int ld_b, const float* W, int K, int N, void* stream);
 
 /* ---- a13: torch.optim.Adam (defaults, base_lego.py:201-204) over one flat fp32 buffer;
  * grad is multiplied by grad_scale first (1/world after the RCCL all-reduce). step is 1-based.

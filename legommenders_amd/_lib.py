@@ -34,6 +34,7 @@ SIGNATURES = {
     "lego_nrms_decode_rows": [P, I, P, P, P, P, P, P],
     "lego_nrms_special_grads": [P, I, P, P, P, I, I, P, P, I, I, P],
     "lego_mask_dropout_rows": [P, I, I, P, I, P, P, P, P],
+    "lego_small_rows_matmul_add": [P, I, P, I, P, I, P, I, P, I, I, P],
     "lego_attn_fold_prepare": [P, P, P, P, P, P, P, P, P, P, I, I, P],
     "lego_attn_fold_grads": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P],
     "lego_scatter_add_rows": [P, I, I, I, P, I, P, P, I, P],

@@ -2,8 +2,8 @@
 // A x D work on WEIGHTS -- no sequence row is touched -- so launch latency, not throughput, is what it costs.  The first version
 // issued these products one launch each through the generic GEMM entry points (13 launches + 3 multi-tensor torch ops per operator
 // and backward pass, all on the side stream) and the NRMS step lost 100 us to them (1.31 -> 1.21 ms with the launches removed).
-// Here each dependency level is ONE launch: a grid of 32 x 32 output tiles over all products of the level (the vector terms are
-// 1 x N products); fp32 FMAs on the vector ALU (a level is ~2 x 17 M MACs spread over ~140 workgroups).
+// Here each dependency level is ONE launch: a grid of 16 x 16 output tiles (one wave each) over all products of the level; the vector
+// terms are 1 x N products.
 // Reference: AttentionOperator.forward, model/operators/attention_operator.py:49-56 (the out-projection inside
 // nn.MultiheadAttention, then self.linear, then AdditiveAttention, model/common/attention.py:31-38) and its autograd backward.
 #include "../../include/lego_hip.h"
@@ -11,11 +11,11 @@
 
 namespace lego {
 
-constexpr int FT = 32;          // output tile edge; 256 threads: thread (ty, tx) owns rows 4 ty .. 4 ty + 3 of column tx
+constexpr int FT = 16;          // output tile edge: one wave, one v_mfma_f32_16x16x4_f32 accumulator
 
 // C[M,N] (+)= sum_k A(m,k) B(k,n) + u[m] v[n] + addv[n]; element strides express NN / NT / TN on row-major operands (one of the two
 // strides of an operand is 1).  The vector terms of a level are products with M = 1 (K = 0: a plain add), so that they get a tile's
-// 256 threads per 32 outputs instead of one thread per output walking K on its own (40 us for two 256 x 256 vector terms)
+// wave per 16 outputs instead of one thread per output walking K on its own (40 us for two 256 x 256 vector terms)
 struct FoldGemm {
     const float* A; int a_sm, a_sk;
     const float* B; int b_sk, b_sn;
@@ -32,51 +32,41 @@ struct FoldLevel {
     int tiles[kMaxGemm + 1];           // prefix sums of the products' tile counts
 };
 
-constexpr int KC = 128;         // reduction chunk staged per round trip: every thread has its 2 x 16 loads of a chunk in flight at once
-                                // (a 32-wide chunk per barrier made a K = 256 tile eight dependent round trips: 40 us per launch)
-
-__device__ __forceinline__ void fold_tile(const FoldGemm& p, int tile, float (&As)[FT][KC + 1], float (&Bs)[KC][FT + 1]) {
+// One WAVE per 16 x 16 output tile, v_mfma_f32_16x16x4_f32 with both operands read straight from global memory (they are a few
+// hundred KB and L2-resident), no LDS, ~40 VGPRs: a launch has to START while a row-strip product or the attention core holds
+// most of every SIMD's registers and LDS -- the first version (256-thread workgroups, 33 KB of LDS, 192 then 80 VGPRs) sat behind the
+// 130 us strip product it was meant to run beside.  Out-of-range elements: clamped address, multiplied by 0 (a conditional load
+// becomes one branch + full wait per element; weights are finite).
+__device__ __forceinline__ void fold_tile(const FoldGemm& p, int tile) {
     const int tn = (p.N + FT - 1) / FT;
     const int m0 = (tile / tn) * FT, n0 = (tile % tn) * FT;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < p.K; k0 += KC) {
-        float ra[FT * KC / 256], rb[FT * KC / 256];
+    const int lane = threadIdx.x, l16 = lane & 15, g4 = lane >> 4;
+    const int am = min(m0 + l16, p.M - 1), bn = min(n0 + l16, p.N - 1);
+    const float fa = m0 + l16 < p.M ? 1.f : 0.f, fb = n0 + l16 < p.N ? 1.f : 0.f;
+    const float* pa = p.A + (size_t)am * p.a_sm;
+    const float* pb = p.B + (size_t)bn * p.b_sn;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 8;                                    // k steps (of 4) whose 2 x 8 loads are in flight together
+    for (int k0 = 0; k0 < p.K; k0 += 4 * U) {
+        float ra[U], rb[U];
 #pragma unroll
-        for (int i = 0; i < FT * KC / 256; ++i) {
-            const int e = threadIdx.x + 256 * i;
-            // consecutive threads run along whichever index is contiguous in memory
-            const int am = p.a_sk == 1 ? e / KC : e % FT, ak = p.a_sk == 1 ? e % KC : e / FT;
-            // out-of-range elements: clamped address, multiplied by 0 (a conditional load here becomes one branch + full wait per
-            // element -- 32 serial round trips, 26 us per launch; weights are finite)
-            const int gm = min(m0 + am, p.M - 1), gk = min(k0 + ak, p.K - 1);
-            ra[i] = p.A[(size_t)gm * p.a_sm + (size_t)gk * p.a_sk] * ((m0 + am < p.M && k0 + ak < p.K) ? 1.f : 0.f);
-            const int bn = p.b_sn == 1 ? e % FT : e / KC, bk = p.b_sn == 1 ? e / FT : e % KC;
-            const int hk = min(k0 + bk, p.K - 1), hn = min(n0 + bn, p.N - 1);
-            rb[i] = p.B[(size_t)hk * p.b_sk + (size_t)hn * p.b_sn] * ((k0 + bk < p.K && n0 + bn < p.N) ? 1.f : 0.f);
+        for (int u = 0; u < U; ++u) {
+            const int k = min(k0 + 4 * u + g4, p.K - 1);
+            ra[u] = pa[(size_t)k * p.a_sk];
+            rb[u] = pb[(size_t)k * p.b_sk];
         }
-        __syncthreads();                                    // the previous chunk's readers are done
+        __builtin_amdgcn_sched_barrier(0);                  // every load of the batch is issued before the first product waits
 #pragma unroll
-        for (int i = 0; i < FT * KC / 256; ++i) {
-            const int e = threadIdx.x + 256 * i;
-            const int am = p.a_sk == 1 ? e / KC : e % FT, ak = p.a_sk == 1 ? e % KC : e / FT;
-            const int bn = p.b_sn == 1 ? e % FT : e / KC, bk = p.b_sn == 1 ? e / FT : e % KC;
-            As[am][ak] = ra[i];
-            Bs[bk][bn] = rb[i];
-        }
-        __syncthreads();
-        const int kn = min(KC, p.K - k0);
-        for (int k = 0; k < kn; ++k) {
-            const float b = Bs[k][tx];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] += As[ty * 4 + i][k] * b;
+        for (int u = 0; u < U; ++u) {
+            const float in = k0 + 4 * u + g4 < p.K ? 1.f : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[u] * (fa * in), rb[u] * fb, acc, 0, 0, 0);
         }
     }
-    const int n = n0 + tx;
+    const int n = n0 + l16;                                  // lane holds column l16, rows 4 * g4 + i
     if (n >= p.N) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int m = m0 + ty * 4 + i;
+        const int m = m0 + 4 * g4 + i;
         if (m >= p.M) continue;
         float x = acc[i];
         if (p.u != nullptr) x += p.u[m] * p.v[n];
@@ -86,19 +76,18 @@ __device__ __forceinline__ void fold_tile(const FoldGemm& p, int tile, float (&A
     }
 }
 
-__global__ __launch_bounds__(256) void fold_level_kernel(FoldLevel L) {
-    __shared__ float As[FT][KC + 1], Bs[KC][FT + 1];        // As[m][k], Bs[k][n]
+__global__ __launch_bounds__(64) void fold_level_kernel(FoldLevel L) {
     const int b = blockIdx.x;
     int i = 0;
     while (i + 1 < L.n_gemm && b >= L.tiles[i + 1]) ++i;
-    fold_tile(L.g[i], b - L.tiles[i], As, Bs);
+    fold_tile(L.g[i], b - L.tiles[i]);
 }
 
 static int launch_level(FoldLevel& L, hipStream_t st, const char* what) {
     L.tiles[0] = 0;
     for (int i = 0; i < L.n_gemm; ++i)
         L.tiles[i + 1] = L.tiles[i] + ((L.g[i].M + FT - 1) / FT) * ((L.g[i].N + FT - 1) / FT);
-    hipLaunchKernelGGL(fold_level_kernel, dim3(L.tiles[L.n_gemm]), dim3(256), 0, st, L);
+    hipLaunchKernelGGL(fold_level_kernel, dim3(L.tiles[L.n_gemm]), dim3(64), 0, st, L);
     return check_launch(what);
 }
 
@@ -153,4 +142,18 @@ extern "C" int lego_attn_fold_grads(const float* Wo, const float* bo, const floa
     M.g[2] = vec_term(s, Wl, D, 1, nullptr, gbo, D, D, 0);                                      // gbo += s Wl
     M.g[3] = vec_term(nullptr, nullptr, 0, 1, s, gbl, D, 0, 0);                                 // gbl += s
     return launch_level(M, st, "lego_attn_fold_grads");
+}
+
+// [SEP] / category gradients of ConcatInputer's small tables taken one product early (engine.py, NRMS GloVe variant): the row sums
+// S_sep[K3], S_cat[n_cat][K3] of d(qkv) at the [SEP] / category positions (lego_nrms_special_grads on d(qkv)) map through the
+// in-projection weight: g_sep += S_sep W_in, g_cat += S_cat W_in  -- one launch (the generic product entry point spent 36 us on each).
+extern "C" int lego_small_rows_matmul_add(const float* S_a, int rows_a, float* out_a, int ld_a, const float* S_b, int rows_b, float* out_b,
+                                          int ld_b, const float* W, int K, int N, void* stream) {
+    LEGO_REQUIRE(K > 0 && N > 0 && rows_a >= 0 && rows_b >= 0, "lego_small_rows_matmul_add: K=%d N=%d rows=%d,%d", K, N, rows_a, rows_b);
+    FoldLevel L{};
+    L.n_gemm = 0;
+    if (rows_a > 0) L.g[L.n_gemm++] = FoldGemm{S_a, K, 1, W, N, 1, out_a, ld_a, nullptr, nullptr, nullptr, rows_a, N, K, 0};
+    if (rows_b > 0) L.g[L.n_gemm++] = FoldGemm{S_b, K, 1, W, N, 1, out_b, ld_b, nullptr, nullptr, nullptr, rows_b, N, K, 0};
+    if (L.n_gemm == 0) return 0;
+    return launch_level(L, (hipStream_t)stream, "lego_small_rows_matmul_add");
 }

@@ -710,7 +710,7 @@ class NrmsEngine(_Base):
         m = torch.cuda.current_stream()
         return m, (m if os.environ.get("LEGO_SERIAL") == "1" else self._sw)
 
-    def _att_bwd(self, pre, ws, G, x_ptr, dx_ptr, rows_dyn, seg_off, n_cap, n_dyn, gout, site, training, st, ev):
+    def _att_bwd(self, pre, ws, G, x_ptr, dx_ptr, rows_dyn, seg_off, n_cap, n_dyn, gout, site, training, st, ev, dx_epi=None):
         """data-gradient chain on the current stream `st`; weight gradients in two groups on the side stream, each behind
         ONE event (`ev[0]`, `ev[1]`) recorded where its inputs are final (the workspace is not overwritten before the
         next forward, which the caller orders after the side stream)"""
@@ -739,8 +739,11 @@ class NrmsEngine(_Base):
             self._deferred.append(side2)
         else:
             side2()
+        # dx = d_qkv W_in; `dx_epi` = (rowinfo, dropout, colsum): the backward of the GloVe projection's mask + Dropout and its bias
+        # gradient in this product's epilogue (NRMS item side)
+        ri, dr, cs = dx_epi if dx_epi is not None else (None, None, None)
         call("lego_linear_bwd_data", _ptr(ws["d_qkv"]), 3 * D, _ptr(P[pre + "multi_head_attention.in_proj_weight"]), D,
-             dx_ptr, D, rows, rows_dyn, 3 * D, D, 0, None, 0, 1.0, None, None, None, None, None, st)
+             dx_ptr, D, rows, rows_dyn, 3 * D, D, 0, None, 0, 1.0, ri, dr, cs, None, None, st)
 
     _deferred = ()
 
@@ -870,6 +873,11 @@ class NrmsEngine(_Base):
              _ptr(self.rowinfo), _ptr(self.row_tok), _stream())
 
     _folds_fresh = False
+    # GloVe variant: mask + Dropout backward and the projection bias gradient in the epilogue of dx = d_qkv W_in, [SEP] / category
+    # gradients from row sums of d(qkv).  Correct (test_nrms_folded_linear_equals_unfolded runs both forms) and 31 us shorter on the
+    # main stream, but the three extra side-stream launches land behind the in-projection weight gradient, where the side stream is
+    # already the longer one: 1.240 against 1.212 ms per step.  Off until the side stream has room.
+    fused_mask = os.environ.get("LEGO_NRMS_FUSED_MASK") == "1"
 
     def _forward_items(self, training):
         P, D = self.P, self.D
@@ -919,17 +927,44 @@ class NrmsEngine(_Base):
         for side in self._deferred:                  # the user operator's side-stream launches: its main chain is enqueued
             side()
         self._deferred = []
+        g_spec, g_cat = G["embedding_vocab_table.__cat_inputer_special_ids.weight"], G["embedding_vocab_table.category.weight"]
+        n_cat = g_cat.shape[0]
+        epi = None
+        fused = self.glove and self.fused_mask
+        if fused:
+            # the data gradient of the in-projection lands in dE already masked + dropout-scaled, with the projection's bias gradient as
+            # its column sums (one epilogue instead of two more passes over dE: 20 + 18-26 us of the main stream's tail)
+            epi = (_ptr(self.tokinfo), self.drop(self.p_proj, SITE_PROJ, training), _ptr(G["embedding_vocab_table.glove.linear.bias"]))
         self._att_bwd("item_op.", self.item_ws, G, _ptr(self.E), _ptr(self.dE), self.cnt(0), self.seg_off, self.NIc,
-                      self.cnt(1), self.d_items, SITE_ITEM_ATT, training, st, sev[2:4])
+                      self.cnt(1), self.d_items, SITE_ITEM_ATT, training, st, sev[2:4], dx_epi=epi)
         # embedding tables: the three summed look-ups of ConcatInputer.get_embeddings.  [SEP] (id 2 of the special table) and the
         # category row come from fixed places of every item's sequence (lego_nrms_special_grads)
-        g_spec, g_cat = G["embedding_vocab_table.__cat_inputer_special_ids.weight"], G["embedding_vocab_table.category.weight"]
-        call("lego_nrms_special_grads", _ptr(self.seg_off), self.NIc, self.cnt(1), _ptr(self.idx_cat), _ptr(self.dE), D, D,
-             _ptr(g_spec, 2 * D), _ptr(g_cat), D, g_cat.shape[0], st)
+        if fused:
+            # ... whose gradient rows the mask has just zeroed in dE: take them one product earlier.  sum_r dE[r] over a set of rows =
+            # (sum_r d_qkv[r]) W_in, so the kernel sums the [SEP] / category ROWS OF d_qkv (3 rows per item) and two tiny products map
+            # the sums through W_in -- on the side stream, behind the in-projection weight gradient
+            ws, W_in = self.item_ws, P["item_op.multi_head_attention.in_proj_weight"]
+            if "S_sep" not in ws:
+                ws["S_sep"], ws["S_cat"] = self._f(3 * D), self._f(n_cat, 3 * D)
+            _, sw_ = self._side()
+
+            def side_special():
+                spp = ctypes.c_void_p(sw_.cuda_stream)
+                with torch.cuda.stream(sw_):
+                    torch._foreach_zero_([ws["S_sep"], ws["S_cat"]])
+                call("lego_nrms_special_grads", _ptr(self.seg_off), self.NIc, self.cnt(1), _ptr(self.idx_cat), _ptr(ws["d_qkv"]), 3 * D, 3 * D,
+                     _ptr(ws["S_sep"]), _ptr(ws["S_cat"]), 3 * D, n_cat, spp)
+                call("lego_small_rows_matmul_add", _ptr(ws["S_sep"]), 1, _ptr(g_spec, 2 * D), D, _ptr(ws["S_cat"]), n_cat, _ptr(g_cat), D,
+                     _ptr(W_in), 3 * D, D, spp)
+            self._deferred.append(side_special)
+        else:
+            call("lego_nrms_special_grads", _ptr(self.seg_off), self.NIc, self.cnt(1), _ptr(self.idx_cat), _ptr(self.dE), D, D,
+                 _ptr(g_spec, 2 * D), _ptr(g_cat), D, n_cat, st)
         if self.glove:
             E0 = self.E0
-            call("lego_mask_dropout_rows", _ptr(self.dE), D, self.Rc, self.cnt(0), D, _ptr(self.tokinfo),
-                 self.drop(self.p_proj, SITE_PROJ, training), _ptr(G["embedding_vocab_table.glove.linear.bias"]), st)
+            if not fused:                            # the three-pass form (kept as the cross-check of the fused epilogue)
+                call("lego_mask_dropout_rows", _ptr(self.dE), D, self.Rc, self.cnt(0), D, _ptr(self.tokinfo),
+                     self.drop(self.p_proj, SITE_PROJ, training), _ptr(G["embedding_vocab_table.glove.linear.bias"]), st)
             call("lego_linear_bwd_weight", _ptr(self.dE), D, _ptr(self.X), E0,
                  _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Rc, self.cnt(0), D, E0, None, None, st)
         else:

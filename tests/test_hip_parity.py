@@ -952,7 +952,9 @@ def test_mask_dropout_rows_fused_colsum(R, W):
 def test_nrms_folded_linear_equals_unfolded(glove):
     """NrmsEngine(fold_linear=1 / 2) -- the attention out-projection folded into AttentionOperator's Linear (attention_operator.py:49-56:
     nothing sits between them), and at level 2 the additive attention's hidden layer and pooled sum taken straight from the attention
-    output -- computes the same scores, loss and parameter gradients as the layer-by-layer form, with dropout on (the
+    output -- computes the same scores, loss and parameter gradients as the layer-by-layer form, with dropout on; the level-1 engine
+    also takes the projection's mask / Dropout backward and bias column sums from the in-projection's data-gradient epilogue and the
+    [SEP] / category gradients from row sums of d(qkv) (`fused_mask`) instead of separate passes over dE (the
     dropout sites and counters do not depend on the fold).  Also with gradients ACCUMULATED over two backward passes: the fold's
     scratch sums (T, s) must not leak from one pass into the next."""
     from legommenders_amd import engine as E
@@ -973,6 +975,7 @@ def test_nrms_folded_linear_equals_unfolded(glove):
     out = {}
     for fold in (0, 1, 2):
         eng = E.NrmsEngine(Pd, tb, B, C, S, heads=8, glove=glove, seed=77, fold_linear=fold)
+        eng.fused_mask = fold == 1      # level 1 also runs the fused-epilogue form of the projection's mask / Dropout / bias-gradient backward
         G = eng.grads_like()
         for _ in range(2):                        # dropout sites are keyed on (seed, step): the same draws with and without the fold
             scores, loss = eng.forward(*ids, training=True)
