@@ -12,6 +12,16 @@ glove = glove_like(cfg["V"], 300, seed=2024, device=dev)
 params = init_naml_params(D=256, V=cfg["V"], n_cat=cfg["n_cat"], glove=glove)
 ts = TrainStep("naml", params, data, 64, K=4, lr=1e-3, total_steps=0, seed=2023, dropout=True, tail="drop", glove=True)
 N = 120
+if os.environ.get("SPIN_MS"):                       # busy the device first: is the slow start a clock ramp?
+    a = torch.randn(4096, 4096, device=dev)
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(int(float(os.environ["SPIN_MS"]) / 1.0)):
+        a = (a @ a).clamp_(-1, 1)
+    t1.record(); torch.cuda.synchronize()
+    print("spin", t0.elapsed_time(t1), "ms")
+if os.environ.get("TOUCH") == "1":                  # ... or first touches of the 480 MB table?
+    print("touch", float(glove.sum()))
 evs = [torch.cuda.Event(enable_timing=True) for _ in range(N + 1)]
 torch.cuda.synchronize()
 evs[0].record()
