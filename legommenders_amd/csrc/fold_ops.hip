@@ -46,7 +46,7 @@ __device__ __forceinline__ void fold_tile(const FoldGemm& p, int tile) {
     const float* pa = p.A + (size_t)am * p.a_sm;
     const float* pb = p.B + (size_t)bn * p.b_sn;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    constexpr int U = 8;                                    // k steps (of 4) whose 2 x 8 loads are in flight together
+    constexpr int U = 16;                                   // k steps (of 4) whose 2 x 16 loads are in flight together
     for (int k0 = 0; k0 < p.K; k0 += 4 * U) {
         float ra[U], rb[U];
 #pragma unroll
