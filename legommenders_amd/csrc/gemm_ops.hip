@@ -272,7 +272,7 @@ static int launch_oneshot(const GemmDims& d, const AL& a, const BL& b, const Epi
         attr_done = true;
     }
     hipLaunchKernelGGL(k, dim3((d.M + ONE_BM - 1) / ONE_BM, (d.N + ONE_BN - 1) / ONE_BN), dim3(ONE_THREADS),
-                       oneshot_lds_bytes<B_MC>(d.K), st, d, a, b, e);
+                       oneshot_lds_bytes<B_MC>(d.K < ONE_KMAX ? d.K : ONE_KMAX), st, d, a, b, e);
     return check_launch(what);
 }
 
@@ -281,7 +281,7 @@ static int launch_rows(const GemmDims& d, const AL& a, const BL& b, const Epi& e
     const int tm = (d.M + 127) / 128;
     if (d.M >= 32 * num_cus() && d.N <= 4 * STRIP_BN) return launch_strip<B_MC, EK>(d, a, b, e, st, what);
     if constexpr (std::is_same<AL, KcRows>::value)
-        if (d.K <= ONE_KMAX && d.K % 4 == 0 &&
+        if (d.K <= 4 * ONE_KMAX && d.K % 4 == 0 &&
             ((d.M + ONE_BM - 1) / ONE_BM) * ((d.N + ONE_BN - 1) / ONE_BN) <= num_cus())     // one round of whole-CU blocks
             return launch_oneshot<B_MC, EK>(d, a, b, e, st, what);
     if (tm * ((d.N + 127) / 128) < 128) {         // few row tiles (user / category side): 64-row tiles fill more CUs

@@ -1036,3 +1036,26 @@ def test_attn_fold_entry_points(D, A):
     torch.cuda.synchronize()
     for got, leaf, name in zip(init, leaves, ("Wo", "bo", "Wl", "bl", "W1", "b1")):
         _close(got.cpu() - 0.25, leaf.grad, rtol=5e-6, what="d" + name)
+
+
+@pytest.mark.parametrize("M,N,Kd", [(200, 256, 768), (1300, 256, 768), (70, 96, 320), (64, 64, 1000), (130, 200, 260)])
+def test_small_row_products_with_long_reductions(M, N, Kd):
+    """A few hundred / thousand rows with a reduction longer than 256 (the NRMS user side's in-projection data gradient: K = 3 D):
+    the one-shot kernel walks the reduction in 256-wide chunks.  NT (linear_fwd) and NN (linear_bwd_data, with accumulate) against
+    float64."""
+    from legommenders_amd import kernels as K
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + N + Kd)
+    x = torch.randn(M, Kd, generator=g).to(dev)
+    W = (torch.randn(N, Kd, generator=g) * 0.1).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    y = K.linear_fwd(x, W, b, act=0)
+    _close(y.cpu(), x.double().cpu() @ W.double().cpu().t() + b.double().cpu(), rtol=2e-6, what="NT")
+    gy = torch.randn(M, Kd, generator=g).to(dev)                       # reduce over Kd: dx[M, N] = gy[M, Kd] . Wt[Kd, N]
+    Wt = (torch.randn(Kd, N, generator=g) * 0.1).to(dev)
+    dx = K.linear_bwd_data(gy, Wt)
+    ref = gy.double().cpu() @ Wt.double().cpu()
+    _close(dx.cpu(), ref, rtol=2e-6, what="NN")
+    acc = torch.full((M, N), 0.5, device=dev)
+    K.linear_bwd_data(gy, Wt, accumulate_into=acc)
+    _close(acc.cpu(), ref + 0.5, rtol=2e-6, what="NN accumulate")
