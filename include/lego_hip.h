@@ -191,13 +191,19 @@ int lego_relu_bwd(float* g, int ldg, const float* ref, int ldr, int rows, int wi
 /* ---- a8: nn.MultiheadAttention core of AttentionOperator (model/operators/attention_operator.py:49-55)
  * over ragged segments: per (segment, head) softmax(q k^T / sqrt(hd)) v with all keys of the segment
  * live (pads are not rows).  qkv rows are [q | k | v] (3*D) from lego_linear_fwd with in_proj. */
+/* `part`: which segments a call handles -- all, only those of <= 32 rows, or only the longer ones.  The two groups run as separate
+ * launches that touch disjoint rows; a caller may put them on two streams (the long-segment launch is latency-bound and hides
+ * behind the HBM-bound short-segment one). */
+#define LEGO_MHSA_ALL 0
+#define LEGO_MHSA_SHORT 1
+#define LEGO_MHSA_LONG 2
 int lego_mhsa_core_fwd(const float* qkv, int ldq, const int32_t* seg_off, int n_cap, const int32_t* n_dyn,
                        int D, int heads, float* out, int ldo, float* probs /*[rows,heads,Lmax] saved*/,
-                       int Lmax, const lego_dropout* drop, int rows_cap, void* stream);
+                       int Lmax, const lego_dropout* drop, int rows_cap, int part, void* stream);
 int lego_mhsa_core_bwd(const float* qkv, int ldq, const int32_t* seg_off, int n_cap, const int32_t* n_dyn,
                        int D, int heads, const float* gout, int ldgo, const float* probs, int Lmax,
                        const lego_dropout* drop, int rows_cap, float* gqkv, int ldgq,
-                       float* colsum /*nullable [3*D]: += column sums of gqkv = the in_proj_bias gradient*/, void* stream);
+                       float* colsum /*nullable [3*D]: += column sums of gqkv = the in_proj_bias gradient*/, int part, void* stream);
 
 /* ---- a8 (engine route): the two affine layers behind the attention core -- nn.MultiheadAttention's out_proj and
  * AttentionOperator.linear (attention_operator.py:49-56, nothing between them) -- and the hidden layer of the additive attention
@@ -222,6 +228,15 @@ int lego_attn_fold_grads(const float* Wo, const float* bo, const float* Wl, cons
  * is run on d(qkv) instead of d(E): sum_r dE[r] = (sum_r dqkv[r]) . W_in. */
 int lego_small_rows_matmul_add(const float* S_a, int rows_a, float* out_a, int ld_a, const float* S_b, int rows_b, float* out_b,
                                int ld_b, const float* W, int K, int N, void* stream);
+
+/* NRMS user head of a TRAINING step in one launch (engine route, folded attention block): user vector from the pooled attention
+ * output (u = Wc p + bc: attention_operator.py:52-56 with the two affine layers folded), DotPredictor over the C candidates
+ * (dot_predictor.py:7-10), CrossEntropy with label 0 (legommender.py:254,263), and their backward: loss += mean CE,
+ * d_user[b] = sum_c g_c item_c, d_items[b*C + c] = g_c u_b (written), d_pooled = Wc^T d_user, g = (softmax - e_0) * gscale. */
+int lego_nrms_user_head_train(const float* pooled, int ldp, const float* Wc, const float* bc, const float* items, int ldi,
+                              int B, int C, int D, float gscale /* dloss / B */, float* user, int ldu, float* scores /*[B,C]*/,
+                              float* loss /*[1] += mean, nullable*/, float* d_user, int lddu, float* d_items, int lddi,
+                              float* d_pooled, int lddp, void* stream);
 
 /* ---- a13: torch.optim.Adam (defaults, base_lego.py:201-204) over one flat fp32 buffer;
  * grad is multiplied by grad_scale first (1/world after the RCCL all-reduce). step is 1-based.

@@ -35,6 +35,7 @@ SIGNATURES = {
     "lego_nrms_special_grads": [P, I, P, P, P, I, I, P, P, I, I, P],
     "lego_mask_dropout_rows": [P, I, I, P, I, P, P, P, P],
     "lego_small_rows_matmul_add": [P, I, P, I, P, I, P, I, P, I, I, P],
+    "lego_nrms_user_head_train": [P, I, P, P, P, I, I, I, I, F, P, I, P, P, P, I, P, I, P, I, P],
     "lego_attn_fold_prepare": [P, P, P, P, P, P, P, P, P, P, I, I, P],
     "lego_attn_fold_grads": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P],
     "lego_scatter_add_rows": [P, I, I, I, P, I, P, P, I, P],
@@ -59,8 +60,8 @@ SIGNATURES = {
     "lego_additive_pool_bwd": [P, I, P, I, P, P, P, I, P, I, I, P, I, P, P, I, P, P, P, P],
     "lego_dot_ce_fwd": [P, I, P, I, I, I, I, P, P, P],
     "lego_dot_ce_bwd": [P, I, P, I, P, I, I, I, F, P, I, P, I, P],
-    "lego_mhsa_core_fwd": [P, I, P, I, P, I, I, P, I, P, I, P, I, P],
-    "lego_mhsa_core_bwd": [P, I, P, I, P, I, I, P, I, P, I, P, I, P, I, P, P],
+    "lego_mhsa_core_fwd": [P, I, P, I, P, I, I, P, I, P, I, P, I, I, P],
+    "lego_mhsa_core_bwd": [P, I, P, I, P, I, I, P, I, P, I, P, I, P, I, P, I, P],
     "lego_user_tower_train": [P, I, P, I, P, P, I, I, I, I, I, F, P, P, P, P, I, P, P, P],
     "lego_rowdot_fwd": [P, I, P, I, I, I, P, P],
     "lego_rowdot_bwd": [P, I, P, I, P, I, I, P, I, P, I, P],

@@ -157,3 +157,120 @@ extern "C" int lego_small_rows_matmul_add(const float* S_a, int rows_a, float* o
     if (L.n_gemm == 0) return 0;
     return launch_level(L, (hipStream_t)stream, "lego_small_rows_matmul_add");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// NRMS user "head" of a training step in one launch (fold level 2): the user vector from the pooled attention output, the dot
+// predictor, CrossEntropy(label 0) and their backward down to the pooled vector --
+//   u = Wc p + bc;  s_c = u . item_c;  loss += CE(s)[0] / B;  g = (softmax(s) - e_0) gscale;
+//   d_user = sum_c g_c item_c;  d_item_c = g_c u;  d_pooled = Wc^T d_user
+// (attention_operator.py:52-56 folded, dot_predictor.py:7-10, legommender.py:254,263 and autograd) -- five dependent launches of
+// ~9 us each on the step's critical path before.  One workgroup per impression, waves over the rows of Wc with 16-byte coalesced
+// loads; Wc is read twice per workgroup from L2.
+namespace lego {
+
+constexpr int kHeadMaxD = 1024, kHeadMaxC = 64;
+
+constexpr int HR = 16;         // rows of Wc whose 16-byte loads a wave has in flight together
+
+__global__ __launch_bounds__(256) void nrms_user_head_kernel(
+    const float* __restrict__ pooled, int ldp, const float* __restrict__ Wc, const float* __restrict__ bc,
+    const float* __restrict__ items, int ldi, int B, int C, int D, float gscale,
+    float* __restrict__ user, int ldu, float* __restrict__ scores, float* loss,
+    float* __restrict__ d_user, int lddu, float* __restrict__ d_items, int lddi, float* __restrict__ d_pooled, int lddp) {
+    __shared__ __attribute__((aligned(16))) float p[kHeadMaxD];
+    __shared__ float u[kHeadMaxD], du[kHeadMaxD], s[kHeadMaxC], g[kHeadMaxC];
+    static_assert(kHeadMaxD >= 4 * 256, "p doubles as the [4][256] fold buffer of the last stage");
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int k = tid; k < D; k += 256) p[k] = pooled[(size_t)b * ldp + k];
+    __syncthreads();
+    // u[n] = Wc[n, :] . p + bc[n]: one wave per row, lanes over k; HR rows' loads in flight per wave (one row at a time is one
+    // memory round trip per row: 64 of them in a row per wave)
+    for (int n0 = wave * HR; n0 < D; n0 += 4 * HR) {
+        float acc[HR];
+#pragma unroll
+        for (int i = 0; i < HR; ++i) acc[i] = 0.f;
+        for (int k = 4 * lane; k < D; k += 256) {
+            f32x4 w[HR];
+#pragma unroll
+            for (int i = 0; i < HR; ++i) w[i] = *reinterpret_cast<const f32x4*>(Wc + (size_t)min(n0 + i, D - 1) * D + k);
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(p + k);
+#pragma unroll
+            for (int i = 0; i < HR; ++i) acc[i] += w[i].x * pv.x + w[i].y * pv.y + w[i].z * pv.z + w[i].w * pv.w;
+        }
+#pragma unroll
+        for (int i = 0; i < HR; ++i) {
+            const float v = wave_sum(acc[i]);
+            const int n = n0 + i;
+            if (lane == 0 && n < D) { const float x = v + bc[n]; u[n] = x; user[(size_t)b * ldu + n] = x; }
+        }
+    }
+    __syncthreads();
+    for (int c = wave; c < C; c += 4) {
+        const float* it = items + (size_t)(b * C + c) * ldi;
+        float acc = 0.f;
+        for (int k = lane; k < D; k += 64) acc += u[k] * it[k];
+        acc = wave_sum(acc);
+        if (lane == 0) { s[c] = acc; scores[b * C + c] = acc; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float mx = -INFINITY, se = 0.f;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, s[c]);
+        for (int c = 0; c < C; ++c) se += expf(s[c] - mx);
+        if (loss != nullptr) atomicAdd(loss, (logf(se) + mx - s[0]) / (float)B);
+        for (int c = 0; c < C; ++c) g[c] = (expf(s[c] - mx) / se - (c == 0 ? 1.f : 0.f)) * gscale;
+    }
+    __syncthreads();
+    for (int n = tid; n < D; n += 256) {
+        float acc = 0.f;
+        const float un = u[n];
+        for (int c = 0; c < C; ++c) {
+            acc += g[c] * items[(size_t)(b * C + c) * ldi + n];
+            d_items[(size_t)(b * C + c) * lddi + n] = g[c] * un;
+        }
+        du[n] = acc;
+        d_user[(size_t)b * lddu + n] = acc;
+    }
+    __syncthreads();
+    // d_pooled[k] = sum_n du[n] Wc[n][k]: lanes over k (coalesced rows of Wc, 4 columns each), the four waves split n and fold
+    // through LDS (p is free by now); HR rows' loads in flight
+    for (int k0 = 0; k0 < D; k0 += 256) {
+        const int k = k0 + 4 * lane;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (k < D) {
+            for (int n0 = wave * HR; n0 < D; n0 += 4 * HR) {
+                f32x4 w[HR];
+#pragma unroll
+                for (int i = 0; i < HR; ++i) w[i] = *reinterpret_cast<const f32x4*>(Wc + (size_t)min(n0 + i, D - 1) * D + k);
+#pragma unroll
+                for (int i = 0; i < HR; ++i) acc += (n0 + i < D ? du[n0 + i] : 0.f) * w[i];
+            }
+        }
+        __syncthreads();
+        float* red = p;                                     // [4][256]
+        if (4 * 256 <= kHeadMaxD) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[wave * 256 + 4 * lane + j] = acc[j];
+        }
+        __syncthreads();
+        if (wave == 0 && k < D) {
+            f32x4 t;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = (red[4 * lane + j] + red[256 + 4 * lane + j]) + (red[512 + 4 * lane + j] + red[768 + 4 * lane + j]);
+            *reinterpret_cast<f32x4*>(d_pooled + (size_t)b * lddp + k) = t;
+        }
+    }
+}
+
+}  // namespace lego
+
+extern "C" int lego_nrms_user_head_train(const float* pooled, int ldp, const float* Wc, const float* bc, const float* items, int ldi,
+                                         int B, int C, int D, float gscale, float* user, int ldu, float* scores, float* loss,
+                                         float* d_user, int lddu, float* d_items, int lddi, float* d_pooled, int lddp, void* stream) {
+    LEGO_REQUIRE(D > 0 && (D & 3) == 0 && D <= kHeadMaxD && C > 0 && C <= kHeadMaxC && (lddp & 3) == 0,
+                 "lego_nrms_user_head_train: D=%d (multiple of 4, <= %d), C=%d (<= %d), lddp=%d", D, kHeadMaxD, C, kHeadMaxC, lddp);
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(nrms_user_head_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pooled, ldp, Wc, bc, items, ldi, B, C, D, gscale,
+                       user, ldu, scores, loss, d_user, lddu, d_items, lddi, d_pooled, lddp);
+    return check_launch("lego_nrms_user_head_train");
+}

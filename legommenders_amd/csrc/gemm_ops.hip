@@ -282,7 +282,8 @@ static int launch_rows(const GemmDims& d, const AL& a, const BL& b, const Epi& e
     if (d.M >= 32 * num_cus() && d.N <= 4 * STRIP_BN) return launch_strip<B_MC, EK>(d, a, b, e, st, what);
     if constexpr (std::is_same<AL, KcRows>::value)
         if (d.K <= 4 * ONE_KMAX && d.K % 4 == 0 &&
-            ((d.M + ONE_BM - 1) / ONE_BM) * ((d.N + ONE_BN - 1) / ONE_BN) <= num_cus())     // one round of whole-CU blocks
+            ((d.M + ONE_BM - 1) / ONE_BM) * ((d.N + ONE_BN - 1) / ONE_BN) <= 3 * num_cus())  // few rounds of whole-CU blocks by
+                                                                                              // CAPACITY: the user side fills 40 %
             return launch_oneshot<B_MC, EK>(d, a, b, e, st, what);
     if (tm * ((d.N + 127) / 128) < 128) {         // few row tiles (user / category side): 64-row tiles fill more CUs
         if (d.N > 64) return launch<C64x128, false, B_MC, EK>(d, a, b, e, (d.M + 63) / 64, (d.N + 127) / 128, 1, st, what);

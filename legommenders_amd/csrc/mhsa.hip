@@ -371,7 +371,7 @@ using namespace lego;
 
 extern "C" int lego_mhsa_core_fwd(const float* qkv, int ldq, const int32_t* seg_off, int n_cap, const int32_t* n_dyn,
                                   int D, int heads, float* out, int ldo, float* probs, int Lmax,
-                                  const lego_dropout* drop, int rows_cap, void* stream) {
+                                  const lego_dropout* drop, int rows_cap, int part, void* stream) {
     LEGO_REQUIRE(heads > 0 && D % heads == 0, "lego_mhsa_core_fwd: D=%d not divisible by heads=%d", D, heads);
     LEGO_REQUIRE(Lmax <= kMaxL, "lego_mhsa_core_fwd: Lmax=%d exceeds %d", Lmax, kMaxL);
     LEGO_REQUIRE((ldq & 3) == 0 && (D & 3) == 0, "lego_mhsa_core_fwd: ldq=%d and D=%d must be multiples of 4", ldq, D);
@@ -381,8 +381,9 @@ extern "C" int lego_mhsa_core_fwd(const float* qkv, int ldq, const int32_t* seg_
     const Dropout dr = to_drop(drop);
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(HD) do { \
-        hipLaunchKernelGGL((mhsa_fwd_kernel<HD, 1>), dim3(short_grid(n_cap, heads)), dim3(64), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, out, ldo, probs, Lmax, dr); \
-        if (Lmax > 32) \
+        if (part != LEGO_MHSA_LONG) \
+            hipLaunchKernelGGL((mhsa_fwd_kernel<HD, 1>), dim3(short_grid(n_cap, heads)), dim3(64), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, out, ldo, probs, Lmax, dr); \
+        if (Lmax > 32 && part != LEGO_MHSA_SHORT) \
             hipLaunchKernelGGL((mhsa_fwd_kernel<HD, 2>), dim3(long_grid(n_cap, heads)), dim3(128), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, out, ldo, probs, Lmax, dr); \
     } while (0)
     switch (hd) {
@@ -398,7 +399,7 @@ extern "C" int lego_mhsa_core_fwd(const float* qkv, int ldq, const int32_t* seg_
 
 extern "C" int lego_mhsa_core_bwd(const float* qkv, int ldq, const int32_t* seg_off, int n_cap, const int32_t* n_dyn,
                                   int D, int heads, const float* gout, int ldgo, const float* probs, int Lmax,
-                                  const lego_dropout* drop, int rows_cap, float* gqkv, int ldgq, float* colsum, void* stream) {
+                                  const lego_dropout* drop, int rows_cap, float* gqkv, int ldgq, float* colsum, int part, void* stream) {
     LEGO_REQUIRE(heads > 0 && D % heads == 0, "lego_mhsa_core_bwd: D=%d not divisible by heads=%d", D, heads);
     LEGO_REQUIRE(Lmax <= kMaxL, "lego_mhsa_core_bwd: Lmax=%d exceeds %d", Lmax, kMaxL);
     LEGO_REQUIRE((ldq & 3) == 0 && (ldgo & 3) == 0 && (D & 3) == 0, "lego_mhsa_core_bwd: ldq=%d, ldgo=%d and D=%d must be multiples of 4", ldq, ldgo, D);
@@ -409,8 +410,9 @@ extern "C" int lego_mhsa_core_bwd(const float* qkv, int ldq, const int32_t* seg_
     (void)rows_cap;
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(HD) do { \
-        hipLaunchKernelGGL((mhsa_bwd_kernel<HD, 1>), dim3(short_grid(n_cap, heads)), dim3(64), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, gout, ldgo, probs, Lmax, ks, gqkv, ldgq, colsum); \
-        if (Lmax > 32) \
+        if (part != LEGO_MHSA_LONG) \
+            hipLaunchKernelGGL((mhsa_bwd_kernel<HD, 1>), dim3(short_grid(n_cap, heads)), dim3(64), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, gout, ldgo, probs, Lmax, ks, gqkv, ldgq, colsum); \
+        if (Lmax > 32 && part != LEGO_MHSA_SHORT) \
             hipLaunchKernelGGL((mhsa_bwd_kernel<HD, 2>), dim3(long_grid(n_cap, heads)), dim3(128), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, gout, ldgo, probs, Lmax, ks, gqkv, ldgq, colsum); \
     } while (0)
     switch (hd) {

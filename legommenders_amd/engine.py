@@ -632,7 +632,7 @@ class NrmsEngine(_Base):
                     pooled=self._f(n_seg, D), d_pooled=self._f(n_seg, D))
 
     # AttentionOperator.forward over ragged segments
-    def _att_fwd(self, pre, ws, x_ptr, rows_dyn, seg_off, n_cap, n_dyn, out, site, training, st):
+    def _att_fwd(self, pre, ws, x_ptr, rows_dyn, seg_off, n_cap, n_dyn, out, site, training, st, head=False):
         P, D, A = self.P, self.D, self.A
         rows = ws["rows"]
         m = torch.cuda.current_stream()          # == st; tagged launches are HIP-event timed on it when bench.py asks
@@ -644,8 +644,9 @@ class NrmsEngine(_Base):
         self.kk(m, "qkv_fwd_" + tg, "lego_linear_fwd", x_ptr, D, _ptr(P[pre + "multi_head_attention.in_proj_weight"]), D,
                 _ptr(P[pre + "multi_head_attention.in_proj_bias"]), _ptr(ws["qkv"]), 3 * D, rows, rows_dyn, 3 * D, D, 0,
                 None, None, None, None)
-        self.kk(m, "mhsa_core_fwd_" + tg, "lego_mhsa_core_fwd", _ptr(ws["qkv"]), 3 * D, _ptr(seg_off), n_cap, n_dyn, D, self.heads,
+        core = ("lego_mhsa_core_fwd", _ptr(ws["qkv"]), 3 * D, _ptr(seg_off), n_cap, n_dyn, D, self.heads,
                 _ptr(ws["o"]), D, _ptr(ws["probs"]), ws["Lmax"], self.drop(self.p_att, site, training), rows)
+        self.kk(m, "mhsa_core_fwd_" + tg, *core, 0)
         if self.fold and self._fold_ev is not None:          # the folded weights come from the side stream (_prepare_folds)
             m.wait_event(self._fold_ev)
             self._fold_ev = None
@@ -654,6 +655,12 @@ class NrmsEngine(_Base):
                     rows, rows_dyn, A, D, 2, None, None, None, None)
             call("lego_additive_pool_fwd", _ptr(ws["t"]), A, _ptr(ws["o"]), D, _ptr(w2), _ptr(seg_off), None, None, n_cap, n_dyn, D, A,
                  _ptr(ws["pooled"]), D, _ptr(ws["wrow"]), st)
+            if head:
+                # the user vector, the dot predictor, the loss and their backward down to d(pooled) in ONE launch (training steps)
+                call("lego_nrms_user_head_train", _ptr(ws["pooled"]), D, _ptr(ws["Wc"]), _ptr(ws["bc"]), _ptr(self.items), D,
+                     self.nb, self.C, D, 1.0 / self.nb, _ptr(out), D, _ptr(self.scores), _ptr(self.loss), _ptr(self.d_user), D,
+                     _ptr(self.d_items), D, _ptr(ws["d_pooled"]), D, st)
+                return
             call("lego_linear_fwd", _ptr(ws["pooled"]), D, _ptr(ws["Wc"]), D, _ptr(ws["bc"]), _ptr(out), D, n_cap, n_dyn, D, D, 0,
                  None, None, None, None, st)
             return
@@ -706,7 +713,7 @@ class NrmsEngine(_Base):
         data-gradient chain (LEGO_SERIAL=1: everything on the current stream)"""
         if getattr(self, "_sw", None) is None:
             self._sw = shared_stream(self.dev, "side0")
-            self._sev = [torch.cuda.Event() for _ in range(8)]
+            self._sev = [torch.cuda.Event() for _ in range(12)]
         m = torch.cuda.current_stream()
         return m, (m if os.environ.get("LEGO_SERIAL") == "1" else self._sw)
 
@@ -722,10 +729,11 @@ class NrmsEngine(_Base):
             self._att_bwd_folded(pre, ws, G, rows_dyn, seg_off, n_cap, n_dyn, gout, st, ev, m, sw, sp)
         else:
             self._att_bwd_head(pre, ws, G, rows_dyn, seg_off, n_cap, n_dyn, gout, st, ev, m, sw, sp)
-        self.kk(torch.cuda.current_stream(), "mhsa_core_bwd_" + pre[:4], "lego_mhsa_core_bwd", _ptr(ws["qkv"]), 3 * D, _ptr(seg_off),
+        core = ("lego_mhsa_core_bwd", _ptr(ws["qkv"]), 3 * D, _ptr(seg_off),
                 n_cap, n_dyn, D, self.heads, _ptr(ws["d_o"]), D, _ptr(ws["probs"]), ws["Lmax"],
                 self.drop(self.p_att, site, training), rows, _ptr(ws["d_qkv"]), 3 * D,
                 _ptr(G[pre + "multi_head_attention.in_proj_bias"]))      # bias gradient = column sums of d_qkv, fused
+        self.kk(m, "mhsa_core_bwd_" + pre[:4], *core, 0)
         if sw is not m:
             ev[1].record(m)
 
@@ -768,8 +776,9 @@ class NrmsEngine(_Base):
         rows = ws["rows"]
         W1 = P[pre + "additive_attention.encoder.0.weight"]
         gw2, gW1, gb1 = (G[pre + "additive_attention.encoder." + k] for k in ("2.weight", "0.weight", "0.bias"))
-        call("lego_linear_bwd_data", _ptr(gout), D, _ptr(ws["Wc"]), D, _ptr(ws["d_pooled"]), D, n_cap, n_dyn, D, D, 0,
-             None, 0, 1.0, None, None, None, None, None, st)
+        if not (pre == "user_op." and self._have_d_pooled):
+            call("lego_linear_bwd_data", _ptr(gout), D, _ptr(ws["Wc"]), D, _ptr(ws["d_pooled"]), D, n_cap, n_dyn, D, D, 0,
+                 None, 0, 1.0, None, None, None, None, None, st)
         call("lego_additive_pool_bwd", _ptr(ws["t"]), A, _ptr(ws["o"]), D, _ptr(P[pre + "additive_attention.encoder.2.weight"]),
              _ptr(seg_off), None, n_cap, n_dyn, D, A, _ptr(ws["d_pooled"]), D, _ptr(ws["wrow"]), _ptr(ws["d_o"]), D,
              _ptr(gw2), _ptr(ws["sp"]), _ptr(self._pool_scratch(A, pre)), st)
@@ -859,10 +868,12 @@ class NrmsEngine(_Base):
         self._forward_items(training)
         if neck_ev is not None:
             neck_ev.record(torch.cuda.current_stream())
-        self._forward_users(training)
         self.loss.zero_()
-        call("lego_dot_ce_fwd", _ptr(self.user), D, _ptr(self.items), D, B, C, D, _ptr(self.scores),
-             _ptr(self.loss) if with_loss else None, st)
+        self._head_done = self.fold == 2 and training and with_loss
+        self._forward_users(training, head=self._head_done)
+        if not self._head_done:
+            call("lego_dot_ce_fwd", _ptr(self.user), D, _ptr(self.items), D, B, C, D, _ptr(self.scores),
+                 _ptr(self.loss) if with_loss else None, st)
         self.step += 1 if training else 0
         return self.scores, self.loss
 
@@ -903,12 +914,15 @@ class NrmsEngine(_Base):
         self._att_fwd("item_op.", self.item_ws, _ptr(self.E), self.cnt(0), self.seg_off, self.NIc, self.cnt(1),
                       self.items, SITE_ITEM_ATT, training, st)
 
-    def _forward_users(self, training):
+    _head_done = False
+    _have_d_pooled = False
+
+    def _forward_users(self, training, head=False):
         if not self._folds_fresh:                # evaluation caches call this without a preceding _forward_items
             self._prepare_folds()
         self._folds_fresh = False
         self._att_fwd("user_op.", self.user_ws, _ptr(self.items, self.BC * self.D), self.cnt(3), self.hist_off, self.nb, None,
-                      self.user, SITE_USER_ATT, training, _stream())
+                      self.user, SITE_USER_ATT, training, _stream(), head=head)
 
     def backward(self, G, gloss: float = 1.0):
         P, B, C, S, D = self.P, self.nb, self.C, self.S, self.D
@@ -917,8 +931,12 @@ class NrmsEngine(_Base):
         step_save = self.step
         if training:
             self.step -= 1
-        call("lego_dot_ce_bwd", _ptr(self.user), D, _ptr(self.items), D, _ptr(self.scores), B, C, D,
-             float(gloss) / B, _ptr(self.d_user), D, _ptr(self.d_items), D, st)
+        head = self._head_done and float(gloss) == 1.0     # forward's fused head already holds d_user, d_items (candidates), d_pooled
+        self._head_done = False
+        if not head:
+            call("lego_dot_ce_bwd", _ptr(self.user), D, _ptr(self.items), D, _ptr(self.scores), B, C, D,
+                 float(gloss) / B, _ptr(self.d_user), D, _ptr(self.d_items), D, st)
+        self._have_d_pooled = head
         m, sw = self._side()
         sev = self._sev if sw is not m else [None] * 6
         self._deferred = []

@@ -895,11 +895,11 @@ def test_mhsa_core_ragged_segments_with_dropout(hd, heads, p):
     out = torch.full((R, D), float("nan"), device=dev)
     probs = torch.zeros(R, heads, Lmax, device=dev)
     drop = (p, 99, 3) if p > 0 else None
-    call("lego_mhsa_core_fwd", _ptr(qkv), 3 * D, _ptr(seg), n, None, D, heads, _ptr(out), D, _ptr(probs), Lmax, _drop(drop), R, _stream())
+    call("lego_mhsa_core_fwd", _ptr(qkv), 3 * D, _ptr(seg), n, None, D, heads, _ptr(out), D, _ptr(probs), Lmax, _drop(drop), R, 0, _stream())
     gqkv = torch.full((R, 3 * D), float("nan"), device=dev)
     colsum = torch.zeros(3 * D, device=dev)
     call("lego_mhsa_core_bwd", _ptr(qkv), 3 * D, _ptr(seg), n, None, D, heads, _ptr(go), D, _ptr(probs), Lmax, _drop(drop), R,
-         _ptr(gqkv), 3 * D, _ptr(colsum), _stream())
+         _ptr(gqkv), 3 * D, _ptr(colsum), 0, _stream())
     torch.cuda.synchronize()
     pr, q64, g64 = probs.cpu().double().reshape(-1), qkv.cpu().double(), go.cpu().double()
     kept = total = 0
