@@ -170,22 +170,24 @@ namespace lego {
 
 constexpr int kHeadMaxD = 1024, kHeadMaxC = 64;
 
-constexpr int HR = 16;         // rows of Wc whose 16-byte loads a wave has in flight together
+constexpr int HR = 8;          // rows of Wc whose 16-byte loads a wave has in flight together (16 spill at 1024 threads)
+constexpr int HW = 16;         // waves per workgroup: at D = 256 every wave has two batches of HR rows per pass over Wc
 
-__global__ __launch_bounds__(256) void nrms_user_head_kernel(
+__global__ __launch_bounds__(64 * HW) void nrms_user_head_kernel(
     const float* __restrict__ pooled, int ldp, const float* __restrict__ Wc, const float* __restrict__ bc,
     const float* __restrict__ items, int ldi, int B, int C, int D, float gscale,
     float* __restrict__ user, int ldu, float* __restrict__ scores, float* loss,
     float* __restrict__ d_user, int lddu, float* __restrict__ d_items, int lddi, float* __restrict__ d_pooled, int lddp) {
     __shared__ __attribute__((aligned(16))) float p[kHeadMaxD];
+    __shared__ __attribute__((aligned(16))) float red[HW][256];
     __shared__ float u[kHeadMaxD], du[kHeadMaxD], s[kHeadMaxC], g[kHeadMaxC];
-    static_assert(kHeadMaxD >= 4 * 256, "p doubles as the [4][256] fold buffer of the last stage");
+    constexpr int NT = 64 * HW;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int k = tid; k < D; k += 256) p[k] = pooled[(size_t)b * ldp + k];
+    for (int k = tid; k < D; k += NT) p[k] = pooled[(size_t)b * ldp + k];
     __syncthreads();
     // u[n] = Wc[n, :] . p + bc[n]: one wave per row, lanes over k; HR rows' loads in flight per wave (one row at a time is one
-    // memory round trip per row: 64 of them in a row per wave)
-    for (int n0 = wave * HR; n0 < D; n0 += 4 * HR) {
+    // memory round trip per row)
+    for (int n0 = wave * HR; n0 < D; n0 += HW * HR) {
         float acc[HR];
 #pragma unroll
         for (int i = 0; i < HR; ++i) acc[i] = 0.f;
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(256) void nrms_user_head_kernel(
         }
     }
     __syncthreads();
-    for (int c = wave; c < C; c += 4) {
+    for (int c = wave; c < C; c += HW) {
         const float* it = items + (size_t)(b * C + c) * ldi;
         float acc = 0.f;
         for (int k = lane; k < D; k += 64) acc += u[k] * it[k];
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(256) void nrms_user_head_kernel(
         for (int c = 0; c < C; ++c) g[c] = (expf(s[c] - mx) / se - (c == 0 ? 1.f : 0.f)) * gscale;
     }
     __syncthreads();
-    for (int n = tid; n < D; n += 256) {
+    for (int n = tid; n < D; n += NT) {
         float acc = 0.f;
         const float un = u[n];
         for (int c = 0; c < C; ++c) {
@@ -232,13 +234,12 @@ __global__ __launch_bounds__(256) void nrms_user_head_kernel(
         d_user[(size_t)b * lddu + n] = acc;
     }
     __syncthreads();
-    // d_pooled[k] = sum_n du[n] Wc[n][k]: lanes over k (coalesced rows of Wc, 4 columns each), the four waves split n and fold
-    // through LDS (p is free by now); HR rows' loads in flight
+    // d_pooled[k] = sum_n du[n] Wc[n][k]: lanes over k (coalesced rows of Wc, 4 columns each), the waves split n and fold through LDS
     for (int k0 = 0; k0 < D; k0 += 256) {
         const int k = k0 + 4 * lane;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (k < D) {
-            for (int n0 = wave * HR; n0 < D; n0 += 4 * HR) {
+            for (int n0 = wave * HR; n0 < D; n0 += HW * HR) {
                 f32x4 w[HR];
 #pragma unroll
                 for (int i = 0; i < HR; ++i) w[i] = *reinterpret_cast<const f32x4*>(Wc + (size_t)min(n0 + i, D - 1) * D + k);
@@ -246,17 +247,13 @@ __global__ __launch_bounds__(256) void nrms_user_head_kernel(
                 for (int i = 0; i < HR; ++i) acc += (n0 + i < D ? du[n0 + i] : 0.f) * w[i];
             }
         }
-        __syncthreads();
-        float* red = p;                                     // [4][256]
-        if (4 * 256 <= kHeadMaxD) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) red[wave * 256 + 4 * lane + j] = acc[j];
-        }
+        if (k0 > 0) __syncthreads();
+        *reinterpret_cast<f32x4*>(&red[wave][4 * lane]) = acc;
         __syncthreads();
         if (wave == 0 && k < D) {
-            f32x4 t;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) t[j] = (red[4 * lane + j] + red[256 + 4 * lane + j]) + (red[512 + 4 * lane + j] + red[768 + 4 * lane + j]);
+            for (int w = 0; w < HW; ++w) t += *reinterpret_cast<const f32x4*>(&red[w][4 * lane]);
             *reinterpret_cast<f32x4*>(d_pooled + (size_t)b * lddp + k) = t;
         }
     }
@@ -270,7 +267,7 @@ extern "C" int lego_nrms_user_head_train(const float* pooled, int ldp, const flo
     LEGO_REQUIRE(D > 0 && (D & 3) == 0 && D <= kHeadMaxD && C > 0 && C <= kHeadMaxC && (lddp & 3) == 0,
                  "lego_nrms_user_head_train: D=%d (multiple of 4, <= %d), C=%d (<= %d), lddp=%d", D, kHeadMaxD, C, kHeadMaxC, lddp);
     if (B <= 0) return 0;
-    hipLaunchKernelGGL(nrms_user_head_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pooled, ldp, Wc, bc, items, ldi, B, C, D, gscale,
+    hipLaunchKernelGGL(nrms_user_head_kernel, dim3(B), dim3(64 * HW), 0, (hipStream_t)stream, pooled, ldp, Wc, bc, items, ldi, B, C, D, gscale,
                        user, ldu, scores, loss, d_user, lddu, d_items, lddi, d_pooled, lddp);
     return check_launch("lego_nrms_user_head_train");
 }

@@ -699,6 +699,9 @@ class NrmsEngine(_Base):
             call("lego_attn_fold_prepare", _ptr(Wo), _ptr(bo), _ptr(Wl), _ptr(bl), _ptr(W1) if two else None, _ptr(b1) if two else None,
                  _ptr(ws["Wc"]), _ptr(ws["bc"]), _ptr(ws["W2"]) if two else None, _ptr(ws["b2"]) if two else None, D, A if two else 0, sp)
         if sw is not m:
+            with torch.cuda.stream(sw):                  # the loss accumulator too (a fill on the main stream costs it the launch
+                self.loss.zero_()                        # and a gap in front of the user head); ordered by the same event
+            self._loss_zeroed = True
             self._fold_ev = self._sev[6]
             self._fold_ev.record(sw)
 
@@ -868,7 +871,9 @@ class NrmsEngine(_Base):
         self._forward_items(training)
         if neck_ev is not None:
             neck_ev.record(torch.cuda.current_stream())
-        self.loss.zero_()
+        if not self._loss_zeroed:
+            self.loss.zero_()
+        self._loss_zeroed = False
         self._head_done = self.fold == 2 and training and with_loss
         self._forward_users(training, head=self._head_done)
         if not self._head_done:
@@ -916,6 +921,7 @@ class NrmsEngine(_Base):
 
     _head_done = False
     _have_d_pooled = False
+    _loss_zeroed = False
 
     def _forward_users(self, training, head=False):
         if not self._folds_fresh:                # evaluation caches call this without a preceding _forward_items
