@@ -622,6 +622,28 @@ class NrmsEngine(_Base):
         self.item_ws = self._att_ws(self.Rc, self.L, max(self.NIc, 1))
         self.user_ws = self._att_ws(B * S, S, B)
 
+    # with the plan (TrainStep's prefetch stream): the decoded index rows and, GloVe variant, the gathered token rows X -- the table is
+    # frozen, so the 20 us gather and the 6 us decode of batch N+1 run beside batch N instead of at the head of its own step
+    _PLAN_FIELDS = _Base._PLAN_FIELDS + ("idx_tok", "idx_spec", "idx_cat", "tokinfo")
+
+    def enable_plan_slots(self):
+        if getattr(self, "_slots", None) is None and self.glove:
+            self._PLAN_FIELDS = NrmsEngine._PLAN_FIELDS + ("X",)
+        return super().enable_plan_slots()
+
+    def plan_on(self, stream, slot, cand, hist, hist_len, nb=None):
+        super().plan_on(stream, slot, cand, hist, hist_len, nb)
+        if self.Rc > 0:
+            self._decode_gather(self._slots[slot], ctypes.c_void_p(stream.cuda_stream))
+
+    def _decode_gather(self, b, st):
+        call("lego_nrms_decode_rows", _ptr(b["row_tok"]), self.Rc, _ptr(b["counters"], 0), _ptr(b["idx_tok"]), _ptr(b["idx_spec"]),
+             _ptr(b["idx_cat"]), _ptr(b["tokinfo"]), st)
+        if self.glove:
+            E0 = self.E0
+            call("lego_gather_rows", _ptr(self.P["embedding_vocab_table.glove.embedding.weight"]), E0, E0, _ptr(b["idx_tok"]),
+                 self.Rc, _ptr(b["counters"], 0), _ptr(b["X"]), E0, 0, st)
+
     def _att_ws(self, rows, Lmax, n_seg):
         D, A, H = self.D, self.A, self.heads
         return dict(rows=rows, Lmax=Lmax, qkv=self._f(rows, 3 * D), o=self._f(rows, D), att=self._f(rows, D),
@@ -868,7 +890,7 @@ class NrmsEngine(_Base):
         self._training = training
         if not planned:
             self._plan(cand, hist, hist_len)
-        self._forward_items(training)
+        self._forward_items(training, planned)
         if neck_ev is not None:
             neck_ev.record(torch.cuda.current_stream())
         if not self._loss_zeroed:
@@ -895,17 +917,15 @@ class NrmsEngine(_Base):
     # already the longer one: 1.240 against 1.212 ms per step.  Off until the side stream has room.
     fused_mask = os.environ.get("LEGO_NRMS_FUSED_MASK") == "1"
 
-    def _forward_items(self, training):
+    def _forward_items(self, training, planned=False):
         P, D = self.P, self.D
         st = _stream()
         self._prepare_folds()
         self._folds_fresh = True
-        call("lego_nrms_decode_rows", _ptr(self.row_tok), self.Rc, self.cnt(0), _ptr(self.idx_tok), _ptr(self.idx_spec),
-             _ptr(self.idx_cat), _ptr(self.tokinfo), st)
+        if not (planned and getattr(self, "_slots", None) is not None):      # else: done with the plan (plan_on)
+            self._decode_gather(self.__dict__, st)
         if self.glove:
             E0 = self.E0
-            call("lego_gather_rows", _ptr(P["embedding_vocab_table.glove.embedding.weight"]), E0, E0, _ptr(self.idx_tok),
-                 self.Rc, self.cnt(0), _ptr(self.X), E0, 0, st)
             call("lego_linear_fwd", _ptr(self.X), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
                  _ptr(P["embedding_vocab_table.glove.linear.bias"]), _ptr(self.E), D, self.Rc, self.cnt(0), D, E0, 0,
                  _ptr(self.tokinfo), self.drop(self.p_proj, SITE_PROJ, training), None, None, st)
