@@ -12,6 +12,9 @@ glove = glove_like(cfg["V"], 300, seed=2024, device=dev)
 params = init_naml_params(D=256, V=cfg["V"], n_cat=cfg["n_cat"], glove=glove)
 ts = TrainStep("naml", params, data, 64, K=4, lr=1e-3, total_steps=0, seed=2023, dropout=True, tail="drop", glove=True)
 N = 120
+if os.environ.get("NOGC") == "1":                   # ... or the host (Python's cyclic GC pausing the enqueue loop)?
+    import gc
+    gc.collect(); gc.disable()
 if os.environ.get("SPIN_MS"):                       # busy the device first: is the slow start a clock ramp?
     a = torch.randn(4096, 4096, device=dev)
     t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
@@ -38,3 +41,4 @@ plain = [d[i] for i in range(60, N) if i % 8 != 0]
 tagged = [d[i] for i in range(60, N) if i % 8 == 0]
 print(f"steady plain {sum(plain)/len(plain):.4f} ms, steps with tagged-kernel events {sum(tagged)/len(tagged):.4f} ms")
 print(f"mean of steps 5-24 (the driver's window): {sum(d[5:25])/20:.4f} ms; steps 40-59: {sum(d[40:60])/20:.4f}")
+print("steps 0-29:", " ".join(f"{x:.3f}" for x in d[:30]))
