@@ -313,8 +313,6 @@ static int tn_split(int M, int N, int K_cap, int taps) {     // k splits of the 
     int split = num_cus() / (tm * tn * taps);
     const int max_s = (K_cap + 255) / 256;          // at least 8 k tiles per workgroup
     if (split > max_s) split = max_s;
-    const int min_s = (K_cap + TN_INFO_CAP - BK - 1) / (TN_INFO_CAP - BK);      // a workgroup's k range fits the LDS pair_info cache
-    if (split < min_s) split = min_s;
     return split < 1 ? 1 : split;
 }
 

@@ -19,7 +19,8 @@ namespace lego {
 
 constexpr int TN_BM = 128, TN_BN = 128, TN_THREADS = 512;     // the long-reduction configuration (2 x 4 waves of 64 x 32)
 constexpr int TN_BM_S = 64, TN_BN_S = 64, TN_THREADS_S = 256;   // plain-row products: 2 x 2 waves of 32 x 32, four workgroups per CU
-constexpr int TN_INFO_CAP = 2048;            // pair_info words cached in LDS = the longest k range of one workgroup (host: tn_split)
+constexpr int TN_INFO_CAP = 2048;            // pair_info words cached in LDS
+constexpr int TN_WINDOW = TN_INFO_CAP - BK;  // rows of a k range walked per refill of that cache (a multiple of BK)
 
 struct TnDims {
     int M, N, K;                 // output M x N, static bound of the reduction length
@@ -84,21 +85,18 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void tn_kernel(TnDims dims, ALoad l
         }
         return;
     }
-    la.K = kend; lb.K = kend;
     la.prepare(tap); lb.prepare(tap);
-    if constexpr (A2 || B2) {
-        const int n_info = kend - kbeg;                  // <= TN_INFO_CAP: the host picks the split accordingly
-        const int* src = A2 ? la.info_src() : lb.info_src();
-        for (int i = tid; i < n_info; i += NT) s_info[i] = src[kbeg + i];
-        if constexpr (A2) la.cache(s_info, kbeg);
-        if constexpr (B2) lb.cache(s_info, kbeg);
-        __syncthreads();
-    }
+    // The k range is walked in WINDOWS of at most TN_WINDOW rows: the pair_info words of a window are what the LDS cache holds.  One
+    // window is the rule (the host sizes the split for the rows a batch usually has); a batch near the CAPACITY of the plan takes
+    // several.  Round 2 first sized the split so that the capacity fitted one window: 27 splits instead of 16 for the headline shape --
+    // 432 workgroups in two rounds on 256 CUs, no XCD dealing, 27 slabs, an L2 hit rate of 0.13 instead of 0.82.
+    constexpr int WIN = (A2 || B2) ? TN_WINDOW : (1 << 30);      // plain operands need no cache: one window
+    int wbeg = kbeg, wend = min(kend, kbeg + WIN);
 
     const int kr = tid / PER, c4 = (tid % PER) * 4;      // this thread's k row inside a pass and its 4 columns
     struct Regs { f32x4 a[NJ], b[NJ], a2[A2 ? NJ : 1], b2[B2 ? NJ : 1]; bool pa[NJ], pb[NJ], pa2[A2 ? NJ : 1], pb2[B2 ? NJ : 1]; };
     auto fetch = [&](Regs& r, int k0) {
-        k0 = min(k0, kend - 1);                          // past the end: re-read the last rows (never committed to a used stage)
+        k0 = min(k0, wend - 1);                          // past the end: re-read the last rows (never committed to a used stage)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int kk = k0 + kr + STEP * j;
@@ -164,21 +162,32 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void tn_kernel(TnDims dims, ALoad l
     // tile t lives in LDS stage t & 1; its global loads are issued at the top of iteration t - 2 and committed at the bottom of
     // iteration t - 1 (after that iteration's MFMAs), i.e. two tiles of matrix work cover every load
     Regs r0, r1;
-    fetch(r0, kbeg);
-    commit(r0, As0, Bs0);
-    fetch(r1, kbeg + BK);
-    __syncthreads();
-    const int nt = (kend - kbeg + BK - 1) / BK;
-    for (int t = 0; t < nt; t += 2) {
-        fetch(r0, kbeg + (t + 2) * BK);
-        tile_mfma(As0, Bs0);
-        commit(r1, As0 + STAGE, Bs0 + STAGE);            // tile t + 1
+    for (; wbeg < kend; wbeg = wend, wend = min(kend, wbeg + WIN)) {
+        la.K = wend; lb.K = wend;                        // rows past the window read as zero; the prefetch past it is never used
+        if constexpr (A2 || B2) {
+            if (wbeg > kbeg) __syncthreads();            // the previous window's loads have left the cache
+            const int* src = A2 ? la.info_src() : lb.info_src();
+            for (int i = tid; i < wend - wbeg; i += NT) s_info[i] = src[wbeg + i];
+            if constexpr (A2) la.cache(s_info, wbeg);
+            if constexpr (B2) lb.cache(s_info, wbeg);
+            __syncthreads();
+        }
+        fetch(r0, wbeg);
+        commit(r0, As0, Bs0);
+        fetch(r1, wbeg + BK);
         __syncthreads();
-        if (t + 1 >= nt) break;
-        fetch(r1, kbeg + (t + 3) * BK);
-        tile_mfma(As0 + STAGE, Bs0 + STAGE);
-        commit(r0, As0, Bs0);                            // tile t + 2
-        __syncthreads();
+        const int nt = (wend - wbeg + BK - 1) / BK;
+        for (int t = 0; t < nt; t += 2) {
+            fetch(r0, wbeg + (t + 2) * BK);
+            tile_mfma(As0, Bs0);
+            commit(r1, As0 + STAGE, Bs0 + STAGE);        // tile t + 1
+            __syncthreads();
+            if (t + 1 >= nt) break;
+            fetch(r1, wbeg + (t + 3) * BK);
+            tile_mfma(As0 + STAGE, Bs0 + STAGE);
+            commit(r0, As0, Bs0);                        // tile t + 2
+            __syncthreads();
+        }
     }
 
     // epilogue: lane holds column li x rows {(v & 3) + 8 * (v >> 2) + 4 * lh} of each 32 x 32 sub-tile
