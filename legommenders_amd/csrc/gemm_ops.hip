@@ -276,15 +276,31 @@ static int launch_oneshot(const GemmDims& d, const AL& a, const BL& b, const Epi
     return check_launch(what);
 }
 
+static int light_mode() {          // A/B switch (tuning): LEGO_LIGHT=0 keeps the one-shot kernel for every small product
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("LEGO_LIGHT"); v = (e != nullptr && e[0] == '0') ? 0 : 1; }
+    return v;
+}
+
+template <bool B_MC, class EK, class AL, class BL>
+static int launch_light(const GemmDims& d, const AL& a, const BL& b, const Epi& e0, hipStream_t st, const char* what) {
+    EK e;
+    static_cast<EpiArgs&>(e) = e0;
+    hipLaunchKernelGGL((light_kernel<B_MC, AL, BL, EK>), dim3((d.M + 15) / 16, (d.N + 31) / 32), dim3(64), 0, st, d, a, b, e);
+    return check_launch(what);
+}
+
 template <bool B_MC, class EK, class AL, class BL>
 static int launch_rows(const GemmDims& d, const AL& a, const BL& b, const Epi& e, hipStream_t st, const char* what) {
     const int tm = (d.M + 127) / 128;
     if (d.M >= 32 * num_cus() && d.N <= 4 * STRIP_BN) return launch_strip<B_MC, EK>(d, a, b, e, st, what);
     if constexpr (std::is_same<AL, KcRows>::value)
         if (d.K <= 4 * ONE_KMAX && d.K % 4 == 0 &&
-            ((d.M + ONE_BM - 1) / ONE_BM) * ((d.N + ONE_BN - 1) / ONE_BN) <= 3 * num_cus())  // few rounds of whole-CU blocks by
+            ((d.M + ONE_BM - 1) / ONE_BM) * ((d.N + ONE_BN - 1) / ONE_BN) <= 3 * num_cus()) { // few rounds of whole-CU blocks by
                                                                                               // CAPACITY: the user side fills 40 %
+            if (light_mode()) return launch_light<B_MC, EK>(d, a, b, e, st, what);
             return launch_oneshot<B_MC, EK>(d, a, b, e, st, what);
+        }
     if (tm * ((d.N + 127) / 128) < 128) {         // few row tiles (user / category side): 64-row tiles fill more CUs
         if (d.N > 64) return launch<C64x128, false, B_MC, EK>(d, a, b, e, (d.M + 63) / 64, (d.N + 127) / 128, 1, st, what);
         return launch<C64x64, false, B_MC, EK>(d, a, b, e, (d.M + 63) / 64, (d.N + 63) / 64, 1, st, what);
