@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64) void light_kernel(GemmDims dims, ALoad la, BLoa
     lb.tile(0);
     const typename ALoad::Row ra = la.row(m0 + l16);
     f32x4 acc[1][2] = {{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}};
-    constexpr int U = 4;                                     // k groups of 16 whose loads are in flight together
+    constexpr int U = 2;                                     // k groups of 16 whose loads are in flight together
     for (int k0 = 0; k0 < K; k0 += 16 * U) {
         f32x4 fa[U], fb[U][2];
 #pragma unroll
