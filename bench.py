@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--time-every", type=int, default=4, help="bracket the roofline kernel and the in-step gather with HIP events every N-th timed step")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even at world size 1 (path check)")
+    ap.add_argument("--no-balance", action="store_true", help="N > 1: deal rows r::W instead of by live-row cost (A/B)")
     ap.add_argument("--small", action="store_true", help="shrunken world for quick checks (NOT the metric config)")
     return ap.parse_args()
 
@@ -191,12 +192,50 @@ def kernel_table(timers):
     return {tag: {"avg_ms": sum(a.elapsed_time(b) for a, b in evs) / max(1, len(evs)), "launches": len(evs)} for tag, evs in timers.items()}
 
 
+def launcher_command(args_list, gpus, port):
+    """argv of the N-rank launch a plain `python bench.py --gpus N` turns into (the driver's own command shape)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(args_list)
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`--gpus N` with N > 1 outside torchrun: this parent (which has made NO GPU call -- device_count() does not initialise
+    HIP on this image) starts N fresh ranks as a child process and relays rank 0's JSON line and the exit code.  It never
+    prints a line itself, so `n_gpus` can not differ from --gpus."""
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible; refusing to measure fewer ranks than asked",
+              file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    res = subprocess.run(launcher_command(argv, args.gpus, free_port()), env=env)
+    return res.returncode
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world_size == args.gpus or world_size == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    if world_size != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} under a launcher with WORLD_SIZE={world_size}: launch with "
+              f"--nproc-per-node == --gpus", file=sys.stderr)
+        sys.exit(2)
+    if torch.cuda.device_count() <= local_rank:
+        print(f"bench.py: rank {rank} has no GPU (LOCAL_RANK {local_rank}, {torch.cuda.device_count()} visible)", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
@@ -216,7 +255,7 @@ def main():
     if args.small:
         cfg.update(n_items=5000, n_users=4000, n_rows=20000, V=20000)
     world = make_world(seed=2023, **cfg)
-    data = DeviceData(world, dev, rank=rank, world_size=world_size, seed=2023)
+    data = DeviceData(world, dev, rank=rank, world_size=world_size, seed=2023, balance=None if args.no_balance else args.batch)
     glove = glove_like(cfg["V"], 300, seed=2024, device=dev)
     B, D, E0 = args.batch, args.hidden, 300
 
@@ -331,6 +370,9 @@ def main():
         extra["allreduce_ms"] = round(a.elapsed_time(b) / 20, 4)
         extra["allreduce_bytes"] = ts.fp.numel * 4
         ts.fp.grad.zero_()
+        seen = torch.ones(1, dtype=torch.int32, device=dev)         # every rank that really ran adds one
+        torch.distributed.all_reduce(seen)
+        extra["ranks_seen"] = int(seen.item())
     if world_size == 1 and not dist_on and not args.no_secondary and not args.small:
         if args.steps < 200:                       # the same configuration over a window long enough to average out jitter
             dl, _, _ = timed_steps(ts, 200, 0, barrier)
@@ -408,6 +450,8 @@ def main():
         "kernels": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kern.items()},
     }
     out.update(extra)
+    out.setdefault("ranks_seen", 1)
+    assert out["ranks_seen"] == args.gpus == out["n_gpus"], "a rank is missing: this line would misreport the job"
     if not args.no_cpu_baseline and world_size == 1:
         out["cpu_baseline"] = cpu_baseline(world, B, D, args.cpu_steps)
     else:

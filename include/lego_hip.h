@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LEGO_ABI_VERSION 1
+#define LEGO_ABI_VERSION 3
 #define LEGO_COUNTERS 8
 
 const char* lego_last_error(void);
@@ -256,11 +256,14 @@ int lego_mark_rows(const int32_t* idx, int n_cap, const int32_t* n_dyn, int rows
  * device: cand[b,0] = positive; min(K,len) distinct draws from the user's true-negative list,
  * the rest uniform item ids in [0,n_items).  The Philox stream of row b is keyed on
  * (seed, step, row_base + b * row_stride): data-parallel rank r of W passes (r, W) -- the row's position in
- * the global batch of the step -- so W ranks x B rows draw what one device with batch W*B draws (0, 1). */
+ * the global batch of the step -- so W ranks x B rows draw what one device with batch W*B draws (0, 1).
+ * row_pos != NULL: the position of row b is row_pos[b] instead (ranks that deal the rows of a global batch by their live-row
+ * cost rather than r::W, train_step.DeviceData(balance=B)). */
 int lego_sample_negatives(const int32_t* row_user /*[B]*/, const int32_t* row_item /*[B]*/,
                           const int32_t* neg_list /*[n_users,neg_cap]*/, const int32_t* neg_len, int neg_cap,
                           int B, int K, int n_items, uint64_t seed, uint32_t step, uint32_t row_base,
-                          uint32_t row_stride, int32_t* cand /*[B,K+1]*/, void* stream);
+                          uint32_t row_stride, const int32_t* row_pos /*[B] or NULL*/, int32_t* cand /*[B,K+1]*/,
+                          void* stream);
 /* hist[b,:] / hist_len[b] = user tables rows of row_user[b]  (the DataSet row copy, data_set.py:61-85) */
 int lego_gather_history(const int32_t* row_user, const int32_t* user_hist /*[n_users,S]*/,
                         const int32_t* user_hist_len, int B, int S, int32_t* hist, int32_t* hist_len, void* stream);

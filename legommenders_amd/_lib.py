@@ -22,6 +22,9 @@ U64 = ctypes.c_uint64
 U32 = ctypes.c_uint32
 
 
+ABI_VERSION = 3      # == LEGO_ABI_VERSION of include/lego_hip.h this binding was written against
+
+
 class LegoDropout(ctypes.Structure):
     _fields_ = [("p", ctypes.c_float), ("seed", ctypes.c_uint64), ("site", ctypes.c_uint32), ("mask", ctypes.c_void_p)]
 
@@ -69,7 +72,7 @@ SIGNATURES = {
     "lego_adam_step": [P, P, P, P, I64, F, F, F, F, I, F, I, P],
     "lego_adam_step_rows": [P, P, P, P, I, I, P, F, F, F, F, I, F, I, P],
     "lego_mark_rows": [P, I, P, I, P, P],
-    "lego_sample_negatives": [P, P, P, P, I, I, I, I, U64, U32, U32, U32, P, P],
+    "lego_sample_negatives": [P, P, P, P, I, I, I, I, U64, U32, U32, U32, P, P, P],
     "lego_gather_history": [P, P, P, I, I, P, P, P],
     "lego_gather_i32": [P, P, I, P, P, P],
     "lego_grouped_metrics": [P, P, P, I, P, I, P, P],
@@ -123,6 +126,11 @@ def lib() -> ctypes.CDLL:
     handle.lego_last_error.restype = ctypes.c_char_p
     handle.lego_last_error.argtypes = []
     handle.lego_abi_version.restype = ctypes.c_int
+    handle.lego_abi_version.argtypes = []
+    got = handle.lego_abi_version()
+    if got != ABI_VERSION:                      # a stale in-tree build would be called with shifted argument lists
+        raise LegoHipError(f"{LIB_PATH} reports C-ABI version {got}, this binding expects {ABI_VERSION}: "
+                           "rebuild with `make -C legommenders_amd/csrc`")
     for name, argtypes in VALUE_FUNCS.items():
         fn = getattr(handle, name)
         fn.restype, fn.argtypes = ctypes.c_int, argtypes

@@ -1080,12 +1080,13 @@ __global__ void mark_rows_kernel(const int* __restrict__ idx, int n_cap, const i
 __global__ void sample_negatives_kernel(const int* __restrict__ row_user, const int* __restrict__ row_item,
                                         const int* __restrict__ neg_list, const int* __restrict__ neg_len, int neg_cap,
                                         int B, int K, int n_items, uint32_t seed_lo, uint32_t seed_hi, uint32_t step,
-                                        uint32_t row_base, uint32_t row_stride, int* cand) {
+                                        uint32_t row_base, uint32_t row_stride, const int* __restrict__ row_pos, int* cand) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     // the Philox stream of a row is keyed on its position in the GLOBAL batch of the step (rank r of W: r + b * W), so that
     // W ranks x B rows draw exactly what one device with batch W * B draws for the same rows
-    const uint32_t gb = row_base + (uint32_t)b * row_stride;
+    // (row_pos: the position read from a table instead -- ranks that deal a global batch's rows by cost, DeviceData.balance)
+    const uint32_t gb = row_pos != nullptr ? (uint32_t)row_pos[b] : row_base + (uint32_t)b * row_stride;
     const int u = row_user[b];
     const int L = min(max(neg_len[u], 0), neg_cap);
     const int n_true = min(K, L);
@@ -1412,11 +1413,12 @@ extern "C" int lego_mark_rows(const int32_t* idx, int n_cap, const int32_t* n_dy
 
 extern "C" int lego_sample_negatives(const int32_t* row_user, const int32_t* row_item, const int32_t* neg_list,
                                      const int32_t* neg_len, int neg_cap, int B, int K, int n_items, uint64_t seed,
-                                     uint32_t step, uint32_t row_base, uint32_t row_stride, int32_t* cand, void* stream) {
+                                     uint32_t step, uint32_t row_base, uint32_t row_stride, const int32_t* row_pos, int32_t* cand,
+                                     void* stream) {
     LEGO_REQUIRE(K < kMaxCand && n_items > 0, "lego_sample_negatives: K=%d n_items=%d unsupported", K, n_items);
     if (B <= 0) return 0;
     hipLaunchKernelGGL(sample_negatives_kernel, dim3((B + 127) / 128), dim3(128), 0, ST, row_user, row_item, neg_list, neg_len,
-                       neg_cap, B, K, n_items, (uint32_t)seed, (uint32_t)(seed >> 32), step, row_base, row_stride, cand);
+                       neg_cap, B, K, n_items, (uint32_t)seed, (uint32_t)(seed >> 32), step, row_base, row_stride, row_pos, cand);
     return check_launch("lego_sample_negatives");
 }
 

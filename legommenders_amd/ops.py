@@ -434,7 +434,7 @@ def sample_negatives(row_user: torch.Tensor, row_item: torch.Tensor, neg_list: t
     B = row_user.numel()
     cand = torch.empty(B, K_neg + 1, dtype=torch.int32, device=row_user.device)
     call("lego_sample_negatives", K._ptr(row_user), K._ptr(row_item), K._ptr(neg_list), K._ptr(neg_len), neg_list.shape[1], B, K_neg,
-         n_items, int(seed), int(step), int(row_base), int(row_stride), K._ptr(cand), K._stream())
+         n_items, int(seed), int(step), int(row_base), int(row_stride), None, K._ptr(cand), K._stream())
     return cand
 
 

@@ -55,8 +55,9 @@ class PluginStep:
         epoch, start, nb = self.schedule.at(self.batch_idx)
         row_user, row_item = d.rows(epoch)                                  # per-epoch reshuffle (train_step.DeviceData)
         ru, ri = _ptr(row_user, start), _ptr(row_item, start)
+        pos = d.positions(epoch)
         call("lego_sample_negatives", ru, ri, _ptr(d.neg_list), _ptr(d.neg_len), d.neg_cap, nb, self.K, d.n_items,
-             self.seed, self.batch_idx, d.rank, d.world_size, _ptr(self.cand), _stream())
+             self.seed, self.batch_idx, d.rank, d.world_size, None if pos is None else _ptr(pos, start), _ptr(self.cand), _stream())
         call("lego_gather_history", ru, _ptr(d.user_hist), _ptr(d.user_hist_len), nb, d.S, _ptr(self.hist),
              _ptr(self.hist_len), _stream())
         return nb

@@ -59,7 +59,45 @@ class FlatParams:
 def rank_seed(seed: int, rank: int) -> int:
     """seed of a rank-local Philox stream family (dropout keep bits: their counters are rank-local row indices, so the rank
     goes into the key; rank 0 keeps `seed`)"""
-    return (int(seed) ^ (0x9E3779B97F4A7C15 * int(rank))) & 0xFFFFFFFFFFFFFFFF
+    # kept below 2^63: the plug-in route passes it as the `int seed` argument of torch.ops.lego_hip.* (an int64 schema)
+    return (int(seed) ^ (0x9E3779B97F4A7C15 * int(rank))) & 0x7FFFFFFFFFFFFFFF
+
+
+def row_cost(world: dict):
+    """live rows a train row puts into a step, from the tables alone (host, int64 [n_rows]): token rows + one instance row
+    per clicked item of the user's history, plus the positive candidate's (the K negatives are drawn later; their expected
+    cost is the same for every row)"""
+    import numpy as np
+    tl = np.asarray(world["title_len"]).astype(np.int64) + 1                       # + the category row of the instance
+    hist, hl = np.asarray(world["user_hist"]), np.asarray(world["user_hist_len"])
+    live = np.arange(hist.shape[1])[None, :] < hl[:, None]
+    user_cost = (tl[np.clip(hist, 0, len(tl) - 1)] * live).sum(1)
+    return torch.from_numpy(user_cost[np.asarray(world["row_user"])] + tl[np.asarray(world["row_item"])])
+
+
+def deal_balanced(perm: torch.Tensor, cost: torch.Tensor, W: int, r: int, B: int):
+    """rows of every global batch (W*B consecutive entries of `perm`; the last one may be shorter, a multiple of W) dealt
+    to W ranks by cost: descending order, snake over the ranks, so every rank gets the same COUNT and near-equal cost.
+    Returns (rank r's rows in visiting order, the position of each inside its global batch)."""
+    n = perm.numel()
+    rows_out, pos_out = [], []
+    G = W * B
+    full = n // G
+    snake = torch.cat([torch.arange(W), torch.arange(W - 1, -1, -1)])
+
+    def one(block, width):          # block: [nb, width] row ids
+        order = torch.argsort(cost[block], dim=1, descending=True, stable=True)             # positions inside the batch
+        owner = snake[torch.arange(width) % (2 * W)]
+        mine = order[:, owner == r]                                                          # [nb, width / W]
+        return torch.gather(block, 1, mine).reshape(-1), mine.reshape(-1)
+
+    if full:
+        a, b = one(perm[: full * G].view(full, G), G)
+        rows_out.append(a); pos_out.append(b)
+    if n > full * G:
+        a, b = one(perm[full * G:].view(1, n - full * G), n - full * G)
+        rows_out.append(a); pos_out.append(b)
+    return torch.cat(rows_out), torch.cat(pos_out)
 
 
 class DeviceData:
@@ -70,9 +108,16 @@ class DeviceData:
     walks ONE permutation drawn from (seed, e), identical on every rank; it is cut to a multiple of the world size and rank r
     takes positions r::world, so every rank has the same number of rows (and steps, and schedule length) and the
     global batch of step s is the contiguous slice perm[s*W*B : (s+1)*W*B] a single device with batch W*B would take.
-    Two epochs are resident (buffer = epoch % 2): the batch after the last one of an epoch is sampled ahead of time."""
+    Two epochs are resident (buffer = epoch % 2): the batch after the last one of an epoch is sampled ahead of time.
 
-    def __init__(self, world: dict, device, rank=0, world_size=1, seed=2023):
+    `balance=B` (W > 1): WHICH rows of a global batch a rank takes is free -- the exchanged gradient is a sum over the same
+    W*B rows -- so instead of `r::W` the rows of every global batch are dealt by their live-row cost (`row_cost`: token rows
+    + item instances of the row's click history and positive, known from the tables): sorted by cost, dealt in a snake
+    (0..W-1, W-1..0, ...), B rows per rank.  A step costs the slowest rank's rows; the snake brings max/mean over the ranks
+    from ~1.1 to ~1.00 (tools/rank_balance.py).  The sampler then reads each row's position in the global batch from a
+    table (`positions`), so the negatives still are what one device with batch W*B draws."""
+
+    def __init__(self, world: dict, device, rank=0, world_size=1, seed=2023, balance: Optional[int] = None):
         i32 = lambda a: torch.as_tensor(a).to(device=device, dtype=torch.int32).contiguous()
         self.device = device
         self.tables = ItemTables(world["title_tok"], world["title_len"], world["cat"], device)
@@ -85,7 +130,10 @@ class DeviceData:
         self._all_user, self._all_item = i32(world["row_user"]), i32(world["row_item"])
         self.n_total = self._all_user.numel()
         self.n_rows = self.n_total // self.world_size          # per rank, equal on every rank
-        self._buf = [dict(epoch=-1, user=None, item=None), dict(epoch=-1, user=None, item=None)]
+        self.balance = int(balance) if balance and self.world_size > 1 else None
+        if self.balance:
+            self._row_cost = row_cost(world)                   # host int64 [n_total]
+        self._buf = [dict(epoch=-1, user=None, item=None, pos=None), dict(epoch=-1, user=None, item=None, pos=None)]
         self.ensure_epoch(0)
 
     def epoch_permutation(self, epoch: int) -> torch.Tensor:
@@ -93,21 +141,32 @@ class DeviceData:
         g = torch.Generator().manual_seed(self.seed + 1000003 * int(epoch))
         return torch.randperm(self.n_total, generator=g)
 
+    def deal(self, epoch: int):
+        """(this rank's row indices for `epoch` in visiting order, their positions in their global batches or None)"""
+        W, r = self.world_size, self.rank
+        perm = self.epoch_permutation(epoch)[: self.n_rows * W]
+        if not self.balance:
+            return perm[r::W], None
+        return deal_balanced(perm, self._row_cost, W, r, self.balance)
+
     def shard_of(self, epoch: int) -> torch.Tensor:
         """this rank's row indices for `epoch`, in visiting order"""
-        perm = self.epoch_permutation(epoch)
-        return perm[: self.n_rows * self.world_size][self.rank::self.world_size]
+        return self.deal(epoch)[0]
 
     def ensure_epoch(self, epoch: int):
         """make the rows of `epoch` resident (enqueued on the current stream; a no-op when they already are)"""
         b = self._buf[epoch % 2]
         if b["epoch"] != epoch:
-            mine = self.shard_of(epoch).to(self.device)
+            mine, pos = self.deal(epoch)
+            mine = mine.to(self.device)
             if b["user"] is None:
                 b["user"], b["item"] = self._all_user[mine].contiguous(), self._all_item[mine].contiguous()
+                b["pos"] = None if pos is None else pos.to(device=self.device, dtype=torch.int32).contiguous()
             else:                                              # in place: sampling kernels hold these addresses
                 torch.index_select(self._all_user, 0, mine, out=b["user"])
                 torch.index_select(self._all_item, 0, mine, out=b["item"])
+                if pos is not None:
+                    b["pos"].copy_(pos.to(torch.int32), non_blocking=False)
             b["epoch"] = epoch
         return b
 
@@ -115,14 +174,18 @@ class DeviceData:
         b = self.ensure_epoch(epoch)
         return b["user"], b["item"]
 
-    # epoch-0 views (tests, tools)
+    def positions(self, epoch: int):
+        """per row of this rank's shard: its position in the global batch it belongs to (None: r + b * W, the sampler's default)"""
+        return self.ensure_epoch(epoch)["pos"]
+
+    # epoch-0 views (tests, tools): fresh tensors, never the resident double buffers the sampling kernels read
     @property
     def row_user(self):
-        return self.rows(0)[0]
+        return self._all_user[self.shard_of(0).to(self.device)]
 
     @property
     def row_item(self):
-        return self.rows(0)[1]
+        return self._all_item[self.shard_of(0).to(self.device)]
 
 
 class BatchSchedule:
@@ -224,8 +287,9 @@ class TrainStep:
         row_user, row_item = d.rows(epoch)
         st = _stream() if stream is None else ctypes.c_void_p(stream.cuda_stream)
         ru, ri = _ptr(row_user, start), _ptr(row_item, start)
+        pos = d.positions(epoch)
         call("lego_sample_negatives", ru, ri, _ptr(d.neg_list), _ptr(d.neg_len), d.neg_cap, nb, self.K, d.n_items,
-             self.seed, batch_idx, d.rank, d.world_size, _ptr(self._cand[slot]), st)
+             self.seed, batch_idx, d.rank, d.world_size, None if pos is None else _ptr(pos, start), _ptr(self._cand[slot]), st)
         call("lego_gather_history", ru, _ptr(d.user_hist), _ptr(d.user_hist_len), nb, d.S, _ptr(self._hist[slot]),
              _ptr(self._hist_len[slot]), st)
         return nb

@@ -175,12 +175,15 @@ class Trainer:
             json.dump(config(), open(os.path.join(self.ckpt_dir, self.signature + ".json"), "w"), default=str)
         self.world = load_world(config.data, config.seed)
         self.legommender, self.kind = build_model(config, self.world, self.device)
-        self.data = DeviceData(self.world, self.device, rank=self.rank, world_size=self.world_size, seed=config.seed)
+        self.data = DeviceData(self.world, self.device, rank=self.rank, world_size=self.world_size, seed=config.seed,
+                               balance=int(self.exp.policy.batch_size))
         pol = self.exp.policy
         self.B = int(pol.batch_size)
         # every row of the rank's shard once per epoch, the short last batch included (DataLoader drop_last=False,
         # manager.py:374-381); shards are equal on all ranks, so steps and schedule length agree everywhere
         self.steps_per_epoch = BatchSchedule(self.data.n_rows, self.B, "keep").steps_per_epoch
+        # schedule length as the reference counts it: len(train_set) // batch_size * epoch (base_lego.py:218-222)
+        sched_steps = max(1, self.data.n_rows // self.B) * int(pol.epoch)
         accumulate = int(pol.accumulate_batch or 1)                       # trainer.py:171
         Env.simple_dev = bool(pol.simple_dev)                            # base_lego.py:121
         params = {k: v.detach() for k, v in self.legommender.state_dict().items()}
@@ -189,7 +192,7 @@ class Trainer:
         if self.kind == "plugin":
             from legommenders_amd.plugin_step import PluginEvaluator, PluginStep
             self.ts = PluginStep(self.legommender, self.data, self.B, K=self.legommender.neg_count, lr=float(pol.lr),
-                                 total_steps=self.steps_per_epoch * int(pol.epoch), warmup=int(pol.n_warmup or 0),
+                                 total_steps=sched_steps, warmup=int(pol.n_warmup or 0),
                                  seed=config.seed, process_group=self.pg, world_size=self.world_size, accumulate=accumulate,
                                  item_lr=pol.item_lr)
             self.evaluator = PluginEvaluator(self.legommender, self.data,
@@ -197,7 +200,7 @@ class Trainer:
                                              process_group=self.pg, rank=self.rank, world_size=self.world_size)
         else:
             self.ts = TrainStep(self.kind, params, self.data, self.B, K=self.legommender.neg_count, lr=float(pol.lr),
-                                total_steps=self.steps_per_epoch * int(pol.epoch), warmup=int(pol.n_warmup or 0),
+                                total_steps=sched_steps, warmup=int(pol.n_warmup or 0),
                                 seed=config.seed, heads=heads, glove=glove, process_group=self.pg, world_size=self.world_size,
                                 accumulate=accumulate)
             self._heads, self._glove = heads, glove
@@ -280,7 +283,7 @@ class Trainer:
             hist = torch.empty(b, S, dtype=torch.int32, device=dev)
             hist_len = torch.empty(b, dtype=torch.int32, device=dev)
             call("lego_sample_negatives", _ptr(users, s), _ptr(items, s), _ptr(d.neg_list), _ptr(d.neg_len), d.neg_cap, b, K,
-                 d.n_items, int(self.config.seed) + 1, bi, 0, 1, _ptr(cand), _stream())
+                 d.n_items, int(self.config.seed) + 1, bi, 0, 1, None, _ptr(cand), _stream())
             call("lego_gather_history", _ptr(users, s), _ptr(d.user_hist), _ptr(d.user_hist_len), b, S, _ptr(hist),
                  _ptr(hist_len), _stream())
             if self.kind == "plugin":

@@ -56,14 +56,14 @@ def test_host_code_under_address_sanitizer(tmp_path):
         "import ctypes\n"
         "from legommenders_amd import _lib\n"
         "h = _lib.lib()\n"
-        "assert h.lego_abi_version() == 1\n"
+        "assert h.lego_abi_version() == _lib.ABI_VERSION\n"
         "rc = h.lego_adam_step(None, None, None, None, ctypes.c_int64(4), 1e-3, 0.9, 0.999, 1e-8, 0, 1.0, 0, None)\n"
         "assert rc != 0 and b'1-based' in h.lego_last_error()\n"
         "rc = h.lego_plan_batch(None, None, None, 0, 5, 50, None, None, 30, None, None, None, None, None, None, None)\n"
         "assert rc != 0 and b'bad sizes' in h.lego_last_error()\n"
         "rc = h.lego_linear_fwd(None, 3, None, 4, None, None, 4, 8, None, 4, 4, 0, None, None, None, None, None)\n"
         "assert rc != 0 and b'multiple of 4' in h.lego_last_error()\n"
-        "rc = h.lego_sample_negatives(None, None, None, None, 100, 4, 99, 10, 1, 0, 0, 1, None, None)\n"
+        "rc = h.lego_sample_negatives(None, None, None, None, 100, 4, 99, 10, 1, 0, 0, 1, None, None, None)\n"
         "assert rc != 0 and b'unsupported' in h.lego_last_error()\n"
         "print('asan-ok')\n")
     env = dict(os.environ, LEGO_HIP_LIB=os.path.join(csrc, "liblego_hip_asan.so"), LD_PRELOAD=rt,
@@ -80,7 +80,16 @@ def test_every_declared_symbol_is_exported(handle):
 
 
 def test_abi_version(handle):
-    assert handle.lego_abi_version() == 1
+    import re
+    assert handle.lego_abi_version() == _lib.ABI_VERSION
+    assert int(re.search(r"#define LEGO_ABI_VERSION (\d+)", open(_lib.HEADER).read()).group(1)) == _lib.ABI_VERSION
+
+
+def test_stale_library_is_refused(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    with pytest.raises(_lib.LegoHipError, match="rebuild"):
+        _lib.lib()
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

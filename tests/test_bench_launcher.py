@@ -1,0 +1,41 @@
+"""bench.py --gpus N outside torchrun starts N ranks itself and can not print a line whose n_gpus differs from --gpus
+(a plain `python bench.py --gpus 8` used to measure ONE GPU and say so only in `n_gpus`)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=300)
+
+
+def test_launcher_argv_is_the_drivers_command_shape():
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.launcher_command(["--gpus", "4", "--steps", "7", "--warmup", "2"], 4, 29517)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29517"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+
+
+def test_more_ranks_than_gpus_fails_loudly():
+    """this container has no GPU: --gpus 2 must exit non-zero with a message and print no JSON line"""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("two GPUs visible")
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0 and "--gpus 2" in r.stderr and "{" not in r.stdout
+
+
+def test_world_size_mismatch_fails_loudly():
+    r = _run(["--gpus", "2"], {"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr and "{" not in r.stdout
+    r = _run(["--gpus", "1"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "{" not in r.stdout

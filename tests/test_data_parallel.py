@@ -188,3 +188,49 @@ def test_optimizer_and_scheduler_state_are_torch_state_dicts():
         o, n = ts.fp.offsets[k], P[k].numel()
         assert torch.equal(ts2.fp.m[o:o + n], ts.fp.m[o:o + n]) and torch.equal(ts2.fp.v[o:o + n], ts.fp.v[o:o + n])
     assert ts2.step_idx == 7
+
+
+def test_balanced_dealing_partitions_every_global_batch():
+    """DeviceData(balance=B): the W ranks' rows of step s are still exactly the global batch perm[s*W*B:(s+1)*W*B] (so the
+    summed gradient is the one-device gradient), B per rank, each row's recorded position is where it sits in that batch,
+    and the per-rank live-row cost is closer to equal than under r::W"""
+    from legommenders_amd.synthetic import make_world
+    from legommenders_amd.train_step import BatchSchedule, DeviceData, row_cost
+    w = make_world(seed=3, n_items=80, n_users=60, n_rows=203, V=100)
+    W, B = 4, 6
+    ranks = [DeviceData(w, "cpu", rank=r, world_size=W, seed=11, balance=B) for r in range(W)]
+    blind = [DeviceData(w, "cpu", rank=r, world_size=W, seed=11) for r in range(W)]
+    one = DeviceData(w, "cpu", seed=11, balance=B)
+    assert one.balance is None and one.positions(0) is None                     # W = 1: nothing to deal
+    cost = row_cost(w)
+    sched = BatchSchedule(ranks[0].n_rows, B, "keep")
+    assert sched.steps_per_epoch == 9 and ranks[0].n_rows == 50                 # 8 full batches + a short one of 2 rows per rank
+    spread_bal, spread_blind = [], []
+    for epoch in (0, 3):
+        perm = one.epoch_permutation(epoch)[: 50 * W]
+        for s in range(sched.steps_per_epoch):
+            _, start, nb = sched.at(s)
+            glob = perm[start * W:(start + nb) * W]
+            rows = [d.shard_of(epoch)[start:start + nb] for d in ranks]
+            pos = [d.positions(epoch)[start:start + nb].long() for d in ranks]
+            assert sorted(torch.cat(rows).tolist()) == sorted(glob.tolist())
+            assert sorted(torch.cat(pos).tolist()) == list(range(nb * W))
+            for r_, p_ in zip(rows, pos):
+                assert torch.equal(glob[p_], r_)
+            for d, r_ in zip(ranks, rows):
+                ru, ri = d.rows(epoch)
+                assert ru[start:start + nb].tolist() == w["row_user"][r_.numpy()].tolist()
+                assert ri[start:start + nb].tolist() == w["row_item"][r_.numpy()].tolist()
+            if nb == B:
+                per = torch.stack([cost[r_].sum() for r_ in rows]).double()
+                spread_bal.append(float(per.max() / per.mean()))
+                per = torch.stack([cost[d.shard_of(epoch)[start:start + nb]].sum() for d in blind]).double()
+                spread_blind.append(float(per.max() / per.mean()))
+    assert np.mean(spread_bal) < 1.0 + 0.5 * (np.mean(spread_blind) - 1.0)
+
+
+def test_rank_seed_fits_a_custom_op_int():
+    """the seed goes through torch.ops.lego_hip.* `int seed` arguments (int64) on the plug-in route"""
+    from legommenders_amd.train_step import rank_seed
+    seeds = [rank_seed(2023, r) for r in range(16)]
+    assert all(0 <= s < 2 ** 63 for s in seeds) and len(set(seeds)) == 16 and seeds[0] == 2023

@@ -60,6 +60,34 @@ def test_rank_streams_differ_and_union_is_the_single_device_draw():
         assert abs(keep - 0.9) < 0.01
 
 
+def test_balanced_dealing_draws_the_single_device_batch():
+    """DeviceData(balance=B): the ranks take the rows of each global batch by cost (snake), and the sampler keys each row on
+    the position the dealing recorded -- so rank r's candidates / histories are rows `pos_r` of the one-device batch"""
+    from legommenders_amd.synthetic import init_naml_params
+    from legommenders_amd.train_step import DeviceData, TrainStep
+    dev, w, W, B = _dev(), _world(n_rows=202), 2, 8
+    P = init_naml_params(D=64, A=64, V=3000, seed=5)
+    ranks = [TrainStep("naml", P, DeviceData(w, dev, rank=r, world_size=W, seed=9, balance=B), B, seed=9, world_size=W) for r in range(W)]
+    one = TrainStep("naml", P, DeviceData(w, dev, seed=9), W * B, seed=9)
+    moved = False
+    for batch_idx in (0, 3, 12, one.steps_per_epoch + 1):              # incl. the short last batch and the reshuffled second epoch
+        nbs = [t.sample_batch(batch_idx, slot=0) for t in ranks]
+        nb1 = one.sample_batch(batch_idx, slot=0)
+        assert nbs[0] == nbs[1] and nb1 == W * nbs[0]
+        torch.cuda.synchronize()
+        epoch, start, nb = ranks[0].schedule.at(batch_idx)
+        g_c, g_h, g_l = one._cand[0].cpu(), one._hist[0].cpu(), one._hist_len[0].cpu()
+        seen = []
+        for r, t in enumerate(ranks):
+            pos = t.data.positions(epoch)[start:start + nb].cpu().long()
+            seen += pos.tolist()
+            moved |= pos.tolist() != list(range(r, W * nb, W))
+            assert torch.equal(t._cand[0][:nb].cpu(), g_c[pos]), (batch_idx, r)
+            assert torch.equal(t._hist[0][:nb].cpu(), g_h[pos]) and torch.equal(t._hist_len[0][:nb].cpu(), g_l[pos])
+        assert sorted(seen) == list(range(W * nb))
+    assert moved                                                        # the dealing is not r::W in disguise
+
+
 def _trajectory_single(kind, P, w, dev, B, steps, seed=9, **kw):
     from legommenders_amd.train_step import DeviceData, TrainStep
     one = TrainStep(kind, P, DeviceData(w, dev, seed=seed), B, seed=seed, dropout=False, total_steps=50, **kw)
@@ -109,16 +137,17 @@ def test_two_ranks_follow_the_single_device_trajectory(kind):
     np.testing.assert_allclose(rank_losses[:12], losses[:12], rtol=5e-5)
 
 
-def test_two_ranks_equal_single_device_parameters_whole_batches():
+@pytest.mark.parametrize("balance", [None, 8])
+def test_two_ranks_equal_single_device_parameters_whole_batches(balance):
     """an even row count, so both layouts see identical rows in every step, short last batch included: parameters after two
-    epochs agree to fp32 summation-order noise"""
+    epochs agree to fp32 summation-order noise -- with the blind r::W dealing and with the cost-balanced one"""
     from legommenders_amd.synthetic import init_naml_params
     from legommenders_amd.train_step import DeviceData, TrainStep
     dev, W, B = _dev(), 2, 8
     w = _world(n_rows=202)
     P = init_naml_params(D=64, A=64, V=3000, seed=5)
-    ranks = [TrainStep("naml", P, DeviceData(w, dev, rank=r, world_size=W, seed=9), B, seed=9, world_size=W, dropout=False,
-                       total_steps=50) for r in range(W)]
+    ranks = [TrainStep("naml", P, DeviceData(w, dev, rank=r, world_size=W, seed=9, balance=balance), B, seed=9, world_size=W,
+                       dropout=False, total_steps=50) for r in range(W)]
     steps = 2 * ranks[0].steps_per_epoch
     assert ranks[0].steps_per_epoch == 13 and ranks[0].schedule.at(12) == (0, 96, 5)
     for _ in range(steps):
@@ -149,7 +178,7 @@ def _gloo_rank(rank, world, port, out_dir, steps):
     torch.cuda.set_device(dev)
     w = _world(n_rows=202)
     P = init_naml_params(D=64, A=64, V=3000, seed=5)
-    ts = TrainStep("naml", P, DeviceData(w, dev, rank=rank, world_size=world, seed=9), 8, seed=9, world_size=world,
+    ts = TrainStep("naml", P, DeviceData(w, dev, rank=rank, world_size=world, seed=9, balance=8), 8, seed=9, world_size=world,
                    process_group=dist.group.WORLD, dropout=False, total_steps=50)
     for _ in range(steps):
         ts.step()                                                    # the product's own step, all-reduce included
@@ -171,6 +200,46 @@ def test_train_step_two_processes_on_one_gpu_over_gloo(tmp_path):
     P = init_naml_params(D=64, A=64, V=3000, seed=5)
     fp1, _ = _trajectory_single("naml", P, _world(n_rows=202), dev, 16, steps)
     _same_trajectory({k: v.cpu() for k, v in fp1.P.items()}, r0, P, fp1.names, steps)
+
+
+def _plugin_rank(rank, world, port, out_dir, steps):
+    """the plug-in route (PluginStep -> Legommender.forward through torch.ops.lego_hip.*) on two ranks WITH dropout: the
+    rank-folded Philox seed travels through the custom ops' int64 `seed` arguments (a 64-bit seed killed rank 1)"""
+    import torch.distributed as dist
+    os.chdir(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from legommenders_amd.config_init import get_configurations
+    from legommenders_amd.plugin_step import PluginStep
+    from legommenders_amd.engine import ItemTables
+    from legommenders_amd.train_step import DeviceData
+    from legommenders_amd.trainer import build_model, load_world
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    cfg = get_configurations(dict(data="config/data/synthetic.yaml", model="config/model/naml.yaml", embed="config/embed/glove.yaml",
+                                  batch_size=8, hidden_size=64, lr=0.001, cuda=0, world="small"))
+    cfg.seed = 2023
+    torch.manual_seed(2023)
+    world_tables = load_world(cfg.data, 2023)
+    model, _ = build_model(cfg, world_tables, dev)
+    model.attach_item_table(ItemTables(world_tables["title_tok"], world_tables["title_len"], world_tables["cat"], dev))
+    data = DeviceData(world_tables, dev, rank=rank, world_size=world, seed=2023, balance=8)
+    ps = PluginStep(model, data, 8, K=4, lr=1e-3, seed=2023, process_group=dist.group.WORLD, world_size=world)
+    from legommenders_amd import functional
+    assert 0 <= functional.SEED < 2 ** 63 and (functional.SEED != 2023) == (rank != 0)
+    losses = [float(ps.step()) for _ in range(steps)]
+    torch.cuda.synchronize()
+    torch.save({"P": {k: v.detach().cpu() for k, v in model.state_dict().items()}, "loss": losses},
+               os.path.join(out_dir, f"plugin{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_plugin_step_two_ranks_with_dropout(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_plugin_rank, args=(2, _free_port(), str(tmp_path), 4), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), f"plugin{r}.pt")) for r in range(2))
+    for k in r0["P"]:
+        assert torch.equal(r0["P"][k], r1["P"][k]), k                # the averaged gradient keeps the replicas identical
+    assert all(np.isfinite(r0["loss"])) and all(np.isfinite(r1["loss"])) and r0["loss"] != r1["loss"]
 
 
 def test_epoch_visits_every_row_once_and_reshuffles():
