@@ -42,6 +42,7 @@ struct EpiArgs {
     size_t tap_stride;        // C offset per tap (TN conv weight gradient)
     const int* row_off_dyn;   // device row offset of C / rowinfo / relu_ref rows
     int M, N, row_off;
+    int rows_form;            // gemm_dma.hpp: 1 = row-major epilogue through LDS (LEGO_EPI_ROWS=0: fragment-shaped stores, A/B)
 };
 
 template <bool ROWINFO, bool ACCUM, bool RELUREF, bool ATOMIC>
@@ -179,6 +180,72 @@ struct EpiT : EpiArgs {
             }
         }
     }
+    // The same epilogue in ROW-MAJOR form (gemm_dma.hpp): the wave's 32-column slab of accumulators goes through a wave-private
+    // LDS tile [NF*16][32] (ds_write_b32 two-way = free, ds_read_b128 conflict-free: tools/lds_swizzle_check.py notes), comes back
+    // as lane = (row lane >> 3 of a group of 8, 4 consecutive columns), and every global access of the epilogue -- the store,
+    // the previous C of an accumulation, the ReLU reference, the keep bits -- is a 16-B (4-B for the bits) access that covers
+    // whole 128-B lines: 8 rows x 128 B per wave-instruction instead of 4 rows x 64 B, a quarter of the store instructions.
+    // Measured on the 26 368 x 256 x 256 product: the fragment-shaped epilogue cost 12 us of a 42 us launch.
+    // Requires N % 4 == 0 and a precomputed keep-bit mask when dropout is on (else the caller takes run16).
+    __device__ __forceinline__ bool rows_form_ok() const { return rows_form != 0 && (N & 3) == 0 && (ldc & 3) == 0 && (drop.p <= 0.f || drop.mask != nullptr) &&
+                                                                  (!RELUREF || (ld_ref & 3) == 0) && (drop_cols & 3) == 0; }
+    template <int NF>
+    __device__ __forceinline__ void run16_rows(f32x4 (&acc)[NF][2], int m_base, int m_end, int n_base, int l16, int g4, float* tile) {
+        constexpr int LD = 32;
+#pragma unroll
+        for (int a = 0; a < NF; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tile[(a * 16 + 4 * g4 + i) * LD + b * 16 + l16] = acc[a][b][i];
+        const int lane = g4 * 16 + l16;
+        const int rsub = lane >> 3, col = n_base + 4 * (lane & 7);
+        const bool col_ok = col < N;
+        const int colc = min(col, N - 4);
+        const f32x4 b4 = bias != nullptr ? *reinterpret_cast<const f32x4*>(bias + colc) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float dinv = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+        const bool dropping = drop.p > 0.f;
+        f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+        for (int g = 0; g < NF * 2; ++g) {
+            const int r = m_base + 8 * g + rsub;
+            const bool ok = r < m_end && col_ok;
+            const int ra = min(r, m_end - 1) + row_off;
+            f32x4 x = *reinterpret_cast<const f32x4*>(tile + (8 * g + rsub) * LD + 4 * (lane & 7));
+            f32x4 old = f32x4{0.f, 0.f, 0.f, 0.f}, ref = f32x4{1.f, 1.f, 1.f, 1.f};
+            if constexpr (ACCUM) old = *reinterpret_cast<const f32x4*>(C + (size_t)ra * ldc + colc);
+            if constexpr (RELUREF) ref = *reinterpret_cast<const f32x4*>(relu_ref + (size_t)ra * ld_ref + colc);
+            const bool live = ROWINFO ? (rowinfo[ra] & RI_LIVE) != 0 : true;
+            uint32_t kw = 0x0f0f0f0fu;
+            if (dropping) kw = *reinterpret_cast<const uint32_t*>(drop.mask + (uint64_t)(ra >> 2) * (uint64_t)drop_cols + (uint64_t)colc);
+            kw >>= (ra & 3);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = x[i] + b4[i];
+                if (act == 1) v = fmaxf(v, 0.f);
+                else if (act == 2) v = fast_tanh(v);
+                if (ROWINFO && !live) v = 0.f;
+                v *= (kw >> (8 * i)) & 1u ? dinv : 0.f;
+                if (ACCUM) v += old[i];
+                if (RELUREF) v = ref[i] > 0.f ? v * relu_scale : 0.f;
+                x[i] = v;
+            }
+            if (ok) {
+                *reinterpret_cast<f32x4*>(C + (size_t)ra * ldc + col) = x;
+                cs += x;
+            }
+        }
+        if (colsum != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float sum = cs[i];
+                sum += __shfl_xor(sum, 8, 64);
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                if (rsub == 0 && col_ok) atomicAdd(colsum + col + i, sum);
+            }
+        }
+    }
 };
 
 using Epi = EpiArgs;      // host-side view; the kernel is instantiated with one EpiT<...> kind
@@ -186,6 +253,7 @@ using Epi = EpiArgs;      // host-side view; the kernel is instantiated with one
 }  // namespace lego
 #include "gemm_wino.hpp"
 #include "gemm_tn.hpp"
+#include "gemm_dma.hpp"
 namespace lego {
 
 static Epi make_epi(float* C, int ldc) {
@@ -194,6 +262,9 @@ static Epi make_epi(float* C, int ldc) {
     e.drop = make_dropout(nullptr); e.drop_cols = 1;
     e.relu_ref = nullptr; e.ld_ref = 0; e.relu_scale = 1.f; e.colsum = nullptr;
     e.tap_stride = 0; e.row_off_dyn = nullptr; e.M = e.N = e.row_off = 0;
+    static int rows_form = -1;
+    if (rows_form < 0) { const char* v = getenv("LEGO_EPI_ROWS"); rows_form = (v != nullptr && v[0] == '0') ? 0 : 1; }
+    e.rows_form = rows_form;
     return e;
 }
 static void set_drop(Epi& e, const lego_dropout* d, int cols) {
@@ -259,6 +330,29 @@ static int launch_strip(const GemmDims& d, const AL& a, const BL& b, const Epi& 
     return check_launch(what);
 }
 
+// the same split with LDS-DMA operand staging (gemm_dma.hpp): plain-row operands only
+template <bool B_MC, class EK, class BL>
+static int launch_dma_strip(const GemmDims& d, const KcRows& a, const BL& b, const Epi& e0, hipStream_t st, const char* what) {
+    EK e;
+    static_cast<EpiArgs&>(e) = e0;
+    auto k = dma_strip_kernel<B_MC, BL, EK>;
+    constexpr size_t lds = dma_lds_bytes<B_MC>();
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int n_panels = (d.N + STRIP_BN - 1) / STRIP_BN;
+    hipLaunchKernelGGL(k, dim3(num_cus() / n_panels * n_panels), dim3(STRIP_THREADS), lds, st, d, a, b, e);
+    return check_launch(what);
+}
+
+static int dma_mode() {            // A/B switch (tuning): LEGO_DMA=0 keeps the register-staged row-strip kernel
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("LEGO_DMA"); v = (e != nullptr && e[0] == '0') ? 0 : 1; }
+    return v;
+}
+
 // small latency-bound products: every load of a 64 x 64 x K block in flight at once (gemm_oneshot.hpp)
 template <bool B_MC, class EK, class AL, class BL>
 static int launch_oneshot(const GemmDims& d, const AL& a, const BL& b, const Epi& e0, hipStream_t st, const char* what) {
@@ -293,7 +387,11 @@ static int launch_light(const GemmDims& d, const AL& a, const BL& b, const Epi& 
 template <bool B_MC, class EK, class AL, class BL>
 static int launch_rows(const GemmDims& d, const AL& a, const BL& b, const Epi& e, hipStream_t st, const char* what) {
     const int tm = (d.M + 127) / 128;
-    if (d.M >= 32 * num_cus() && d.N <= 4 * STRIP_BN) return launch_strip<B_MC, EK>(d, a, b, e, st, what);
+    if (d.M >= 32 * num_cus() && d.N <= 4 * STRIP_BN) {
+        if constexpr (std::is_same<AL, KcRows>::value && (std::is_same<BL, KcRows>::value || std::is_same<BL, McRows>::value))
+            if (dma_mode() && d.K >= 4 && (!B_MC || d.N % 4 == 0)) return launch_dma_strip<B_MC, EK>(d, a, b, e, st, what);
+        return launch_strip<B_MC, EK>(d, a, b, e, st, what);
+    }
     if constexpr (std::is_same<AL, KcRows>::value)
         if (d.K <= 4 * ONE_KMAX && d.K % 4 == 0 &&
             ((d.M + ONE_BM - 1) / ONE_BM) * ((d.N + ONE_BN - 1) / ONE_BN) <= 3 * num_cus()) { // few rounds of whole-CU blocks by
@@ -576,6 +674,7 @@ extern "C" int lego_debug_gemm_nt(int variant, const float* x, const float* W, c
         case 7: return launch<TileCfg<128, 128, 4, 2, true>, false, false, EpiPlain>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, 1, st, "dbg7");
         case 8: return launch<TileCfg<128, 128, 2, 4, true>, false, false, EpiPlain>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, 1, st, "dbg8");
         case 9: return launch_strip<false, EpiPlain>(d, a, b, e, st, "dbg9");
+        case 10: return launch_dma_strip<false, EpiPlain>(d, a, b, e, st, "dbg10");
         default: return set_error("lego_debug_gemm_nt: unknown variant %d", variant);
     }
 }

@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Reference TRAINING band on a learnable world: tests/golden/train_band_{naml,nrms}.{json,npz}.
+
+Runs ONLY in the build container (needs /root/reference).  It drives the REAL reference -- its `Legommender`, its
+`Resampler` (negative sampling with python `random`), its `DataSet`, a `DataLoader(shuffle=True)` and the training loop of
+`trainer.py:184-204` (Adam + HF linear schedule, `base_lego.py:201-223`), torch dropout ON (0.1 at the reference's three
+sites) -- on `legommenders_amd.synthetic.make_learnable_world`, for several seeds, and scores the dev rows through the
+reference's own `Legommender.forward` (test phase) + `MetricPool` (`base_lego.py:400-427`, `utils/metrics.py`).
+
+Stored (data only): per seed GAUC / NDCG@10 / MRR before and after training, the mean training loss of the last 50 steps,
+Both sides start every seed from `synthetic.init_*_params(seed)` (loaded into the reference model by its own state_dict
+keys), so the MI355X run differs only in its random streams (Philox dropout, device sampler, its own shuffle).  `tests/test_train_band.py` (-m gpu) holds the HIP trainer's
+mean GAUC to the reference's mean within 0.002 + the reference's seed spread.
+
+    python tests/golden/make_train_band.py [naml|nrms ...]
+"""
+from __future__ import annotations
+
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+import make_golden as MG                                              # noqa: E402  (stubs + duck-typed tables)
+from legommenders_amd.synthetic import glove_table_np, init_naml_params, init_nrms_params, make_learnable_world   # noqa: E402
+
+WORLD = dict(seed=0, n_items=1200, n_users=900, n_rows=9600, V=3000, T=16, S=20, n_cat=18, neg_cap=20, p_pref=0.8,
+             p_topic=0.5, pool=30, n_dev_users=400, dev_neg=8)
+HYPER = dict(D=64, B=32, lr=1e-3, epochs=2, dropout=0.1, heads=8, K=4, glove_seed=77)
+SEEDS = (11, 12, 13, 14, 15, 16, 17, 18)
+METRICS = ["GAUC", "NDCG@10", "MRR"]
+
+
+def build(kind, w, seed):
+    """Manager.__init__ order (loader/manager.py:139-153,294-326) on duck-typed tables of the learnable world"""
+    from loader.env import Env
+    Env.device = torch.device("cpu")
+    from loader.column_map import ColumnMap
+    from loader.embedding_hub import EmbeddingHub
+    from loader.resampler import Resampler
+    from model.lego_config import LegoConfig
+    from model.legommender import Legommender
+    from model.operators.ada_operator import AdaOperator
+    from model.operators.attention_operator import AttentionOperator
+    from model.operators.cnn_operator import CNNOperator
+    from model.predictors.dot_predictor import DotPredictor
+    D, p, heads = HYPER["D"], HYPER["dropout"], HYPER["heads"]
+    glove_v, cat_v = MG.SizedVocab("glove", w["V"]), MG.SizedVocab("category", w["n_cat"])
+    item_v, user_v = MG.SizedVocab("item_id", w["n_items"]), MG.SizedVocab("user_id", w["n_users"])
+    hist = [w["user_hist"][u, : w["user_hist_len"][u]].tolist() for u in range(w["n_users"])]
+    neg = [w["neg_list"][u, : w["neg_len"][u]].tolist() for u in range(w["n_users"])]
+    item_rows = [{"item_id": i, "title@glove": w["title_tok"][i, : w["title_len"][i]].tolist(), "category": int(w["cat"][i])}
+                 for i in range(w["n_items"])]
+    item_ut = MG.FakeUT(item_rows, [MG.Feat("item_id", item_v), MG.Feat("title@glove", glove_v, w["T"]),
+                                    MG.Feat("category", cat_v)], "item_id")
+    user_rows = [{"user_id": u, "history": list(hist[u]), "neg": list(neg[u])} for u in range(w["n_users"])]
+    user_ut = MG.FakeUT(user_rows, [MG.Feat("user_id", user_v), MG.Feat("history", item_v, w["S"]),
+                                    MG.Feat("neg", item_v, w["neg_cap"])], "user_id")
+
+    def inter(users, items, labels):
+        rows = [{"index": r, "user_id": int(users[r]), "item_id": int(items[r]), "click": int(labels[r]),
+                 "history": list(hist[users[r]]), "neg": list(neg[users[r]])} for r in range(len(users))]
+        return MG.FakeUT(rows, [MG.Feat("index", MG.SizedVocab("index", len(rows))), MG.Feat("user_id", user_v),
+                                MG.Feat("item_id", item_v), MG.Feat("click", MG.SizedVocab("click", 2)),
+                                MG.Feat("history", item_v, w["S"]), MG.Feat("neg", item_v, w["neg_cap"])], "index")
+    train_ut = inter(w["row_user"], w["row_item"], np.ones(w["n_rows"], dtype=np.int64))
+    v = w["valid"]
+    dev_ut = inter(v["user"], v["item"], v["label"])
+    if kind == "naml":
+        lc = LegoConfig(hidden_size=D, item_hidden_size=D, neg_count=HYPER["K"],
+                        user_config={"inputer_config": {"use_cls_token": False, "use_sep_token": False}},
+                        item_config={"dropout": p, "kernel_size": 3})
+        lc.set_component_classes(CNNOperator, AdaOperator, DotPredictor)
+    else:
+        lc = LegoConfig(hidden_size=D, item_hidden_size=D, neg_count=HYPER["K"],
+                        item_config={"num_attention_heads": heads, "attention_dropout": p,
+                                     "inputer_config": {"use_cls_token": False, "use_sep_token": True}},
+                        user_config={"num_attention_heads": heads, "attention_dropout": p,
+                                     "inputer_config": {"use_cls_token": False, "use_sep_token": False}})
+        lc.set_component_classes(AttentionOperator, AttentionOperator, DotPredictor)
+    lc.set_item_ut(item_ut, ["title@glove", "category"])
+    lc.set_user_ut(user_ut, ["history"])
+    lc.set_column_map(ColumnMap(item_col="item_id", user_col="user_id", history_col="history", neg_col="neg",
+                                label_col="click", group_col="user_id"))
+    eh = EmbeddingHub(embedding_dim=D, transformation="auto", transformation_dropout=p)
+    path = "/tmp/_band_glove_%d_%d.npy" % (HYPER["glove_seed"], w["V"])
+    np.save(path, glove_table_np(HYPER["glove_seed"], w["V"]))
+    eh.load_pretrained_embedding(path, vocab_name="glove", frozen=True)
+    eh.register_ut(item_ut, ["title@glove", "category"])
+    lc.set_embedding_hub(eh)
+    lc.build_components()
+    lc.register_inputer_vocabs()
+    torch.manual_seed(seed)                       # the model's initial parameters are a function of the seed alone
+    model = Legommender(lc)
+    return model, Resampler(lc), train_ut, dev_ut
+
+
+def evaluate(model, resampler, dev_ut):
+    """base_lego.py:349-427: test-phase scores of every dev row, then the reference's MetricPool"""
+    from loader.data_set import DataSet
+    from loader.env import Env
+    from torch.utils.data import DataLoader
+    from utils.metrics import MetricPool
+    Env.test()
+    model.eval()
+    loader = DataLoader(DataSet(dev_ut, resampler), batch_size=200, shuffle=False)
+    scores, labels, groups = [], [], []
+    with torch.no_grad():
+        for batch in loader:
+            s = model(batch=batch)
+            scores.append(s.squeeze(1) if s.dim() == 2 else s)
+            labels.append(batch["click"])
+            groups.append(batch["user_id"])
+    scores, labels, groups = torch.cat(scores), torch.cat(labels), torch.cat(groups)
+    res = MetricPool.parse(METRICS).calculate(scores.tolist(), labels.tolist(), groups.tolist())
+    return {k: float(v) for k, v in res.items()}
+
+
+def run_seed(kind, w, seed):
+    from loader.data_set import DataSet
+    from loader.env import Env
+    from torch.utils.data import DataLoader
+    from transformers import get_linear_schedule_with_warmup
+    random.seed(seed); np.random.seed(seed)                           # utils/function.py:58-75 (seeding)
+    model, resampler, train_ut, dev_ut = build(kind, w, seed)
+    # initial parameters: OUR seeded initialiser (torch CPU generator: the same values on the GPU box), loaded into the reference
+    # model by its own state_dict keys -- both sides then start from the same point without a parameter fixture
+    A = int(model.state_dict()["item_op.additive_attention.encoder.0.weight"].shape[0])
+    glove = torch.from_numpy(glove_table_np(HYPER["glove_seed"], w["V"]))
+    if kind == "naml":
+        P = init_naml_params(D=HYPER["D"], A=A, V=w["V"], n_cat=w["n_cat"], seed=seed, glove=glove)
+    else:
+        P = init_nrms_params(D=HYPER["D"], A=A, V=w["V"], n_cat=w["n_cat"], heads=HYPER["heads"], seed=seed, glove=glove)
+    assert set(P) == set(model.state_dict()), set(P) ^ set(model.state_dict())
+    for k, v in model.state_dict().items():
+        assert tuple(v.shape) == tuple(P[k].shape), (k, v.shape, P[k].shape)
+    model.load_state_dict(P)
+    init = dict(A=A)
+    before = evaluate(model, resampler, dev_ut)
+    B, epochs = HYPER["B"], HYPER["epochs"]
+    opt = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=HYPER["lr"])   # base_lego.py:201-204
+    sched = get_linear_schedule_with_warmup(opt, num_warmup_steps=0, num_training_steps=len(train_ut) // B * epochs)
+    torch.manual_seed(seed + 1000)                                    # shuffle + dropout streams
+    loader = DataLoader(DataSet(train_ut, resampler), batch_size=B, shuffle=True)               # manager.py:374-381
+    losses = []
+    opt.zero_grad()
+    for epoch in range(epochs):                                       # trainer.py:184-204
+        model.train()
+        Env.train()
+        for batch in loader:
+            loss = model(batch=batch)
+            loss.backward()
+            opt.step()
+            sched.step()
+            opt.zero_grad()
+            losses.append(float(loss))
+    after = evaluate(model, resampler, dev_ut)
+    return init, dict(seed=seed, before=before, after=after, steps=len(losses), first_loss=float(np.mean(losses[:20])),
+                      last_loss=float(np.mean(losses[-50:])))
+
+
+def main():
+    kinds = sys.argv[1:] or ["naml", "nrms"]
+    MG.install_stubs()
+    torch.set_num_threads(8)
+    w = make_learnable_world(**WORLD)
+    for kind in kinds:
+        runs, inits = [], {}
+        for seed in SEEDS:
+            t0 = time.time()
+            init, r = run_seed(kind, w, seed)
+            runs.append(r)
+            inits.update(init)
+            print(kind, seed, "GAUC %.4f -> %.4f" % (r["before"]["GAUC"], r["after"]["GAUC"]), "NDCG@10 %.4f" % r["after"]["NDCG@10"],
+                  "loss %.4f -> %.4f" % (r["first_loss"], r["last_loss"]), "%.0f s" % (time.time() - t0), flush=True)
+        g = np.array([r["after"]["GAUC"] for r in runs])
+        out = dict(kind=kind, world=WORLD, hyper=dict(HYPER, **inits), metrics=METRICS, runs=runs,
+                   init="legommenders_amd.synthetic.init_%s_params(D, A, V, n_cat, seed=run seed, glove=glove_table_np(glove_seed, V))" % kind,
+                   mean={m: float(np.mean([r["after"][m] for r in runs])) for m in METRICS},
+                   spread={m: float(np.max([r["after"][m] for r in runs]) - np.min([r["after"][m] for r in runs])) for m in METRICS},
+                   std={m: float(np.std([r["after"][m] for r in runs], ddof=1)) for m in METRICS},
+                   mean_before={m: float(np.mean([r["before"][m] for r in runs])) for m in METRICS},
+                   torch=torch.__version__,
+                   note="reference run: torch dropout, python-random negatives, DataLoader(shuffle=True), num_workers=0")
+        json.dump(out, open(os.path.join(HERE, f"train_band_{kind}.json"), "w"), indent=1)
+        print(kind, "mean GAUC %.4f spread %.4f" % (g.mean(), g.max() - g.min()))
+
+
+if __name__ == "__main__":
+    main()

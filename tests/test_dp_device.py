@@ -207,14 +207,16 @@ def _plugin_rank(rank, world, port, out_dir, steps):
     rank-folded Philox seed travels through the custom ops' int64 `seed` arguments (a 64-bit seed killed rank 1)"""
     import torch.distributed as dist
     os.chdir(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from legommenders_amd.config_init import get_configurations
+    from legommenders_amd.trainer import get_configurations
     from legommenders_amd.plugin_step import PluginStep
     from legommenders_amd.engine import ItemTables
     from legommenders_amd.train_step import DeviceData
-    from legommenders_amd.trainer import build_model, load_world
+    from legommenders_amd.trainer import build_model, load_world  # noqa: E402
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
+    from legommenders_amd.loader.env import Env
+    Env.set_device(0)
     cfg = get_configurations(dict(data="config/data/synthetic.yaml", model="config/model/naml.yaml", embed="config/embed/glove.yaml",
                                   batch_size=8, hidden_size=64, lr=0.001, cuda=0, world="small"))
     cfg.seed = 2023

@@ -8,19 +8,25 @@ P, I = ctypes.c_void_p, ctypes.c_int
 L.lego_debug_gemm_nt.argtypes = [I, P, P, P, P, I, I, I, P]
 L.lego_debug_gemm_nt.restype = I
 dev = torch.device('cuda:0')
+VARIANTS = tuple(int(v) for v in sys.argv[1].split(',')) if len(sys.argv) > 1 else (9, 10)
+_blocker = torch.zeros(1 << 27, dtype=torch.float32, device=dev)
 def bench(fn, n=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()
+    for _ in range(3): _blocker.add_(1.0)      # ~1 ms of queued work: the host enqueues the timed launches while it runs
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-names = {0: "128x128 4w(2x2)", 1: "128x128 8w(2x4)", 2: "256x128 8w(4x2)", 3: "128x256 8w(2x4)", 4: "64x128 4w(1x4)", 5: "128x128 8w(4x2)", 6: "64x256 4w(1x4)", 7: "128x128 8w(4x2) stag", 8: "128x128 8w(2x4) stag", 9: "strip 16x16x4"}
-for (M, N, Kd) in [(26368, 256, 768), (24000, 256, 768), (28672, 256, 768), (32768, 256, 768), (65536, 256, 768), (26368, 256, 256), (26368, 256, 300), (26368, 200, 256), (1000, 256, 768), (26368+5, 240, 96), (3200, 200, 256), (3200, 256, 256), (3520, 256, 256), (6400, 256, 256)]:
+names = {0: "128x128 4w(2x2)", 1: "128x128 8w(2x4)", 2: "256x128 8w(4x2)", 3: "128x256 8w(2x4)", 4: "64x128 4w(1x4)", 5: "128x128 8w(4x2)", 6: "64x256 4w(1x4)", 7: "128x128 8w(4x2) stag", 8: "128x128 8w(2x4) stag", 9: "strip 16x16x4", 10: "strip LDS-DMA"}
+SHAPES = [(26368, 256, 768), (24000, 256, 768), (28672, 256, 768), (32768, 256, 768), (65536, 256, 768), (26368, 256, 256), (26368, 256, 300), (26368, 200, 256), (1000, 256, 768), (26368+5, 240, 96), (3200, 200, 256), (3200, 256, 256), (3520, 256, 256), (6400, 256, 256), (26368, 768, 256), (30720, 768, 300), (105600, 256, 256), (26368, 256, 32), (26368, 256, 4), (26368, 256, 36)]
+if len(sys.argv) > 2 and sys.argv[2] == 'short':
+    SHAPES = [(26368, 256, 768), (26368, 256, 256), (26368, 256, 300), (30720, 768, 256), (105600, 256, 256), (6400, 256, 256)]
+for (M, N, Kd) in SHAPES:
     x = torch.randn(M, Kd, device=dev); W = torch.randn(N, Kd, device=dev) * 0.05; b = torch.randn(N, device=dev)
     ref = x @ W.T + b
-    for v in (9,):
+    for v in VARIANTS:
         y = torch.zeros(M, N, device=dev)
         def run():
             rc = L.lego_debug_gemm_nt(v, x.data_ptr(), W.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, Kd, None)

@@ -2,7 +2,7 @@
 # VGPR / spill / scratch / LDS of every kernel in a HIP source: tools/regs.sh legommenders_amd/csrc/gemm_ops.hip [filter]
 src=$1; filt=${2:-.}
 out=/tmp/regs_$$.s
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S "$src" -o $out 2>/dev/null
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S $EXTRA "$src" -o $out 2>/dev/null
 python3 - "$out" "$filt" <<'PY'
 import re, sys, subprocess
 txt = open(sys.argv[1]).read()
