@@ -19,7 +19,7 @@ steps / ms so the driver's wall clock still bounds them):
   roofline_gather    the GloVe row gather: `frac_in_step` = in-step duration on the prefetch stream (HIP events there,
                      overlapped with the previous step's user-side chain); `frac` = back-to-back standalone launches
                      (cache-assisted: most rows then hit the Infinity Cache)
-  long_run           >= 200 steps of the same configuration when --steps is smaller (a 20-step window is 14 ms)
+  long_run           2000 steps of the same configuration when --steps is smaller (a 20-step window is 14 ms)
   secondary          NRMS config 3 (with its dominant-kernel roofline), the worst-case dense NAML world (every history
                      50, every title 30 tokens) and a world with MIND-like length statistics are NOT the metric; they are printed so that the number's dependence
                      on the model and on raggedness is on record
@@ -60,6 +60,7 @@ def parse():
                     help="nrms only: null = trainable [V, hidden] token table (config/embed/null.yaml) instead of frozen GloVe + Linear")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the long run and the secondary configurations")
+    ap.add_argument("--no-bert", action="store_true", help="skip the BERT-base secondary line (config 5)")
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--time-every", type=int, default=4, help="bracket the roofline kernel and the in-step gather with HIP events every N-th timed step")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even at world size 1 (path check)")
@@ -68,17 +69,37 @@ def parse():
     return ap.parse_args()
 
 
-def pmc_traffic():
-    """HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, run separately --
-    counters cannot be read from inside this process); newest profiles/r*_traffic.json, else {}."""
+def kernel_sources_sha():
+    """sha256 (16 hex) over the HIP sources the kernels are built from: a PMC summary is valid for exactly one such tree"""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "legommenders_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic():
+    """HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, run separately -- counters cannot be
+    read from inside this process): the newest profiles/r*_traffic.json, ONLY when it was taken on the kernel sources of this
+    tree (`kernel_sources_sha` recorded by tools/traffic_from_pmc.py).  Returns (bytes per tag, source record); a stale or
+    unmarked file yields no bytes and says so in the record -- `roofline.traffic` is then null rather than a number measured
+    on other kernels (VERDICT r2 weak #9a)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
+    now = kernel_sources_sha()
     if not files:
-        return {}
+        return {}, {"file": None, "stale": True, "kernel_sources_sha": now}
     try:
-        return {k: v.get("hbm_bytes_per_launch") for k, v in json.load(open(files[-1]))["kernels"].items()}
+        d = json.load(open(files[-1]))
     except Exception:
-        return {}
+        return {}, {"file": os.path.relpath(files[-1], ROOT), "stale": True, "kernel_sources_sha": now}
+    src = {"file": os.path.relpath(files[-1], ROOT), "taken_on_kernel_sources_sha": d.get("kernel_sources_sha"),
+           "taken_on_commit": d.get("commit"), "kernel_sources_sha": now, "stale": d.get("kernel_sources_sha") != now}
+    if src["stale"]:
+        return {}, src
+    return {k: v.get("hbm_bytes_per_launch") for k, v in d["kernels"].items()}, src
 
 
 def cpu_baseline(world, B, D, steps):
@@ -336,8 +357,10 @@ def main():
         kern[k] = v
     for k in kern:
         kern[k]["overlapped"] = k not in solo and not k.startswith("gather_rows")
-    traffic = pmc_traffic()
+    traffic, traffic_src = pmc_traffic()
     roofline = dominant(kern, flops, solo, traffic)
+    if roofline is not None:
+        roofline["traffic_source"] = traffic_src
     roofline_gather = None
     if gather_ms:
         gbytes = gather_rows * E0 * 4 * 2 + gather_rows * 4     # row read + row write + index
@@ -352,7 +375,10 @@ def main():
         if ins and ins["avg_ms"] > 0:
             b_in = rows_per_launch * (E0 * 4 * 2 + 4)
             g_in = b_in / (ins["avg_ms"] * 1e-3) / 1e9
+            g_rd = rows_per_launch * E0 * 4 / (ins["avg_ms"] * 1e-3) / 1e9        # the row READS only
             roofline_gather.update({"achieved_in_step": round(g_in, 1), "frac_in_step": round(g_in / PEAK_HBM_GBS, 4),
+                                    "achieved_reads_only_in_step": round(g_rd, 1),
+                                    "frac_reads_only_in_step": round(g_rd / PEAK_HBM_GBS, 4),
                                     "avg_launch_ms_in_step": round(ins["avg_ms"], 5), "launches_in_step": ins["launches"],
                                     "timed_in_step": "HIP events on the prefetch stream inside the timed region (the gather of "
                                                      "batch N+1 runs beside batch N's user-side chain)"})
@@ -374,9 +400,10 @@ def main():
         torch.distributed.all_reduce(seen)
         extra["ranks_seen"] = int(seen.item())
     if world_size == 1 and not dist_on and not args.no_secondary and not args.small:
-        if args.steps < 200:                       # the same configuration over a window long enough to average out jitter
-            dl, _, _ = timed_steps(ts, 200, 0, barrier)
-            extra["long_run"] = {"steps": 200, "ms_per_step": round(dl / 200 * 1e3, 4), "value": round(B * 200 / dl, 1),
+        if args.steps < 2000:                      # the same configuration over a window long enough to average out jitter (and
+            n_long = 2000                          # for a once-a-second GPU-busy sampler to see the device at work: ~1.3 s)
+            dl, _, _ = timed_steps(ts, n_long, 0, barrier)
+            extra["long_run"] = {"steps": n_long, "ms_per_step": round(dl / n_long * 1e3, 4), "value": round(B * n_long / dl, 1),
                                  "unit": "impressions/s"}
         sec = {}
         del ts
@@ -425,6 +452,25 @@ def main():
             "live_token_rows_per_step": round(c4[0] / 100, 1), "item_instances_per_step": round(c4[1] / 100, 1)}
         del t4, dm
         torch.cuda.empty_cache()
+        # config 5: BERT-base news encoder through the plug-in route (random-init BertConfig() defaults = bert-base-uncased
+        # shapes; the blocks run in PyTorch-ROCm as SURVEY.md 8f-2 prescribes, gather / Linear / pools / dot + CE on the
+        # path's kernels).  Both modes the reference has: tune_from = 0 (11 blocks train) and cached-layer (tune_from = 9:
+        # layer-9 states of every item resident in HBM, 2 blocks train).  Few steps: a step is 0.1-0.6 s.
+        if not args.no_bert:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bert_naml_bench
+            from legommenders_amd.loader.env import Env
+            bsec = {}
+            for name, tf, st in (("tune_from_0", 0, 3), ("tune_from_9_cached_layer", 9, 10)):
+                r = bert_naml_bench.run(batch=B, steps=st, warmup=1, layers=12, hidden=D, tune_from=tf)
+                bsec[name] = {"steps": st, "warmup": 1, "ms_per_step": round(r["s_per_step"] * 1e3, 2), "value": r["impressions_per_s"],
+                              "unit": "impressions/s", "bert_blocks_run": r["bert_layers_run"], "trainable_params": r["trainable_params"],
+                              "layer_cache_s": r["layer_cache_s"], "layer_cache_GB": r["layer_cache_GB"], "final_loss": round(r["loss"], 4)}
+                torch.cuda.empty_cache()
+            Env.set_lm_cache(False)
+            sec["bert_naml_base"] = dict(bsec, workload=f"MIND-small-shaped BERT-NAML (BASELINE config 5): BertConfig() defaults "
+                                         f"(768 x 12 blocks x 12 heads, random init), item_page_size 64 in the yaml, hidden={D} bs={B}, "
+                                         f"5 000-item world, full plug-in train step (device sampler ids, fwd, bwd, torch Adam), fp32")
         extra["secondary"] = sec
 
     if rank != 0:

@@ -263,6 +263,52 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
     }
 }
 
+// The same gather as ONE WAVE PER DESTINATION ROW, four rows in flight per wave (MI355X_MICROARCH.md, "Indexed rows": random
+// 1 152-B rows gathered into registers read at 5.5-5.8 TB/s in this shape): a row is w4 <= 128 pieces of 16 B, lane l moves
+// pieces l and l + 64; the row index is wave-uniform (scalar load), there is no per-element division, and every row's pieces
+// are contiguous in one instruction.  Rows are dealt to waves round-robin so that neighbouring waves write neighbouring rows.
+__global__ __launch_bounds__(256) void gather_rows_wave_kernel(const float* __restrict__ table, int ld_table, int w4,
+                                                               const int* __restrict__ idx, int rows_cap,
+                                                               const int* __restrict__ rows_dyn, float* __restrict__ out, int ld_out,
+                                                               int accumulate) {
+    const int rows = rows_dyn != nullptr ? min(rows_cap, *rows_dyn) : rows_cap;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    const int n_waves = gridDim.x * (blockDim.x >> 6);
+    constexpr int U = 4;
+    const bool two = lane + 64 < w4, one = lane < w4;
+    for (int r0 = wave; r0 < rows; r0 += U * n_waves) {
+        f32x4 a[U], b[U];
+        int src[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + u * n_waves;
+            src[u] = r < rows ? idx[r] : -1;                    // wave-uniform
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            a[u] = b[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (src[u] >= 0) {
+                const f32x4* row = reinterpret_cast<const f32x4*>(table + (size_t)src[u] * ld_table);
+                if (one) a[u] = row[lane];
+                if (two) b[u] = row[lane + 64];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + u * n_waves;
+            if (r >= rows) continue;
+            f32x4* dst = reinterpret_cast<f32x4*>(out + (size_t)r * ld_out);
+            if (accumulate) {
+                if (src[u] >= 0) { if (one) dst[lane] += a[u]; if (two) dst[lane + 64] += b[u]; }
+            } else {
+                if (one) dst[lane] = a[u];
+                if (two) dst[lane + 64] = b[u];
+            }
+        }
+    }
+}
+
 // NRMS sequence rows: the plan's row_tok word encodes token id (>= 0), SEP (-2) or category (-(3+cat))
 __global__ void nrms_decode_rows_kernel(const int* __restrict__ row_tok, int R_cap, const int* __restrict__ R_dyn,
                                         int* idx_tok, int* idx_special, int* idx_cat, int* tokinfo) {
@@ -1181,6 +1227,15 @@ extern "C" int lego_gather_rows(const float* table, int ld_table, int width, con
                                 const int32_t* rows_dyn, float* out, int ld_out, int accumulate, void* stream) {
     LEGO_REQUIRE((width & 3) == 0 && (ld_table & 3) == 0 && (ld_out & 3) == 0, "lego_gather_rows: width/ld must be multiples of 4");
     if (rows_cap <= 0) return 0;
+    static int wave_form = -1;                       // LEGO_GATHER_WAVE=0: the flat float4 stream (A/B)
+    if (wave_form < 0) { const char* v = getenv("LEGO_GATHER_WAVE"); wave_form = (v != nullptr && v[0] == '0') ? 0 : 1; }
+    if (wave_form && width >= 64 * 4 && width <= 128 * 4) {          // rows of 1-2 KB: one wave per row, 16 waves per CU
+        const int want_blocks = (rows_cap + 4 * 4 - 1) / (4 * 4);     // 4 waves per block x 4 rows in flight
+        const int blocks = want_blocks < 1024 ? (want_blocks > 0 ? want_blocks : 1) : 1024;
+        hipLaunchKernelGGL(gather_rows_wave_kernel, dim3(blocks), dim3(256), 0, ST, table, ld_table, width / 4, idx, rows_cap, rows_dyn, out,
+                           ld_out, accumulate);
+        return check_launch("lego_gather_rows");
+    }
     const long long total = (long long)rows_cap * (width / 4);
     const long long want = (total + 4 * 256 - 1) / (4 * 256);
     const int blocks = (int)(want < 8192 ? (want > 0 ? want : 1) : 8192);

@@ -10,15 +10,10 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--layers", type=int, default=12)
-    ap.add_argument("--hidden", type=int, default=256)
-    ap.add_argument("--tune_from", type=int, default=0, help="k > 0: cached-layer mode, blocks [k+1:] train on the HBM-resident layer-k cache")
-    a = ap.parse_args()
+def run(batch=64, steps=5, warmup=2, layers=12, hidden=256, tune_from=0, n_items=5000, item_page_size=64):
+    """build the model, run `warmup` + `steps` training steps; returns the result record (also used by bench.py's
+    `secondary.bert_naml_base`)"""
+    a = argparse.Namespace(batch=batch, steps=steps, warmup=warmup, layers=layers, hidden=hidden, tune_from=tune_from)
     from legommenders_amd.engine import ItemTables
     from legommenders_amd.loader.class_hub import ClassHub
     from legommenders_amd.loader.column_map import ColumnMap
@@ -30,7 +25,7 @@ def main():
     from legommenders_amd.synthetic import MIND_SMALL, make_world
     dev = torch.device("cuda:0")
     Env.set_device(dev)
-    cfg = dict(MIND_SMALL); cfg.update(n_items=5000, n_users=4000, n_rows=20000, V=30522)
+    cfg = dict(MIND_SMALL); cfg.update(n_items=n_items, n_users=4000, n_rows=20000, V=30522)
     w = make_world(seed=2023, **cfg)
     H, D, V = 768, a.hidden, cfg["V"]
     n_items = w["title_tok"].shape[0]
@@ -43,7 +38,7 @@ def main():
     bert = dict(vocab_size=V, hidden_size=H, num_hidden_layers=a.layers, num_attention_heads=12, intermediate_size=3072,
                 max_position_embeddings=512)
     ops, preds = ClassHub.operators(), ClassHub.predictors()
-    lc = LegoConfig(hidden_size=D, item_hidden_size=H, neg_count=4,
+    lc = LegoConfig(hidden_size=D, item_hidden_size=H, neg_count=4, item_page_size=item_page_size,     # bert-naml.yaml: 64
                     user_config={"inputer_config": {"use_cls_token": False, "use_sep_token": False}},
                     item_config={"tune_from": a.tune_from, "use_lora": False, "lora_r": None, "lora_alpha": None,
                                  "inputer_config": {"use_cls_token": False, "use_sep_token": False}, "transformer_config": bert})
@@ -91,10 +86,23 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     n_par = sum(p.numel() for p in model.parameters() if p.requires_grad)
-    print({"model": "BERT-NAML plug-in route", "batch": B, "bert_layers_run": len(model.item_op.transformer.encoder.layer),
+    return ({"model": "BERT-NAML plug-in route", "batch": B, "bert_layers_run": len(model.item_op.transformer.encoder.layer),
            "trainable_params": n_par, "s_per_step": round(dt, 4), "impressions_per_s": round(B / dt, 1), "loss": float(loss.detach()),
-           "tune_from": a.tune_from, "layer_cache_s": round(t_cache, 3) if a.tune_from else None,
+           "item_page_size": item_page_size, "tune_from": a.tune_from, "layer_cache_s": round(t_cache, 3) if a.tune_from else None,
            "layer_cache_GB": round(model.item_op.hidden_weights.numel() * 4 / 1e9, 3) if a.tune_from else None})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--tune_from", type=int, default=0, help="k > 0: cached-layer mode, blocks [k+1:] train on the HBM-resident layer-k cache")
+    ap.add_argument("--item_page_size", type=int, default=64, help="items per transformer call (config/model/bert-naml.yaml: 64; 0 = all at once)")
+    a = ap.parse_args()
+    print(run(a.batch, a.steps, a.warmup, a.layers, a.hidden, a.tune_from, item_page_size=a.item_page_size))
 
 
 if __name__ == "__main__":

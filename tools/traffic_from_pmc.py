@@ -11,7 +11,7 @@ from collections import defaultdict
 
 def tag_of(name):
     n = name.replace("lego::", "")
-    if n.startswith("gather_rows_kernel"):
+    if n.startswith("gather_rows_kernel") or n.startswith("gather_rows_wave_kernel"):
         return "gather_rows"
     if "wino_kernel<false>" in n:
         return "conv3_fwd"
@@ -24,6 +24,9 @@ def tag_of(name):
     m = re.match(r"(?:void )?(mhsa_(?:fwd|bwd)_kernel)<(\d+), (\d+)>", n)
     if m:
         return f"{m.group(1)}<{m.group(2)},{m.group(3)}>"
+    if "dma_strip_kernel" in n:
+        ep = re.search(r"EpiT<([^>]*)>", n).group(1).replace("false", "0").replace("true", "1").replace(" ", "")
+        return "dma_strip<%s,%s>" % ("NN" if "McRows" in n else "NT", ep)
     if "strip_kernel" in n and "KcConvA" in n and "KcTapW" in n:
         return "conv3_fwd"
     if "strip_kernel" in n and "KcConvA" in n:
@@ -61,7 +64,14 @@ def main():
         wk = sum(wv) / max(1, len(wv))
         kernels[t] = {"FETCH_SIZE": fk, "WRITE_SIZE": wk, "fetch_bytes_corrected": fk * 1024 * 2, "write_bytes": wk * 1024,
                       "hbm_bytes_per_launch": fk * 1024 * 2 + wk * 1024, "launches_averaged": [len(fv), len(wv)]}
-    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `LEGO_SERIAL=1 bench.py --steps 20 "
+    import os, subprocess
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    try:
+        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except Exception:
+        commit = None
+    json.dump({"kernel_sources_sha": bench.kernel_sources_sha(), "commit": commit, "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `LEGO_SERIAL=1 bench.py --steps 20 "
                        "--warmup 5`; KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B "
                        "for 16 B/lane coalesced reads); averages over the last 3/4 of the launches",
                "kernels": kernels}, open(out, "w"), indent=1)
