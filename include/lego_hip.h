@@ -71,6 +71,10 @@ int lego_gather_rows(const float* table, int ld_table, int width, const int32_t*
 /* backward of a TRAINABLE table (embed/null.yaml): grad_table[idx[r]] += g[r] (dense grad semantics) */
 int lego_scatter_add_rows(float* grad_table, int ld_table, int width, int table_rows /*<= 32: LDS pre-reduction*/,
                           const int32_t* idx, int rows_cap, const int32_t* rows_dyn, const float* g, int ld_g, void* stream);
+/* the same for destination rows in [row_lo, row_hi) only: the 410 MB table gradient of embed/null is produced bucket by bucket
+ * under data parallelism, so that bucket k is all-reduced while bucket k+1 is scattered (train_step.TrainStep.exchange hooks) */
+int lego_scatter_add_rows_range(float* grad_table, int ld_table, int width, const int32_t* idx, int rows_cap,
+                                const int32_t* rows_dyn, const float* g, int ld_g, int row_lo, int row_hi, void* stream);
 
 /* ---- a4/a5/a6/a8: Linear layers.  out[M,N] = act(x[M,K] . W[N,K]^T + bias) * live * dropout.
  * act: 0 none (nn.Linear: embedding_hub.py:95, cnn_operator.py:59, attention_operator.py:56),

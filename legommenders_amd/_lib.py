@@ -42,6 +42,7 @@ SIGNATURES = {
     "lego_attn_fold_prepare": [P, P, P, P, P, P, P, P, P, P, I, I, P],
     "lego_attn_fold_grads": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P],
     "lego_scatter_add_rows": [P, I, I, I, P, I, P, P, I, P],
+    "lego_scatter_add_rows_range": [P, I, I, P, I, P, P, I, I, I, P],
     "lego_linear_fwd": [P, I, P, I, P, P, I, I, P, I, I, I, P, P, P, P, P],
     "lego_linear_bwd_data": [P, I, P, I, P, I, I, P, I, I, I, P, I, F, P, P, P, P, P, P],
     "lego_linear_bwd_weight": [P, I, P, I, P, I, I, P, I, I, P, P, P],

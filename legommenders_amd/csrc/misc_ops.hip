@@ -407,15 +407,18 @@ __global__ void dropout_mask_kernel(Dropout d, int rows_cap, const int* __restri
     }
 }
 
+// (row_lo, row_hi): only destination rows in [row_lo, row_hi) are touched -- the table gradient is produced bucket by
+// bucket, so that bucket k is on the wire while bucket k+1 is still being scattered (train_step.TrainStep, world > 1)
 __global__ void scatter_add_rows_kernel(float* grad_table, int ld_table, int width, const int* __restrict__ idx,
-                                        int rows_cap, const int* __restrict__ rows_dyn, const float* __restrict__ g, int ld_g) {
+                                        int rows_cap, const int* __restrict__ rows_dyn, const float* __restrict__ g, int ld_g,
+                                        int row_lo, int row_hi) {
     const int rows = rows_dyn != nullptr ? min(rows_cap, *rows_dyn) : rows_cap;
     const long long total = (long long)rows * width;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int r = (int)(e / width);
         const int c = (int)(e - (long long)r * width);
         const int i = idx[r];
-        if (i >= 0) atomicAdd(grad_table + (size_t)i * ld_table + c, g[(size_t)r * ld_g + c]);
+        if (i >= row_lo && i < row_hi) atomicAdd(grad_table + (size_t)i * ld_table + c, g[(size_t)r * ld_g + c]);
     }
 }
 
@@ -1288,8 +1291,20 @@ extern "C" int lego_scatter_add_rows(float* grad_table, int ld_table, int width,
     }
     const long long total = (long long)rows_cap * width;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(blocks), dim3(256), 0, ST, grad_table, ld_table, width, idx, rows_cap, rows_dyn, g, ld_g);
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(blocks), dim3(256), 0, ST, grad_table, ld_table, width, idx, rows_cap, rows_dyn, g, ld_g,
+                       0, 0x7fffffff);
     return check_launch("lego_scatter_add_rows");
+}
+
+extern "C" int lego_scatter_add_rows_range(float* grad_table, int ld_table, int width, const int32_t* idx, int rows_cap,
+                                           const int32_t* rows_dyn, const float* g, int ld_g, int row_lo, int row_hi, void* stream) {
+    LEGO_REQUIRE(row_lo >= 0 && row_hi >= row_lo, "lego_scatter_add_rows_range: bad row range [%d, %d)", row_lo, row_hi);
+    if (rows_cap <= 0 || row_hi == row_lo) return 0;
+    const long long total = (long long)rows_cap * width;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(blocks), dim3(256), 0, ST, grad_table, ld_table, width, idx, rows_cap, rows_dyn, g, ld_g,
+                       row_lo, row_hi);
+    return check_launch("lego_scatter_add_rows_range");
 }
 
 extern "C" int lego_nrms_special_grads(const int32_t* seg_off, int n_cap, const int32_t* n_dyn, const int32_t* idx_cat,

@@ -205,6 +205,7 @@ class _Base:
 
     fused_grads = None      # set by bind_grads(): enables the fused user tower (forward writes its gradient partials)
     touched_rows = None     # uint8 [V] flags of the trainable token table's rows that have received a gradient (TrainStep)
+    grad_hooks = None       # (dense_ready(), bucket_ready(lo_row, hi_row), rows_per_bucket): data-parallel TrainStep, trainable table
 
     def bind_grads(self, G):
         """Let training forwards write gradient partials directly (TrainStep binds its flat grad views once)."""
@@ -1016,14 +1017,26 @@ class NrmsEngine(_Base):
                  _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Rc, self.cnt(0), D, E0, None, None, st)
         else:
             V = G["embedding_vocab_table.glove.weight"].shape[0]
-            call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.glove.weight"]), D, D, V, _ptr(self.idx_tok),
-                 self.Rc, self.cnt(0), _ptr(self.dE), D, st)
             if self.touched_rows is not None:       # TrainStep: rows that have ever had a gradient (row-skipping dense Adam)
                 call("lego_mark_rows", _ptr(self.idx_tok), self.Rc, self.cnt(0), V, _ptr(self.touched_rows), st)
+            if self.grad_hooks is None:
+                call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.glove.weight"]), D, D, V, _ptr(self.idx_tok),
+                     self.Rc, self.cnt(0), _ptr(self.dE), D, st)
         for side in self._deferred:                  # the item operator's side-stream launches, behind its whole main chain
             side()
         self._deferred = ()
         if sw is not m:
             sev[4].record(sw)
             m.wait_event(sev[4])                     # every gradient is ordered on the caller's stream again
+        if self.grad_hooks is not None and not self.glove:
+            # data parallel with the trainable table: every dense gradient is final here, so its all-reduce starts now; the
+            # table gradient follows bucket by bucket (destination-row ranges), each bucket handed to the exchange as soon as
+            # its scatter is enqueued -- the ring works on bucket k while bucket k+1 is being scattered
+            dense_ready, bucket_ready, per = self.grad_hooks
+            dense_ready()
+            for lo in range(0, V, per):
+                hi = min(V, lo + per)
+                call("lego_scatter_add_rows_range", _ptr(G["embedding_vocab_table.glove.weight"]), D, D, _ptr(self.idx_tok),
+                     self.Rc, self.cnt(0), _ptr(self.dE), D, lo, hi, st)
+                bucket_ready(lo, hi)
         self.step = step_save

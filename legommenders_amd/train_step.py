@@ -268,6 +268,7 @@ class TrainStep:
         self.accumulate, self._acc, self.batch_idx = max(1, int(accumulate)), 0, 0
         self.pg, self.world = process_group, world_size
         self.force_allreduce = force_allreduce
+        self.overlap_exchange = os.environ.get("LEGO_OVERLAP_EXCHANGE", "1") != "0"
         self.counter_sum = torch.zeros(8, dtype=torch.int64, device=dev)
         self._grad_clean = True                    # FlatParams allocates a zeroed gradient buffer
 
@@ -310,12 +311,38 @@ class TrainStep:
         self._ready[slot].record(self.pre)
         self._planned_step = batch_idx
 
+    # ---- overlapped exchange of the trainable token table (embed/null, 410 MB): the engine's backward calls these hooks
+    # (engine.grad_hooks) -- dense part first, then one table bucket after another, each as an ASYNCHRONOUS all-reduce that
+    # RCCL orders behind the work enqueued so far and runs on its own stream, i.e. beside the scatter of the next bucket
+    def _exchange_hooks(self):
+        if self.table is None or not (self.world > 1 or self.force_allreduce) or not torch.distributed.is_initialized():
+            return None                                # (tests emulate ranks in one process and exchange by hand: no hooks)
+        o, rows, width = self.table
+        per = max(1, self.BUCKET_BYTES // (4 * width))
+        self._works = []
+
+        def dense_ready():
+            self._works.append(torch.distributed.all_reduce(self.touched, op=torch.distributed.ReduceOp.MAX, group=self.pg, async_op=True))
+            if o > 0:
+                self._works.append(torch.distributed.all_reduce(self.fp.grad[:o], group=self.pg, async_op=True))
+
+        def bucket_ready(lo, hi):
+            self._works.append(torch.distributed.all_reduce(self.fp.grad[o + lo * width:o + hi * width], group=self.pg, async_op=True))
+        return dense_ready, bucket_ready, per
+
     def sync_gradients(self):
         """the ONE gradient exchange of an optimiser step: all-reduce(sum) of the flat buffer (1/world is applied inside
         Adam).  A buffer above BUCKET_BYTES (the 410 MB trainable token table of embed/null) goes out as a train of
-        asynchronous bucket all-reduces on RCCL's stream, so the ring is busy with bucket k while k+1 is still being enqueued
-        and the wire time is bounded by bandwidth, not by one serial 410 MB launch."""
+        asynchronous bucket all-reduces on RCCL's stream; when the backward ran with the exchange hooks (the step's own path)
+        that train was started DURING the backward -- dense part at the join of the side streams, each table bucket behind
+        its own scatter -- and only has to be waited for here."""
         if not (self.world > 1 or self.force_allreduce):
+            return
+        works = getattr(self, "_works", None)
+        if works:
+            for w in works:
+                w.wait()
+            self._works = []
             return
         if getattr(self, "table", None) is not None:         # a row touched on ANY rank has a gradient everywhere after the sum
             torch.distributed.all_reduce(self.touched, op=torch.distributed.ReduceOp.MAX, group=self.pg)
@@ -362,7 +389,9 @@ class TrainStep:
                                       fork_ev=go, neck_ev=neck)
         if self.prefetch:
             self._prefetch(self.batch_idx + 1, neck)       # next batch: starts where this step's item tower ends
+        self.engine.grad_hooks = self._exchange_hooks() if (last_of_cycle and self.overlap_exchange) else None
         self.engine.backward(self.fp.G)
+        self.engine.grad_hooks = None
         self.batch_idx += 1
         if not self.prefetch:
             self.counter_sum += self.engine.counters

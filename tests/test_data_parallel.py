@@ -112,6 +112,33 @@ def _sync_worker(rank, world, port, out_dir):
         want = sum(torch.randn(ts.fp.numel, generator=torch.Generator().manual_seed(100 + r)) for r in range(world))
         assert torch.allclose(ts.fp.grad, want, atol=1e-6), (rank, buckets)
         assert ts.fp.split == ts.fp.offsets["embedding_vocab_table.glove.weight"] > 0      # the table is last in the buffer
+    # the OVERLAPPED form (engine.grad_hooks): dense part when the dense gradients are final, then one asynchronous all-reduce
+    # per table bucket as the backward produces it; sync_gradients only waits.  Must equal the serial exchange.
+    ts = TrainStep.__new__(TrainStep)
+    ts.fp = FlatParams(P, (), "cpu", last=("embedding_vocab_table.glove.weight",))
+    ts.pg, ts.world, ts.force_allreduce, ts.BUCKET_BYTES = dist.group.WORLD, world, False, 16 * 8 * 4      # 16 table rows per bucket
+    o = ts.fp.offsets["embedding_vocab_table.glove.weight"]
+    ts.table, ts.touched = (o, 50, 8), torch.zeros(50, dtype=torch.uint8)
+    ts.touched[rank::3] = 1
+    g = torch.Generator().manual_seed(200 + rank)
+    full = torch.randn(ts.fp.numel, generator=g)
+    dense_ready, bucket_ready, per = ts._exchange_hooks()
+    assert per == 16
+    ts.fp.grad[:o].copy_(full[:o])                   # the dense gradients are final ...
+    dense_ready()
+    for lo in range(0, 50, per):                      # ... then the table gradient arrives bucket by bucket
+        hi = min(50, lo + per)
+        ts.fp.grad[o + lo * 8:o + hi * 8].copy_(full[o + lo * 8:o + hi * 8])
+        bucket_ready(lo, hi)
+    assert len(ts._works) == 2 + 4
+    ts.sync_gradients()
+    assert ts._works == []
+    want = sum(torch.randn(ts.fp.numel, generator=torch.Generator().manual_seed(200 + r)) for r in range(world))
+    assert torch.allclose(ts.fp.grad, want, atol=1e-6)
+    flags = torch.zeros(50, dtype=torch.uint8)
+    for r in range(world):
+        flags[r::3] = 1
+    assert torch.equal(ts.touched, flags)
     dist.destroy_process_group()
 
 

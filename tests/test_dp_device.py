@@ -202,6 +202,53 @@ def test_train_step_two_processes_on_one_gpu_over_gloo(tmp_path):
     _same_trajectory({k: v.cpu() for k, v in fp1.P.items()}, r0, P, fp1.names, steps)
 
 
+def _gloo_rank_table(rank, world, port, out_dir, steps):
+    """NRMS with the trainable token table: the step's exchange runs in its OVERLAPPED form (engine.grad_hooks: dense part at
+    the join of the side streams, the table gradient as bucketed scatters, each bucket all-reduced behind its own scatter)"""
+    import torch.distributed as dist
+    from legommenders_amd.synthetic import init_nrms_params
+    from legommenders_amd.train_step import DeviceData, TrainStep
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    w = _world(n_rows=202)
+    P = init_nrms_params(D=64, A=64, V=3000, seed=5, glove=None)
+    TrainStep.BUCKET_BYTES = 512 * 64 * 4                              # 512 table rows per bucket: 6 buckets at V = 3000
+    ts = TrainStep("nrms", P, DeviceData(w, dev, rank=rank, world_size=world, seed=9, balance=8), 8, seed=9, world_size=world,
+                   process_group=dist.group.WORLD, dropout=False, total_steps=50, glove=False)
+    assert ts.table is not None and ts.overlap_exchange and ts._exchange_hooks()[2] == 512
+    for _ in range(steps):
+        ts.step()
+    torch.cuda.synchronize()
+    torch.save({k: v.cpu() for k, v in ts.fp.P.items()}, os.path.join(out_dir, f"table{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_overlapped_table_exchange_two_processes(tmp_path):
+    import torch.multiprocessing as mp
+    from legommenders_amd.synthetic import init_nrms_params
+    steps = 10
+    mp.spawn(_gloo_rank_table, args=(2, _free_port(), str(tmp_path), steps), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), f"table{r}.pt")) for r in range(2))
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), k
+    dev = _dev()
+    P = init_nrms_params(D=64, A=64, V=3000, seed=5, glove=None)
+    fp1, _ = _trajectory_single("nrms", P, _world(n_rows=202), dev, 16, steps, glove=False)
+    # parameters that really travelled (Adam moves every element by ~lr per step when its gradient is signal; tensors whose
+    # gradient is rounding noise at this initialisation -- the key bias, the user tower's hidden layer -- move 100x less and
+    # only carry that noise): the table, the item tower, the category / special rows
+    one = {k: v.cpu() for k, v in fp1.P.items()}
+    names = [k for k in fp1.names if float((one[k] - P[k]).norm()) >= 0.2 * 1e-3 * steps * float(P[k].numel()) ** 0.5]
+    assert any(k.startswith("item_op.") for k in names) and len(names) >= 6, names
+    _same_trajectory(one, r0, P, names, steps)
+    # the table itself: rows that had a gradient moved identically, rows that never had one are bit-identical to the init
+    tk = "embedding_vocab_table.glove.weight"
+    moved_rows = (one[tk] != P[tk]).any(1)
+    assert torch.equal(moved_rows, (r0[tk] != P[tk]).any(1)) and 0 < int(moved_rows.sum()) < P[tk].shape[0]
+    assert float((one[tk] - r0[tk]).norm()) <= 5e-2 * float((one[tk] - P[tk]).norm())
+
+
 def _plugin_rank(rank, world, port, out_dir, steps):
     """the plug-in route (PluginStep -> Legommender.forward through torch.ops.lego_hip.*) on two ranks WITH dropout: the
     rank-folded Philox seed travels through the custom ops' int64 `seed` arguments (a 64-bit seed killed rank 1)"""
