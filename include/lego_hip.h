@@ -68,6 +68,27 @@ int lego_plan_dense(const int32_t* mask /*[n,L] or NULL = all live*/, int n, int
 int lego_gather_rows(const float* table, int ld_table, int width, const int32_t* idx, int rows_cap,
                      const int32_t* rows_dyn /*nullable*/, float* out, int ld_out,
                      int accumulate /*1: out[r] += row where idx >= 0 (ConcatInputer's summed look-ups)*/, void* stream);
+/* ---- a4, de-duplicated: the projection Linear(glove[tok]) of Transformation (loader/embedding_hub.py:73-96) depends on the
+ * token id alone, and a batch repeats tokens (Zipf).  lego_unique_tokens builds, from the plan's row_tok[R]: uniq[U] (distinct
+ * ids, ascending), inv[R] (row -> index into uniq), perm[R] (rows grouped by inv), start[U] (first position of each group in
+ * perm) and *n_uniq = U.  Workspaces: stamp[V] (zero-initialised ONCE, never cleared; `epoch` must differ from every earlier
+ * call's and from 0), rank[V], bsum[ceil(V/1024)], cnt[min(R_cap,V)].  perm / start / cnt may be NULL (no grouping); sort_keys
+ * (nullable, [R_cap]) receives inv with the rows past R set to INT32_MAX: the key array lego_sort_rows groups the rows by. */
+int lego_unique_tokens(const int32_t* row_tok, int R_cap, const int32_t* R_dyn, int V, uint32_t* stamp, uint32_t epoch,
+                       int32_t* rank, int32_t* bsum, int32_t* uniq, int32_t* inv, int32_t* cnt, int32_t* start,
+                       int32_t* perm, int32_t* sort_keys, int32_t* n_uniq, void* stream);
+/* perm = the row indices 0 .. n-1 stably sorted by keys[r] (radix sort over `key_bits` bits + the sentinel's top bit; rocPRIM
+ * through hipCUB: a utility on the prefetch stream, not a hot kernel).  temp: lego_sort_rows_temp_bytes(n) bytes. */
+int lego_sort_rows(const int32_t* keys, int n, int32_t* keys_sorted, int32_t* perm, void* temp, int64_t temp_bytes, void* stream);
+int64_t lego_sort_rows_temp_bytes(int n);
+/* out[r,:] = dropout_r(src[inv[r],:]) for r < rows: expands per-token projections to token rows, the site's Dropout applied
+ * per ROW (embedding_hub.py:95-96: Dropout(Linear(.))) */
+int lego_expand_rows(const float* src, int ld_src, const int32_t* inv, int rows_cap, const int32_t* rows_dyn, int width,
+                     const lego_dropout* drop, float* out, int ld_out, void* stream);
+/* out[u,:] = sum over rows r with inv[r] == u of g[r,:] (u < U; perm = the rows grouped by inv): the per-token sums the
+ * projection's weight gradient is formed from.  Clears out[0:U] first. */
+int lego_segment_sum_rows(const float* g, int ld_g, int width, const int32_t* perm, const int32_t* inv, int R_cap,
+                          const int32_t* R_dyn, float* out, int ld_out, int U_cap, const int32_t* U_dyn, void* stream);
 /* backward of a TRAINABLE table (embed/null.yaml): grad_table[idx[r]] += g[r] (dense grad semantics) */
 int lego_scatter_add_rows(float* grad_table, int ld_table, int width, int table_rows /*<= 32: LDS pre-reduction*/,
                           const int32_t* idx, int rows_cap, const int32_t* rows_dyn, const float* g, int ld_g, void* stream);

@@ -42,6 +42,10 @@ SIGNATURES = {
     "lego_attn_fold_prepare": [P, P, P, P, P, P, P, P, P, P, I, I, P],
     "lego_attn_fold_grads": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P],
     "lego_scatter_add_rows": [P, I, I, I, P, I, P, P, I, P],
+    "lego_unique_tokens": [P, I, P, I, P, U32, P, P, P, P, P, P, P, P, P, P],
+    "lego_sort_rows": [P, I, P, P, P, I64, P],
+    "lego_expand_rows": [P, I, P, I, P, I, P, P, I, P],
+    "lego_segment_sum_rows": [P, I, I, P, P, I, P, P, I, I, P, P],
     "lego_scatter_add_rows_range": [P, I, I, P, I, P, P, I, I, I, P],
     "lego_linear_fwd": [P, I, P, I, P, P, I, I, P, I, I, I, P, P, P, P, P],
     "lego_linear_bwd_data": [P, I, P, I, P, I, I, P, I, I, I, P, I, F, P, P, P, P, P, P],
@@ -82,6 +86,7 @@ SIGNATURES = {
 
 # entry points that return a VALUE instead of a status (bound separately; tests/test_abi.py checks them against the header too)
 VALUE_FUNCS = {"lego_conv3_wino_du_slabs": [I, I, I]}
+VALUE_FUNCS_I64 = {"lego_sort_rows_temp_bytes": [I]}
 
 
 class LegoHipError(RuntimeError):
@@ -135,6 +140,9 @@ def lib() -> ctypes.CDLL:
     for name, argtypes in VALUE_FUNCS.items():
         fn = getattr(handle, name)
         fn.restype, fn.argtypes = ctypes.c_int, argtypes
+    for name, argtypes in VALUE_FUNCS_I64.items():
+        fn = getattr(handle, name)
+        fn.restype, fn.argtypes = ctypes.c_int64, argtypes
     for name, argtypes in SIGNATURES.items():
         try:
             fn = getattr(handle, name)
@@ -175,7 +183,7 @@ def declared_prototypes():
     header (or in the binding) fails on the CPU, not as a crash in a GPU test."""
     import re
     out = {}
-    for ret, name, args in re.findall(r"\b(int|const\s+char\s*\*)\s+(lego_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", _header_text()):
+    for ret, name, args in re.findall(r"\b(int64_t|int|const\s+char\s*\*)\s+(lego_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", _header_text()):
         kinds = []
         for a in (x.strip() for x in args.split(",")):
             if not a or a == "void":

@@ -231,7 +231,12 @@ struct EpiT : EpiArgs {
                 x[i] = v;
             }
             if (ok) {
-                *reinterpret_cast<f32x4*>(C + (size_t)ra * ldc + col) = x;
+                float* dst = C + (size_t)ra * ldc + col;
+                // rows_form 2 / 3: write-through (sc1) / streaming (nt) stores -- the output leaves L2 while the kernel still
+                // computes instead of waiting as dirty lines for the write-back at the kernel boundary
+                if (rows_form == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(x) : "memory");
+                else if (rows_form == 3) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(dst), "v"(x) : "memory");
+                else *reinterpret_cast<f32x4*>(dst) = x;
                 cs += x;
             }
         }
@@ -263,7 +268,7 @@ static Epi make_epi(float* C, int ldc) {
     e.relu_ref = nullptr; e.ld_ref = 0; e.relu_scale = 1.f; e.colsum = nullptr;
     e.tap_stride = 0; e.row_off_dyn = nullptr; e.M = e.N = e.row_off = 0;
     static int rows_form = -1;
-    if (rows_form < 0) { const char* v = getenv("LEGO_EPI_ROWS"); rows_form = (v != nullptr && v[0] == '0') ? 0 : 1; }
+    if (rows_form < 0) { const char* v = getenv("LEGO_EPI_ROWS"); rows_form = (v != nullptr && v[0] >= '0' && v[0] <= '3') ? v[0] - '0' : 1; }
     e.rows_form = rows_form;
     return e;
 }
@@ -462,6 +467,7 @@ static int launch_tn(int M, int N, int K_cap, const int* k_dyn, const AL& a, con
         const int tm = (M + 63) / 64, tn = (N + 63) / 64;
         const int deal = split % 8 == 0;
         TnDims d{M, N, K_cap, k_dyn, split, taps, 0, tm, tn, deal};
+        if (K_cap >= TN_LONG) d.min_chunk = 512;       // (the de-duplicated projection: 4.6 k distinct tokens under a 105 k capacity)
         auto k = tn_kernel<AL, BL, false, 2, 2, 1>;
         constexpr size_t lds = tn_lds_bytes(TN_BM_S, TN_BN_S, false);
         hipLaunchKernelGGL(k, deal ? dim3(tm * tn * taps * split) : dim3(tm, tn, taps * split), dim3(TN_THREADS_S), lds, st, d, a, b, e);

@@ -29,6 +29,8 @@ struct TnDims {
     size_t slab_stride;          // SLAB: floats between the partial outputs of consecutive k splits (taps * tap_stride)
     int tiles_m, tiles_n;        // output tiles
     int deal;                    // 1: 1-D grid, the workgroups of one k split dealt to ONE XCD (split_k % 8 == 0)
+    int min_chunk = 0;           // a k split covers at least this many reduction rows: when the dynamic K is far below the capacity
+                                 // the split was sized for, the trailing splits are empty instead of every split getting a sliver
 };
 
 constexpr size_t tn_lds_bytes(int bm = TN_BM, int bn = TN_BN, bool info = true) {
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void tn_kernel(TnDims dims, ALoad l
     const int m0 = bx * BM, n0 = by * BN;
     const int z = bz % dims.split_k, tap = bz / dims.split_k;
     int chunk = (K + dims.split_k - 1) / dims.split_k;
-    chunk = (chunk + BK - 1) / BK * BK;
+    chunk = max((chunk + BK - 1) / BK * BK, dims.min_chunk);
     const int kbeg = z * chunk, kend = min(K, kbeg + chunk);
     float* C = e.C + (size_t)tap * e.tap_stride + (SLAB ? (size_t)z * dims.slab_stride : 0);
     if (kbeg >= kend) {

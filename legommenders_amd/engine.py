@@ -241,7 +241,36 @@ class NamlEngine(_Base):
         self.rowinfo = torch.zeros(max(self.Rc, self.NIc * self.T), **i32)     # the plan kernel always writes rowinfo/row_tok
         self.row_tok = torch.zeros(max(self.Rc, self.NIc * self.T), **i32)
         self.inst_cat = torch.zeros(self.NIc, **i32)
-        self.X = self._f(self.Rc, E0)
+        # Token de-duplication of the projection (csrc/misc_ops.hip, "unique tokens of a batch"): Linear(glove[tok]) depends on
+        # the token id alone, so it is computed once per DISTINCT token of the batch (Xu -> Hu), expanded to the token rows
+        # with the site's per-row dropout (H), and its weight gradient is formed from per-token sums of dH (dHu).  Exact up
+        # to fp32 summation order; LEGO_DEDUP=0 keeps the row-by-row projection (X -> H).
+        self.dedup = os.environ.get("LEGO_DEDUP", "1") != "0" and self.Rc > 0
+        # the weight gradient from per-token sums of dH (lego_sort_rows + lego_segment_sum_rows + a product over the distinct
+        # tokens) is built and tested, but measured SLOWER on the bench world: its Zipf head puts a fifth of the rows into one
+        # group, whose partial sums meet in one 1-KB row (46 us for the sums + 25 for the product against 54 for the product over
+        # the token rows) -- off by default
+        self.dedup_bwd = self.dedup and os.environ.get("LEGO_DEDUP_BWD", "0") == "1"
+        V = P["embedding_vocab_table.glove.embedding.weight"].shape[0]
+        self.V = V
+        self.Uc = min(self.Rc, V) if self.dedup else 0
+        if self.dedup:
+            self.uq_stamp = torch.zeros(V, dtype=torch.int32, device=self.dev)       # uint32 epochs; never cleared
+            self.uq_rank = torch.zeros(V, **i32)
+            self.uq_bsum = torch.zeros((V + 1023) // 1024 + 1, **i32)
+            self.uq_cnt = torch.zeros(self.Uc + 1, **i32)
+            self.uq_start = torch.zeros(self.Uc + 1, **i32)
+            self.uniq = torch.zeros(self.Uc, **i32)
+            self.inv = torch.zeros(self.Rc, **i32)
+            self.perm = torch.zeros(self.Rc, **i32)
+            self.uq_keys = torch.zeros(self.Rc, **i32)
+            self.uq_keys_sorted = torch.zeros(self.Rc, **i32)
+            self.uq_temp = torch.zeros(max(int(_lib.lib().lego_sort_rows_temp_bytes(self.Rc)), 256), dtype=torch.uint8, device=self.dev)
+            self.Xu = self._f(self.Uc, E0)
+            self.Hu = self._f(self.Uc, D)
+            self.dHu = self._f(self.Uc, D)
+            self._uq_epoch = 0
+        self.X = self._f(1, E0) if self.dedup_bwd else self._f(self.Rc, E0)
         self.H = self._f(self.Rc, D)
         self.Y = self._f(self.Ryc, D)
         self.Tt = self._f(self.Ryc, A)
@@ -275,7 +304,13 @@ class NamlEngine(_Base):
     # ------------------------------------------------------------------ prefetched token-row gather
     # The GloVe table is frozen, so the gathered rows X of a batch depend on its plan only: with plan slots enabled
     # (TrainStep) the gather of step N+1 runs right after its plan on the prefetch stream, off the critical path.
-    _PLAN_FIELDS = _Base._PLAN_FIELDS + ("X", "pair_info", "mask_proj", "mask_conv")
+    _PLAN_FIELDS = _Base._PLAN_FIELDS + ("X", "pair_info", "mask_proj", "mask_conv", "inst_cat")
+    _DEDUP_FIELDS = ("Xu", "uniq", "inv", "perm")
+
+    def enable_plan_slots(self):
+        if getattr(self, "_slots", None) is None and self.dedup:
+            self._PLAN_FIELDS = type(self)._PLAN_FIELDS + self._DEDUP_FIELDS
+        return super().enable_plan_slots()
 
     # ---- dropout keep bits made ahead of time (lego_dropout_mask, same bits the epilogues would draw): the GEMM
     # epilogues of the step then read one byte per 4 rows x column instead of running Philox on the critical path
@@ -304,9 +339,25 @@ class NamlEngine(_Base):
         """k1: X[r, :] = glove[row_tok[r], :] for the planned token rows (embedding_hub.py:95, frozen table)"""
         b = self.__dict__ if into is None else into
         s = torch.cuda.current_stream() if stream is None else stream
+        tag = "gather_rows_in_step" if stream is not None else "gather_rows"
+        if self.dedup:
+            # distinct tokens of the planned rows (uniq / inv / perm, U -> counters[6]), then ONE table row per distinct token
+            self._uq_epoch = self._uq_epoch % 0x7FFFFFF0 + 1
+            self.kk(s, None, "lego_unique_tokens", _ptr(b["row_tok"]), self.Rc, _ptr(b["counters"], 0), self.V, _ptr(self.uq_stamp),
+                    self._uq_epoch, _ptr(self.uq_rank), _ptr(self.uq_bsum), _ptr(b["uniq"]), _ptr(b["inv"]), _ptr(self.uq_cnt),
+                    _ptr(self.uq_start), None, _ptr(self.uq_keys) if self.dedup_bwd else None, _ptr(b["counters"], 6))
+            if self.dedup_bwd:                       # rows grouped by distinct token: perm (the weight gradient sums dH per token)
+                self.kk(s, None, "lego_sort_rows", _ptr(self.uq_keys), self.Rc, _ptr(self.uq_keys_sorted), _ptr(b["perm"]),
+                        _ptr(self.uq_temp), self.uq_temp.numel())
+            self.kk(s, tag, "lego_gather_rows", _ptr(self.P["embedding_vocab_table.glove.embedding.weight"]), self.E0, self.E0,
+                    _ptr(b["uniq"]), self.Uc, _ptr(b["counters"], 6), _ptr(b["Xu"]), self.E0, 0)
+            if not self.dedup_bwd:                   # the weight gradient still runs over the token rows: X[r] = Xu[inv[r]]
+                self.kk(s, None, "lego_expand_rows", _ptr(b["Xu"]), self.E0, _ptr(b["inv"]), self.Rc, _ptr(b["counters"], 0), self.E0,
+                        None, _ptr(b["X"]), self.E0)
+            return
         # with timers on (bench.py) the launch is bracketed by HIP events on the stream it runs on: on the prefetch stream
         # that is the gather's duration INSIDE the step, overlapped with the previous step's user-side chain
-        self.kk(s, "gather_rows_in_step" if stream is not None else "gather_rows", "lego_gather_rows",
+        self.kk(s, tag, "lego_gather_rows",
                 _ptr(self.P["embedding_vocab_table.glove.embedding.weight"]), self.E0, self.E0,
                 _ptr(b["row_tok"]), self.Rc, _ptr(b["counters"], 0), _ptr(b["X"]), self.E0, 0)
 
@@ -319,6 +370,8 @@ class NamlEngine(_Base):
 
     def plan_on(self, stream, slot, cand, hist, hist_len, nb=None):
         super().plan_on(stream, slot, cand, hist, hist_len, nb)
+        b = self._slots[slot]                        # category id of every planned instance: a function of the plan alone
+        self.kk(stream, None, "lego_gather_i32", _ptr(self.tb.cat), _ptr(b["inst_item"]), self.NIc, _ptr(b["counters"], 1), _ptr(b["inst_cat"]))
         if self.Rc > 0:
             if self.wino:
                 self.plan_pairs(stream, self._slots[slot])
@@ -391,6 +444,7 @@ class NamlEngine(_Base):
                 _ptr(self.tb.title_tok), _ptr(self.tb.title_len), self.T,
                 _ptr(self.counters), _ptr(self.inst_item), _ptr(self.seg_off), _ptr(self.hist_off),
                 _ptr(self.rowinfo), _ptr(self.row_tok))
+        self.kk(m, None, "lego_gather_i32", _ptr(self.tb.cat), _ptr(self.inst_item), self.NIc, self.cnt(1), _ptr(self.inst_cat))
         if self.wino:
             self.plan_pairs(m)
 
@@ -410,12 +464,12 @@ class NamlEngine(_Base):
             self.kk(sb, None, "lego_conv3_wino_pack", _ptr(P["item_op.cnn.weight"]), _ptr(self.wino_u), _ptr(self.wino_ut), D, D)
         else:
             self.kk(sb, None, "lego_conv3_pack", _ptr(P["item_op.cnn.weight"]), _ptr(self.wt), D, D)
-        if sb is not m:
+        one_wait = os.environ.get("LEGO_ONE_WAIT", "0") == "1"      # A/B: the conv waits ONCE, for the whole side chain (measured 1 % slower)
+        if sb is not m and not one_wait:
             ev[8].record(sb)
         if zero_loss:
             with torch.cuda.stream(sb):
                 self.loss.zero_()
-        self.kk(sb, None, "lego_gather_i32", _ptr(self.tb.cat), _ptr(self.inst_item), self.NIc, self.cnt(1), _ptr(self.inst_cat))
         self.kk(sb, None, "lego_gather_rows", _ptr(P["embedding_vocab_table.category.weight"]), D, D, _ptr(self.inst_cat),
                 self.NIc, self.cnt(1), _ptr(self.cat_emb), D, 0)
         self.kk(sb, None, "lego_linear_fwd", _ptr(self.cat_emb), D, _ptr(P["item_op.linear.weight"]), D,
@@ -425,13 +479,22 @@ class NamlEngine(_Base):
             ev[1].record(sb)
         # main stream: k1 frozen GloVe row gather, then Transformation = Dropout(Linear(.)) (embedding_hub.py:95-96)
         if not gathered:                             # else: done with the plan on the prefetch stream (plan_on)
-            self.kk(m, "gather_rows", "lego_gather_rows", _ptr(P["embedding_vocab_table.glove.embedding.weight"]), E0, E0,
-                    _ptr(self.row_tok), self.Rc, self.cnt(0), _ptr(self.X), E0, 0)
-        self.kk(m, "proj_fwd", "lego_linear_fwd", _ptr(self.X), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
-                _ptr(P["embedding_vocab_table.glove.linear.bias"]), _ptr(self.H), D, self.Rc, self.cnt(0), D, E0, 0,
-                None, self.drop(self.p_proj, SITE_PROJ, training), None, None)      # every planned row is live
+            self.gather_tokens()
+        if self.dedup:
+            self.kk(m, "proj_fwd", "lego_linear_fwd", _ptr(self.Xu), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
+                    _ptr(P["embedding_vocab_table.glove.linear.bias"]), _ptr(self.Hu), D, self.Uc, self.cnt(6), D, E0, 0,
+                    None, None, None, None)
+            self.kk(m, "proj_expand", "lego_expand_rows", _ptr(self.Hu), D, _ptr(self.inv), self.Rc, self.cnt(0), D,
+                    self.drop(self.p_proj, SITE_PROJ, training), _ptr(self.H), D)
+        else:
+            self.kk(m, "proj_fwd", "lego_linear_fwd", _ptr(self.X), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
+                    _ptr(P["embedding_vocab_table.glove.linear.bias"]), _ptr(self.H), D, self.Rc, self.cnt(0), D, E0, 0,
+                    None, self.drop(self.p_proj, SITE_PROJ, training), None, None)      # every planned row is live
         if sb is not m:
-            m.wait_event(ev[8])                      # packed conv weights (long done: first thing on the side stream)
+            # the side chain is three short kernels (packed conv weights, category rows, category Linear: the category ids come
+            # with the plan) and ends while the projection still runs: ONE wait here covers the conv's weights and the category
+            # rows of Y -- every cross-stream wait costs the main stream 6-14 us of idle even when already signalled
+            m.wait_event(ev[1] if one_wait else ev[8])
         # k3: conv + relu + mask + dropout (cnn_operator.py:54-57)
         if self.wino:
             self.kk(m, "conv3_fwd", "lego_conv3_wino_fwd", _ptr(self.H), D, _ptr(self.wino_u), _ptr(P["item_op.cnn.bias"]),
@@ -442,8 +505,8 @@ class NamlEngine(_Base):
                     _ptr(self.Y), D, self.Rc, self.cnt(0), D, D, self.drop(self.p_conv, SITE_CONV, training), 0)
         if neck_ev is not None:
             neck_ev.record(m)                        # the next batch's prefetch chain starts here (see forward)
-        if sb is not m:
-            m.wait_event(ev[1])                      # category rows of Y, zeroed loss
+        if sb is not m and not one_wait:
+            m.wait_event(ev[1])                      # category rows of Y
         # k5: additive attention pool over [title tokens..., category] (attention.py:31-38)
         self._additive_fwd(m, "item_op.", _ptr(self.Y), self.Ryc, self.cnt(2), self.Tt, A, self.seg_off, self.cnt(0),
                            self.NIc, self.cnt(1), self.items, self.wrow)
@@ -534,8 +597,14 @@ class NamlEngine(_Base):
             self.kk(m, "conv3_bwd_weight", "lego_conv3_bwd_weight", _ptr(self.dY), D, _ptr(self.H), D, _ptr(self.rowinfo),
                     _ptr(self.dwt), self.Rc, self.cnt(0), D, D)
             self.kk(m, None, "lego_conv3_unpack_add", _ptr(self.dwt), _ptr(G["item_op.cnn.weight"]), D, D)
-        self.kk(m, "proj_bwd_weight", "lego_linear_bwd_weight", _ptr(self.dH), D, _ptr(self.X), E0,
-                _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Rc, self.cnt(0), D, E0, None, None)
+        if self.dedup_bwd:                           # per-token sums of dH, then the product over the distinct tokens only
+            self.kk(m, "proj_bwd_segsum", "lego_segment_sum_rows", _ptr(self.dH), D, D, _ptr(self.perm), _ptr(self.inv), self.Rc, self.cnt(0),
+                    _ptr(self.dHu), D, self.Uc, self.cnt(6))
+            self.kk(m, "proj_bwd_weight", "lego_linear_bwd_weight", _ptr(self.dHu), D, _ptr(self.Xu), E0,
+                    _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Uc, self.cnt(6), D, E0, None, None)
+        else:
+            self.kk(m, "proj_bwd_weight", "lego_linear_bwd_weight", _ptr(self.dH), D, _ptr(self.X), E0,
+                    _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Rc, self.cnt(0), D, E0, None, None)
         self._fork(ev[6], sb, m)
         self.step = step_save
 

@@ -35,6 +35,7 @@ from legommenders_amd.synthetic import glove_table_np, init_naml_params, init_nr
 WORLD = dict(seed=0, n_items=1200, n_users=900, n_rows=9600, V=3000, T=16, S=20, n_cat=18, neg_cap=20, p_pref=0.8,
              p_topic=0.5, pool=30, n_dev_users=400, dev_neg=8)
 HYPER = dict(D=64, B=32, lr=1e-3, epochs=2, dropout=0.1, heads=8, K=4, glove_seed=77)
+EPOCHS = dict(naml=2, nrms=5)     # NRMS starts from GAUC 0.5 and is still mid-climb after 2 epochs (seed spread 0.08): 5 epochs
 SEEDS = (11, 12, 13, 14, 15, 16, 17, 18)
 METRICS = ["GAUC", "NDCG@10", "MRR"]
 
@@ -145,7 +146,7 @@ def run_seed(kind, w, seed):
     model.load_state_dict(P)
     init = dict(A=A)
     before = evaluate(model, resampler, dev_ut)
-    B, epochs = HYPER["B"], HYPER["epochs"]
+    B, epochs = HYPER["B"], EPOCHS[kind]
     opt = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=HYPER["lr"])   # base_lego.py:201-204
     sched = get_linear_schedule_with_warmup(opt, num_warmup_steps=0, num_training_steps=len(train_ut) // B * epochs)
     torch.manual_seed(seed + 1000)                                    # shuffle + dropout streams
@@ -182,7 +183,7 @@ def main():
             print(kind, seed, "GAUC %.4f -> %.4f" % (r["before"]["GAUC"], r["after"]["GAUC"]), "NDCG@10 %.4f" % r["after"]["NDCG@10"],
                   "loss %.4f -> %.4f" % (r["first_loss"], r["last_loss"]), "%.0f s" % (time.time() - t0), flush=True)
         g = np.array([r["after"]["GAUC"] for r in runs])
-        out = dict(kind=kind, world=WORLD, hyper=dict(HYPER, **inits), metrics=METRICS, runs=runs,
+        out = dict(kind=kind, world=WORLD, hyper=dict(HYPER, epochs=EPOCHS[kind], **inits), metrics=METRICS, runs=runs,
                    init="legommenders_amd.synthetic.init_%s_params(D, A, V, n_cat, seed=run seed, glove=glove_table_np(glove_seed, V))" % kind,
                    mean={m: float(np.mean([r["after"][m] for r in runs])) for m in METRICS},
                    spread={m: float(np.max([r["after"][m] for r in runs]) - np.min([r["after"][m] for r in runs])) for m in METRICS},

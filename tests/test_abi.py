@@ -17,7 +17,7 @@ def handle():
 
 def test_header_and_binding_agree(handle):
     declared = set(_lib.declared_symbols())
-    bound = set(_lib.SIGNATURES) | set(_lib.VALUE_FUNCS) | {"lego_last_error", "lego_abi_version"}
+    bound = set(_lib.SIGNATURES) | set(_lib.VALUE_FUNCS) | set(_lib.VALUE_FUNCS_I64) | {"lego_last_error", "lego_abi_version"}
     assert declared == bound, (declared - bound, bound - declared)
 
 
@@ -25,9 +25,9 @@ def test_prototypes_in_the_header_match_the_binding(handle):
     """argument COUNT and KIND (pointer / int / float / 64-bit) of every entry point, header vs ctypes binding"""
     protos = _lib.declared_prototypes()
     assert set(protos) == set(_lib.declared_symbols())            # every declaration was parsed
-    for name, argtypes in list(_lib.SIGNATURES.items()) + list(_lib.VALUE_FUNCS.items()):
+    for name, argtypes in list(_lib.SIGNATURES.items()) + list(_lib.VALUE_FUNCS.items()) + list(_lib.VALUE_FUNCS_I64.items()):
         ret, kinds = protos[name]
-        assert ret == "int", name
+        assert ret == ("int64_t" if name in _lib.VALUE_FUNCS_I64 else "int"), name
         assert len(kinds) == len(argtypes), (name, len(kinds), len(argtypes))
         for i, (h, b) in enumerate(zip(kinds, argtypes)):
             assert h is b, (name, i, h, b)

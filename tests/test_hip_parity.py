@@ -427,7 +427,8 @@ def test_fused_user_tower_matches_unfused():
     _grads_close(g_fused, G, "fused")
 
 
-@pytest.mark.parametrize("env", [{"LEGO_SERIAL": "1"}, {"LEGO_WINO": "0"}, {"LEGO_SERIAL": "1", "LEGO_WINO": "0"}])
+@pytest.mark.parametrize("env", [{"LEGO_SERIAL": "1"}, {"LEGO_WINO": "0"}, {"LEGO_SERIAL": "1", "LEGO_WINO": "0"}, {"LEGO_DEDUP": "0"},
+                                 {"LEGO_DMA": "0"}, {"LEGO_EPI_ROWS": "0"}])
 def test_switches_keep_the_result(env, monkeypatch):
     """the two environment switches the product still reads (tools/README.md): single-stream launch order for profiling and
     the direct three-tap conv instead of the Winograd form -- same logits, loss and gradients as the reference fixture"""
@@ -441,7 +442,7 @@ def test_switches_keep_the_result(env, monkeypatch):
     B, C = batch["cand"].shape
     ids = [torch.tensor(batch[k]).int().to(dev).contiguous() for k in ("cand", "hist", "hist_len")]
     eng = NamlEngine(Pd, tb, B, C, batch["hist"].shape[1], p_proj=0.0, p_conv=0.0)
-    assert eng.wino == ("LEGO_WINO" not in env)
+    assert eng.wino == ("LEGO_WINO" not in env) and eng.dedup == ("LEGO_DEDUP" not in env)
     g = eng.grads_like()
     scores, l = eng.forward(*ids, training=True)
     eng.backward(g)
@@ -449,6 +450,75 @@ def test_switches_keep_the_result(env, monkeypatch):
     _close(scores.cpu(), logits, rtol=1e-4, atol=2e-5, what="logits")
     assert abs(float(l) - loss) < 2e-5
     _grads_close(g, G, str(env))
+
+
+def test_unique_tokens_expand_and_segment_sum():
+    """the projection de-duplication kernels against torch: uniq / inv / perm of a Zipf-like id list (one id holding a fifth
+    of the rows, the case that makes a group span many waves), the expansion with per-row dropout bits, the per-token sums"""
+    import ctypes
+    from legommenders_amd._lib import LegoDropout, call
+    dev = _dev()
+    rs = np.random.RandomState(3)
+    V, R_cap, R, D = 5000, 9000, 7777, 256
+    tok = np.minimum(rs.zipf(1.2, size=R_cap) - 1, V - 1).astype(np.int32)
+    i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
+    P = lambda t, off=0: ctypes.c_void_p(t.data_ptr() + off * t.element_size())
+    row_tok, R_dyn = torch.tensor(tok).to(dev), torch.tensor([R], dtype=torch.int32, device=dev)
+    stamp, rank, bsum = i32(V), i32(V), i32((V + 1023) // 1024 + 1)
+    Uc = min(R_cap, V)
+    uniq, inv, cnt, start, perm, n_u = i32(Uc), i32(R_cap), i32(Uc + 1), i32(Uc + 1), i32(R_cap), i32(1)
+    for epoch in (1, 2):                                  # a second call on the same stamp table (nothing is cleared in between)
+        if epoch == 2:
+            row_tok = torch.tensor(np.minimum(rs.zipf(1.3, size=R_cap) - 1 + 7, V - 1).astype(np.int32)).to(dev)
+        keys = i32(R_cap)
+        call("lego_unique_tokens", P(row_tok), R_cap, P(R_dyn), V, P(stamp), epoch, P(rank), P(bsum), P(uniq), P(inv), P(cnt), P(start),
+             P(perm), P(keys), P(n_u), None)
+        torch.cuda.synchronize()
+        t = row_tok[:R].cpu().long()
+        want_u, want_inv = torch.unique(t, sorted=True, return_inverse=True)
+        U = int(n_u.item())
+        assert U == want_u.numel()
+        assert torch.equal(uniq[:U].cpu().long(), want_u) and torch.equal(inv[:R].cpu().long(), want_inv)
+        pm = perm[:R].cpu().long()
+        assert sorted(pm.tolist()) == list(range(R))
+        grouped = want_inv[pm]
+        assert bool((grouped[1:] >= grouped[:-1]).all())                  # rows grouped by token, groups in ascending order
+        assert torch.equal(start[:U].cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), torch.bincount(want_inv, minlength=U).cumsum(0)[:-1]]))
+        # the same grouping through the radix sort (what the engine uses: no atomics, stable -> a deterministic order)
+        from legommenders_amd import _lib as L_
+        assert torch.equal(keys[:R].cpu().long(), want_inv) and bool((keys[R:] == 0x7fffffff).all())
+        temp = torch.zeros(int(L_.lib().lego_sort_rows_temp_bytes(R_cap)), dtype=torch.uint8, device=dev)
+        ks, perm2 = i32(R_cap), i32(R_cap)
+        call("lego_sort_rows", P(keys), R_cap, P(ks), P(perm2), P(temp), temp.numel(), None)
+        torch.cuda.synchronize()
+        want_perm = torch.sort(want_inv, stable=True).indices
+        assert torch.equal(perm2[:R].cpu().long(), want_perm) and sorted(perm2[R:].cpu().tolist()) == list(range(R, R_cap))
+        perm = perm2
+    # expand with dropout bits: the same keep decisions the GEMM epilogue of the row-by-row projection takes
+    g = torch.Generator().manual_seed(5)
+    src = torch.randn(U, D, generator=g).to(dev)
+    mask = torch.zeros(((R_cap + 3) // 4) * D + 4, dtype=torch.uint8, device=dev)
+    d = LegoDropout(0.1, 99, 7, None)
+    call("lego_dropout_mask", ctypes.byref(d), R_cap, None, D, P(mask), None)
+    out_m, out_p, out_0 = (torch.full((R_cap, D), 7.0, device=dev) for _ in range(3))
+    call("lego_expand_rows", P(src), D, P(inv), R_cap, P(R_dyn), D, ctypes.byref(LegoDropout(0.1, 99, 7, mask.data_ptr())), P(out_m), D, None)
+    call("lego_expand_rows", P(src), D, P(inv), R_cap, P(R_dyn), D, ctypes.byref(d), P(out_p), D, None)
+    call("lego_expand_rows", P(src), D, P(inv), R_cap, P(R_dyn), D, None, P(out_0), D, None)
+    torch.cuda.synchronize()
+    plain = src[inv[:R].long()]
+    assert torch.equal(out_0[:R], plain) and bool((out_0[R:] == 7.0).all())
+    assert torch.equal(out_m, out_p)
+    bits = np.unpackbits(mask[:((R_cap + 3) // 4) * D].cpu().numpy().reshape(-1, D, 1), axis=2, bitorder="little")[:, :, :4]   # [R/4, D, 4]
+    keep = torch.tensor(bits.transpose(0, 2, 1).reshape(-1, D)[:R].astype(np.float32)).to(dev)
+    assert torch.allclose(out_m[:R], plain * keep / 0.9, rtol=1e-6, atol=0) and 0.88 < float(keep.mean()) < 0.92
+    # per-token sums
+    gr = torch.randn(R_cap, D, generator=g).to(dev)
+    seg = torch.full((Uc, D), 3.0, device=dev)
+    call("lego_segment_sum_rows", P(gr), D, D, P(perm), P(inv), R_cap, P(R_dyn), P(seg), D, Uc, P(n_u), None)
+    torch.cuda.synchronize()
+    want = torch.zeros(U, D, dtype=torch.float64).index_add_(0, want_inv, gr[:R].cpu().double())
+    err = (seg[:U].cpu().double() - want).abs().max() / want.abs().max()
+    assert float(err) < 1e-5 and bool((seg[U:] == 3.0).all())
 
 
 def test_precomputed_dropout_mask_equals_in_kernel_draw():
