@@ -259,6 +259,7 @@ using Epi = EpiArgs;      // host-side view; the kernel is instantiated with one
 #include "gemm_wino.hpp"
 #include "gemm_tn.hpp"
 #include "gemm_dma.hpp"
+#include "gemm_wino_dma.hpp"
 namespace lego {
 
 static Epi make_epi(float* C, int ldc) {
@@ -590,8 +591,31 @@ extern "C" int lego_conv3_bwd_weight(const float* gy, int ldg, const float* h, i
 
 
 // ---- Winograd F(2,3) form of the conv over row pairs (gemm_wino.hpp)
+static int launch_wino_dma(const WinoArgs& w, const Epi& e, hipStream_t st, const char* what) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)wino_dma_lds_bytes());
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(wino_dma_kernel, dim3(num_cus() / 16 * 16), dim3(STRIP_THREADS), wino_dma_lds_bytes(), st, w, e);
+    return check_launch(what);
+}
+
+// LEGO_WINO_DMA=1 selects the LDS-DMA form of the Winograd kernel (gemm_wino_dma.hpp).  It is exact (same differences to the
+// direct conv as wino_kernel) and measured SLOWER: 91.6 vs 78.9 us forward, 93.3 vs 81.3 us data gradient on 23 k rows
+// (tools/wino_check.py) -- two LDS reads + a packed add per A fragment, 256 VGPRs with 25 spills -- so the register-staged
+// kernel stays the default.
+static int wino_dma_mode() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("LEGO_WINO_DMA"); v = (e != nullptr && e[0] == '1') ? 1 : 0; }
+    return v;
+}
+
 template <bool B_MC>
 static int launch_wino(const WinoArgs& w, const Epi& e, hipStream_t st, const char* what) {
+    if constexpr (!B_MC)
+        if (wino_dma_mode()) return launch_wino_dma(w, e, st, what);
     auto k = wino_kernel<B_MC>;
     constexpr size_t lds = wino_lds_bytes<B_MC>();
     static bool attr_done = false;

@@ -428,7 +428,7 @@ def test_fused_user_tower_matches_unfused():
 
 
 @pytest.mark.parametrize("env", [{"LEGO_SERIAL": "1"}, {"LEGO_WINO": "0"}, {"LEGO_SERIAL": "1", "LEGO_WINO": "0"}, {"LEGO_DEDUP": "0"},
-                                 {"LEGO_DMA": "0"}, {"LEGO_EPI_ROWS": "0"}])
+                                 {"LEGO_DMA": "0"}, {"LEGO_EPI_ROWS": "0"}, {"LEGO_WINO_DMA": "1"}, {"LEGO_DEDUP_BWD": "1"}])
 def test_switches_keep_the_result(env, monkeypatch):
     """the two environment switches the product still reads (tools/README.md): single-stream launch order for profiling and
     the direct three-tap conv instead of the Winograd form -- same logits, loss and gradients as the reference fixture"""
