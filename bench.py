@@ -206,6 +206,7 @@ def tagged_steps(ts, steps, barrier):
     barrier()
     ts.engine.timers = None
     cs = ts.counter_sum.tolist()
+    tagged_steps.uniq = cs[6] / steps
     return timers, cs[0] / steps, cs[1] / steps
 
 
@@ -293,7 +294,7 @@ def main():
         torch.cuda.synchronize()
 
     ts = make_ts(args.model, data, force=args.force_dist, embed=args.embed)
-    in_region = {"naml": {"conv3_fwd", "gather_rows_in_step"}, "nrms": {"qkv_fwd_item"}}[args.model]
+    in_region = {"naml": {"conv3_fwd", "gather_rows_in_step", "expand_rows_in_step"}, "nrms": {"qkv_fwd_item"}}[args.model]
     dt, timers, loss = timed_steps(ts, args.steps, args.warmup, barrier, args.time_every, tags=in_region)
     host_ms = timed_steps.host_s / args.steps * 1e3
     if dist_on:
@@ -303,8 +304,11 @@ def main():
     final_loss = float(loss.item())
     cs = ts.counter_sum.tolist()
     rows_per_launch, inst_per_launch = cs[0] / max(1, args.steps), cs[1] / max(1, args.steps)
+    dedup = bool(getattr(ts.engine, "dedup", False))
+    uniq_per_launch = cs[6] / max(1, args.steps) if dedup else rows_per_launch     # distinct tokens: the rows the projection runs on
     # every tagged kernel on a few extra steps AFTER the timed region; the kernels bracketed inside it keep their in-region figures
     tm_all, rows_tab, inst_tab = tagged_steps(ts, 8, barrier)
+    uniq_tab = tagged_steps.uniq
     kern = kernel_table(tm_all)
     kern_in = kernel_table(timers)
 
@@ -312,8 +316,17 @@ def main():
     eng = ts.engine
     gather_ms, gather_rows = None, 0
     if hasattr(eng, "gather_tokens") and getattr(eng, "Rc", 0) > 0:
+        from legommenders_amd.engine import _ptr, _stream
+        from legommenders_amd._lib import call as _call
+        glove_w = eng.P["embedding_vocab_table.glove.embedding.weight"]
+
+        def gather_once():                              # the row gather alone, on the plan of the last step
+            if dedup:
+                _call("lego_gather_rows", _ptr(glove_w), E0, E0, _ptr(eng.uniq), eng.Uc, eng.cnt(6), _ptr(eng.Xu), E0, 0, _stream())
+            else:
+                eng.gather_tokens()
         for _ in range(4):
-            eng.gather_tokens()
+            gather_once()
         blocker = torch.zeros(1 << 27, dtype=torch.float32, device=dev)    # ~0.3 ms of GPU work: the host enqueues the
         torch.cuda.synchronize()                                           # whole timed chain while it runs, so the
         for _ in range(3):                                                 # chain is not host-bound
@@ -321,18 +334,18 @@ def main():
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(20):
-            eng.gather_tokens()
+            gather_once()
         b.record()
         torch.cuda.synchronize()
         del blocker
         gather_ms = a.elapsed_time(b) / 20
-        gather_rows = int(eng.counters[0].item())
+        gather_rows = int(eng.counters[6 if dedup else 0].item())
 
     # ---- per-kernel roofline: algorithmic flops per launch over the HIP-event durations
-    def flops_for(rows, inst):
+    def flops_for(rows, inst, uniq=None):
         yrows = rows + inst
         if args.model == "naml":
-            return {"proj_fwd": 2.0 * rows * D * E0,
+            return {"proj_fwd": 2.0 * (rows if uniq is None else uniq) * D * E0,     # de-duplicated: one row per distinct token
                     "conv3_fwd": 2.0 * rows * D * 3 * D,
                     "conv3_bwd_data": 2.0 * rows * D * 3 * D,
                     "conv3_bwd_weight": 2.0 * rows * D * 3 * D,
@@ -347,8 +360,8 @@ def main():
         wino = ("conv3_fwd", "conv3_bwd_data", "conv3_bwd_weight") if getattr(eng, "wino", False) else ()
     else:
         solo, wino = ("qkv_fwd_item", "out_proj_fwd_item", "linear_fwd_item", "outlin_fwd_item", "additive_fwd_item"), ()
-    price(kern, flops_for(rows_tab, inst_tab), wino)
-    flops = flops_for(rows_per_launch, inst_per_launch)
+    price(kern, flops_for(rows_tab, inst_tab, uniq_tab if dedup else None), wino)
+    flops = flops_for(rows_per_launch, inst_per_launch, uniq_per_launch if dedup else None)
     price(kern_in, flops, wino)
     for k in kern:
         kern[k]["timed"] = "8 steps after the timed region, every tagged kernel bracketed"
@@ -356,7 +369,7 @@ def main():
         v["timed"] = "inside the timed region"
         kern[k] = v
     for k in kern:
-        kern[k]["overlapped"] = k not in solo and not k.startswith("gather_rows")
+        kern[k]["overlapped"] = k not in solo and not k.startswith("gather_rows") and not k.startswith("expand_rows")
     traffic, traffic_src = pmc_traffic()
     roofline = dominant(kern, flops, solo, traffic)
     if roofline is not None:
@@ -369,13 +382,13 @@ def main():
                            "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic.get("gather_rows"),
                            "avg_launch_ms": round(gather_ms, 5), "timed": "20 back-to-back launches of one plan after the timed "
                            "region: cache-assisted (the PMC pass shows a third of the row reads reaching HBM)",
-                           "algorithmic_bytes_per_launch": gbytes,
+                           "algorithmic_bytes_per_launch": gbytes, "rows_gathered_per_launch": gather_rows,
                            "dense_reference_bytes_per_launch": B * 55 * 30 * 1200}
         ins = kern.get("gather_rows_in_step")
         if ins and ins["avg_ms"] > 0:
-            b_in = rows_per_launch * (E0 * 4 * 2 + 4)
+            b_in = uniq_per_launch * (E0 * 4 * 2 + 4)
             g_in = b_in / (ins["avg_ms"] * 1e-3) / 1e9
-            g_rd = rows_per_launch * E0 * 4 / (ins["avg_ms"] * 1e-3) / 1e9        # the row READS only
+            g_rd = uniq_per_launch * E0 * 4 / (ins["avg_ms"] * 1e-3) / 1e9        # the row READS only
             roofline_gather.update({"achieved_in_step": round(g_in, 1), "frac_in_step": round(g_in / PEAK_HBM_GBS, 4),
                                     "achieved_reads_only_in_step": round(g_rd, 1),
                                     "frac_reads_only_in_step": round(g_rd / PEAK_HBM_GBS, 4),
@@ -384,6 +397,16 @@ def main():
                                                      "batch N+1 runs beside batch N's user-side chain)"})
 
     extra = {}
+    exp_in = kern.get("expand_rows_in_step")
+    if dedup and exp_in and exp_in["avg_ms"] > 0:
+        # the de-duplicated path's HBM-heavy data movement: X[r] = Xu[inv[r]] for the weight gradient (prefetch stream, in step):
+        # reads the distinct rows (L2-resident after the table gather), writes one 1200-B row per token row
+        eb = rows_per_launch * E0 * 4 + uniq_per_launch * E0 * 4 + rows_per_launch * 4
+        eg = eb / (exp_in["avg_ms"] * 1e-3) / 1e9
+        extra["roofline_expand"] = {"kernel": "expand_rows (X = Xu[inv])", "bound": "hbm", "achieved": round(eg, 1), "peak": PEAK_HBM_GBS,
+                                    "unit": "GB/s", "frac": round(eg / PEAK_HBM_GBS, 4), "avg_launch_ms": round(exp_in["avg_ms"], 5),
+                                    "algorithmic_bytes_per_launch": int(eb), "launches": exp_in["launches"],
+                                    "timed": "HIP events on the prefetch stream inside the timed region"}
     if dist_on:                                    # the step's one collective on its own: 20 all-reduces of the gradient buffer
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ts.sync_gradients()
@@ -490,7 +513,10 @@ def main():
                    "global_batch": B * world_size, "parallelism": f"dp{world_size}",
                    "raggedness": "histories ~ clipped geometric (mean 20 of 50 slots), titles ~ U[5,30] tokens: pad rows are skipped",
                    "live_token_rows_per_step": round(rows_per_launch, 1),
-                   "item_instances_per_step": round(inst_per_launch, 1)},
+                   "item_instances_per_step": round(inst_per_launch, 1),
+                   "distinct_tokens_per_step": round(uniq_per_launch, 1) if dedup else None,
+                   "projection": ("once per DISTINCT token of the batch, expanded to the token rows (exact: the frozen-table "
+                                  "projection depends on the token id alone); LEGO_DEDUP=0 projects row by row") if dedup else "row by row"},
         "final_loss": round(final_loss, 5),
         "roofline": roofline, "roofline_gather": roofline_gather,
         "kernels": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kern.items()},

@@ -352,8 +352,8 @@ class NamlEngine(_Base):
             self.kk(s, tag, "lego_gather_rows", _ptr(self.P["embedding_vocab_table.glove.embedding.weight"]), self.E0, self.E0,
                     _ptr(b["uniq"]), self.Uc, _ptr(b["counters"], 6), _ptr(b["Xu"]), self.E0, 0)
             if not self.dedup_bwd:                   # the weight gradient still runs over the token rows: X[r] = Xu[inv[r]]
-                self.kk(s, None, "lego_expand_rows", _ptr(b["Xu"]), self.E0, _ptr(b["inv"]), self.Rc, _ptr(b["counters"], 0), self.E0,
-                        None, _ptr(b["X"]), self.E0)
+                self.kk(s, "expand_rows_in_step" if stream is not None else None, "lego_expand_rows", _ptr(b["Xu"]), self.E0, _ptr(b["inv"]),
+                        self.Rc, _ptr(b["counters"], 0), self.E0, None, _ptr(b["X"]), self.E0)
             return
         # with timers on (bench.py) the launch is bracketed by HIP events on the stream it runs on: on the prefetch stream
         # that is the gather's duration INSIDE the step, overlapped with the previous step's user-side chain

@@ -6,7 +6,7 @@ def short(n):
     n = n.replace("lego::", "").replace("void ", "")
     m = re.match(r"(\w+)<(.*)>\(", n)
     if "gemm_kernel" in n or "strip_kernel" in n or "tn_kernel" in n or "oneshot_kernel" in n:
-        kind = re.match(r"(\w+?)_kernel", n).group(1)
+        kind = "dma_strip" if "dma_strip_kernel" in n else re.match(r"(\w+?)_kernel", n).group(1)
         tc = re.search(r"TileCfg<([\d, ]+)", n)
         ld = re.findall(r"(Kc\w+|Mc\w+)", n)[:2]
         ep = re.search(r"EpiT<([^>]*)>", n)

@@ -11,7 +11,7 @@ t0 = rows[a]['e']
 def short(n):
     n = n.replace('lego::', '').replace('void ', '')
     if 'strip_kernel' in n or 'gemm_kernel' in n:
-        kind = 'strip' if 'strip_kernel' in n else 'gemm'
+        kind = ('dma_strip' if 'dma_strip_kernel' in n else 'strip') if 'strip_kernel' in n else 'gemm'
         tc = re.search(r'TileCfg<([\d, ]+)', n)
         ld = re.findall(r'(Kc\w+|Mc\w+)', n)[:2]
         ep = re.search(r'EpiT<([^>]*)>', n).group(1).replace('false', '0').replace('true', '1').replace(' ', '')
