@@ -43,6 +43,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+_json_out = sys.stdout
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 WINO_ISSUE = 2.0 / 3.0            # Winograd F(2,3): 4 C MACs per row pair and output column instead of 6 C
@@ -248,6 +249,12 @@ def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args, sys.argv[1:]))
+    # the ONE JSON line goes to the process's real stdout; everything else that writes to file descriptor 1 from here on
+    # (RCCL prints a version banner there when a communicator is created) is sent to stderr, so the line stays alone
+    global _json_out
+    _json_out = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -528,7 +535,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(world, B, D, args.cpu_steps)
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out))
+    _json_out.write(json.dumps(out) + "\n")
+    _json_out.flush()
     if dist_on:
         torch.distributed.destroy_process_group()
 

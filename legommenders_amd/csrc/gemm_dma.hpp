@@ -45,9 +45,14 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_dst_uniform) {
 }
 
 // operands: A = plain K-contiguous rows (KcRows); B = KcRows (NT) or McRows (NN)
-template <int NF, bool B_MC, class BLoad, class Epi>
+// NW waves side by side over the 256 columns, CF = 16 / NW column fragments each: 8 x 2 (two waves per SIMD, 256 VGPRs each) or
+// 4 x 4 (ONE wave per SIMD with up to 512 registers: half the LDS fragment reads per MFMA, a 4-wave barrier, no partner wave to
+// arbitrate the matrix pipe with -- and none to hide a stall behind)
+template <int NF, bool B_MC, int NW, class BLoad, class Epi>
 __device__ __forceinline__ void dma_pass(const KcRows& la, const BLoad& lb, Epi& epi, char* lds, int m0, int m_end, int n0, int K) {
     constexpr int STAGE = dma_stage_bytes<B_MC>();
+    constexpr int CF = 16 / NW, AI = 16 / NW, BI = 32 / NW;     // column fragments per wave; glds per wave and tile for A / B
+    static_assert(NW == 4 || NW == 8, "8 x 2 or 4 x 4 waves x column fragments");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -57,32 +62,32 @@ __device__ __forceinline__ void dma_pass(const KcRows& la, const BLoad& lb, Epi&
 
     // ---- DMA sources.  KC images: lane = (row lane >> 3 of the instruction's 8 rows, slot lane & 7); chunk = slot ^ (row & 7)
     const int chunk = (lane & 7) ^ (lane >> 3);              // every instruction starts at a row that is a multiple of 8
-    const char* pa[2];
+    const char* pa[AI];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-        pa[j] = reinterpret_cast<const char*>(la.p + (size_t)min(m0 + 16 * wave + 8 * j + (lane >> 3), la.ext - 1) * la.ld);
-    const char* pb[4];
-    if constexpr (B_MC) {                                    // instruction j of the wave = k row 4 * wave + j, lane = 4 columns
+    for (int j = 0; j < AI; ++j)
+        pa[j] = reinterpret_cast<const char*>(la.p + (size_t)min(m0 + 8 * (AI * wave + j) + (lane >> 3), la.ext - 1) * la.ld);
+    const char* pb[BI];
+    if constexpr (B_MC) {                                    // instruction j of the wave = k row BI * wave + j, lane = 4 columns
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pb[j] = reinterpret_cast<const char*>(lb.p + min(n0 + 4 * lane, lb.ext - 4));
+        for (int j = 0; j < BI; ++j) pb[j] = reinterpret_cast<const char*>(lb.p + min(n0 + 4 * lane, lb.ext - 4));
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            pb[j] = reinterpret_cast<const char*>(lb.p + (size_t)min(n0 + 32 * wave + 8 * j + (lane >> 3), lb.ext - 1) * lb.ld);
+        for (int j = 0; j < BI; ++j)
+            pb[j] = reinterpret_cast<const char*>(lb.p + (size_t)min(n0 + 8 * (BI * wave + j) + (lane >> 3), lb.ext - 1) * lb.ld);
     }
     auto issue = [&](int t, int stage) {
         char* sA = lds + stage * STAGE;
         char* sB = sA + DMA_A_BYTES;
         const int kc = min(t * BK + 4 * chunk, K - 4) * 4;   // byte offset of this lane's chunk inside its row (clamped: tail tile)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) glds16(pa[j] + kc, sA + (16 * wave + 8 * j) * DMA_ROW_BYTES);
+        for (int j = 0; j < AI; ++j) glds16(pa[j] + kc, sA + 8 * (AI * wave + j) * DMA_ROW_BYTES);
         if constexpr (B_MC) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                glds16(pb[j] + (size_t)min(t * BK + 4 * wave + j, K - 1) * lb.ld * 4, sB + (4 * wave + j) * (DMA_MC_LD * 4));
+            for (int j = 0; j < BI; ++j)
+                glds16(pb[j] + (size_t)min(t * BK + BI * wave + j, K - 1) * lb.ld * 4, sB + (BI * wave + j) * (DMA_MC_LD * 4));
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) glds16(pb[j] + kc, sB + (32 * wave + 8 * j) * DMA_ROW_BYTES);
+            for (int j = 0; j < BI; ++j) glds16(pb[j] + kc, sB + 8 * (BI * wave + j) * DMA_ROW_BYTES);
         }
     };
 
@@ -91,16 +96,16 @@ __device__ __forceinline__ void dma_pass(const KcRows& la, const BLoad& lb, Epi&
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         offA[q] = l16 * DMA_ROW_BYTES + (((4 * q + g4) ^ (l16 & 7)) << 4);
-        if constexpr (B_MC) offB[q] = DMA_A_BYTES + ((16 * q + 4 * g4) * DMA_MC_LD + wave * 32 + l16) * 4;
-        else offB[q] = DMA_A_BYTES + (wave * 32 + l16) * DMA_ROW_BYTES + (((4 * q + g4) ^ (l16 & 7)) << 4);
+        if constexpr (B_MC) offB[q] = DMA_A_BYTES + ((16 * q + 4 * g4) * DMA_MC_LD + wave * (16 * CF) + l16) * 4;
+        else offB[q] = DMA_A_BYTES + (wave * (16 * CF) + l16) * DMA_ROW_BYTES + (((4 * q + g4) ^ (l16 & 7)) << 4);
     }
-    auto read_frags = [&](int stage, int q, f32x4 (&fa)[NF], f32x4 (&fb)[2]) {
+    auto read_frags = [&](int stage, int q, f32x4 (&fa)[NF], f32x4 (&fb)[CF]) {
         const char* sA = lds + stage * STAGE + offA[q];
         const char* sB = lds + stage * STAGE + offB[q];
 #pragma unroll
         for (int a = 0; a < NF; ++a) fa[a] = *reinterpret_cast<const f32x4*>(sA + a * 16 * DMA_ROW_BYTES);
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < CF; ++b) {
             if constexpr (B_MC) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) fb[b][j] = *reinterpret_cast<const float*>(sB + (j * DMA_MC_LD + b * 16) * 4);
@@ -110,17 +115,17 @@ __device__ __forceinline__ void dma_pass(const KcRows& la, const BLoad& lb, Epi&
         }
     };
 
-    f32x4 acc[NF][2];
+    f32x4 acc[NF][CF];
 #pragma unroll
     for (int a = 0; a < NF; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 fa0[NF], fb0[2], fa1[NF], fb1[2];
-    auto mfma_j = [&](const f32x4 (&fa)[NF], const f32x4 (&fb)[2], int j) {
+        for (int b = 0; b < CF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 fa0[NF], fb0[CF], fa1[NF], fb1[CF];
+    auto mfma_j = [&](const f32x4 (&fa)[NF], const f32x4 (&fb)[CF], int j) {
 #pragma unroll
         for (int a = 0; a < NF; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < CF; ++b)
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
     };
 
@@ -130,10 +135,14 @@ __device__ __forceinline__ void dma_pass(const KcRows& la, const BLoad& lb, Epi&
     // (a previous pass's epilogue stores may still be draining: vmcnt retires in issue order on gfx9-family parts -- LLVM's own
     // counted waits rely on it -- so older stores only make the counted waits below conservative, and they drain under this
     // pass's MFMAs)
+    auto wait_one_in_flight = [&]() {                        // the tile issued last stays in flight: AI + BI glds of this wave
+        if constexpr (NW == 8) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+    };
     issue(0, 0);
     if (T > 1) {
         issue(1, 1);
-        asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+        wait_one_in_flight();
     } else {
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
@@ -149,14 +158,14 @@ __device__ __forceinline__ void dma_pass(const KcRows& la, const BLoad& lb, Epi&
             const int kmax = t + 1 < T ? BK : rem;
             const bool v0 = 4 * g4 < kmax, v1 = 16 + 4 * g4 < kmax;
 #pragma unroll
-            for (int b = 0; b < 2; ++b) { fb0[b] = zero_unless(v0, fb0[b]); fb1[b] = zero_unless(v1, fb1[b]); }
+            for (int b = 0; b < CF; ++b) { fb0[b] = zero_unless(v0, fb0[b]); fb1[b] = zero_unless(v1, fb1[b]); }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) mfma_j(fa0, fb0, j);
 #pragma unroll
         for (int j = 0; j < 3; ++j) mfma_j(fa1, fb1, j);
         if (t + 1 < T) {
-            if (t + 2 < T) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+            if (t + 2 < T) wait_one_in_flight();
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             const int s1 = sc == 2 ? 0 : sc + 1;
             read_frags(s1, 0, fa0, fb0);
@@ -169,20 +178,28 @@ __device__ __forceinline__ void dma_pass(const KcRows& la, const BLoad& lb, Epi&
     for (int t = 0; t < T; ++t) body(t);
     asm volatile("s_barrier" ::: "memory");                // every DMA has landed (vmcnt(0) above) and every wave has read its last
                                                             // fragments: the stages are free for the epilogue's row tiles
-    if (epi.rows_form_ok()) {
-        epi.template run16_rows<NF>(acc, m0, m_end, n0 + wave * 32, l16, g4, reinterpret_cast<float*>(lds) + wave * (NF * 16 * 32));
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // a next pass refills the stages
-    } else {
-        epi.template run16<NF>(acc, m0, m_end, n0 + wave * 32, l16, g4);
-    }
+    const bool rows_form = epi.rows_form_ok();
+    float* tile = reinterpret_cast<float*>(lds) + wave * (NF * 16 * 32);
+    auto slab = [&](auto hh) {                               // one 32-column slab of the wave's columns
+        constexpr int h = decltype(hh)::value;
+        f32x4 part[NF][2];
+#pragma unroll
+        for (int a = 0; a < NF; ++a) { part[a][0] = acc[a][2 * h]; part[a][1] = acc[a][2 * h + 1]; }
+        const int nb = n0 + wave * (16 * CF) + 32 * h;
+        if (rows_form) epi.template run16_rows<NF>(part, m0, m_end, nb, l16, g4, tile);
+        else epi.template run16<NF>(part, m0, m_end, nb, l16, g4);
+    };
+    slab(std::integral_constant<int, 0>{});
+    if constexpr (CF == 4) slab(std::integral_constant<int, 1>{});
+    if (rows_form) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // a next pass refills the stages
 }
 
 // Passes of at most DMA_BM = 112 rows (7 row fragments), not 128: with 8 fragments the kernel needs all 256 VGPRs that 512
 // threads allow, two of its waves fill a SIMD's 512 registers, and the side streams' single-wave products (gemm_oneshot.hpp
 // light_kernel, fold_ops.hip: 40-72 VGPRs, no LDS) can not START beside it -- the step was 25 us LONGER than with the
 // register-staged strip kernel although every product that uses this kernel was shorter.
-template <bool B_MC, class BLoad, class Epi>
-__global__ __launch_bounds__(STRIP_THREADS) void dma_strip_kernel(GemmDims dims, KcRows la, BLoad lb, Epi epi) {
+template <bool B_MC, int NW, class BLoad, class Epi>
+__global__ __launch_bounds__(NW * 64) void dma_strip_kernel(GemmDims dims, KcRows la, BLoad lb, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
     int M = dims.M;
@@ -207,10 +224,10 @@ __global__ __launch_bounds__(STRIP_THREADS) void dma_strip_kernel(GemmDims dims,
         const int m_end = min(strip_end, m0 + sp.sub);
         const int nf = (m_end - m0 + 15) >> 4;              // block-uniform
         switch (nf) {
-            case 1: case 2: dma_pass<2, B_MC>(la, lb, epi, lds, m0, m_end, n0, K); break;
-            case 3: case 4: dma_pass<4, B_MC>(la, lb, epi, lds, m0, m_end, n0, K); break;
-            case 5: case 6: dma_pass<6, B_MC>(la, lb, epi, lds, m0, m_end, n0, K); break;
-            default: dma_pass<7, B_MC>(la, lb, epi, lds, m0, m_end, n0, K); break;
+            case 1: case 2: dma_pass<2, B_MC, NW>(la, lb, epi, lds, m0, m_end, n0, K); break;
+            case 3: case 4: dma_pass<4, B_MC, NW>(la, lb, epi, lds, m0, m_end, n0, K); break;
+            case 5: case 6: dma_pass<6, B_MC, NW>(la, lb, epi, lds, m0, m_end, n0, K); break;
+            default: dma_pass<7, B_MC, NW>(la, lb, epi, lds, m0, m_end, n0, K); break;
         }
     }
 }

@@ -337,11 +337,19 @@ static int launch_strip(const GemmDims& d, const AL& a, const BL& b, const Epi& 
 }
 
 // the same split with LDS-DMA operand staging (gemm_dma.hpp): plain-row operands only
-template <bool B_MC, class EK, class BL>
+static int dma_waves() {           // LEGO_DMA_WAVES=4: one wave per SIMD (4 x 4 column fragments, up to 512 registers); default 8
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("LEGO_DMA_WAVES"); v = (e != nullptr && e[0] == '4') ? 4 : 8; }
+    return v;
+}
+
+template <bool B_MC, class EK, class BL, int NW = 8>
 static int launch_dma_strip(const GemmDims& d, const KcRows& a, const BL& b, const Epi& e0, hipStream_t st, const char* what) {
+    if constexpr (NW == 8)
+        if (dma_waves() == 4) return launch_dma_strip<B_MC, EK, BL, 4>(d, a, b, e0, st, what);
     EK e;
     static_cast<EpiArgs&>(e) = e0;
-    auto k = dma_strip_kernel<B_MC, BL, EK>;
+    auto k = dma_strip_kernel<B_MC, NW, BL, EK>;
     constexpr size_t lds = dma_lds_bytes<B_MC>();
     static bool attr_done = false;
     if (!attr_done) {
@@ -349,7 +357,7 @@ static int launch_dma_strip(const GemmDims& d, const KcRows& a, const BL& b, con
         attr_done = true;
     }
     const int n_panels = (d.N + STRIP_BN - 1) / STRIP_BN;
-    hipLaunchKernelGGL(k, dim3(num_cus() / n_panels * n_panels), dim3(STRIP_THREADS), lds, st, d, a, b, e);
+    hipLaunchKernelGGL(k, dim3(num_cus() / n_panels * n_panels), dim3(NW * 64), lds, st, d, a, b, e);
     return check_launch(what);
 }
 
@@ -705,6 +713,7 @@ extern "C" int lego_debug_gemm_nt(int variant, const float* x, const float* W, c
         case 8: return launch<TileCfg<128, 128, 2, 4, true>, false, false, EpiPlain>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, 1, st, "dbg8");
         case 9: return launch_strip<false, EpiPlain>(d, a, b, e, st, "dbg9");
         case 10: return launch_dma_strip<false, EpiPlain>(d, a, b, e, st, "dbg10");
+        case 13: return launch_dma_strip<false, EpiPlain, KcRows, 4>(d, a, b, e, st, "dbg13");
         default: return set_error("lego_debug_gemm_nt: unknown variant %d", variant);
     }
 }

@@ -405,36 +405,54 @@ __global__ __launch_bounds__(256) void expand_rows_kernel(const float* __restric
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     const int n_waves = gridDim.x * (blockDim.x >> 6);
-    constexpr int U = 4;
-    const int c = blockIdx.y * 256 + 4 * lane;               // widths above 256: one column block of 256 per blockIdx.y
-    const bool in = c < width;
+    constexpr int U = 4;                                     // a wave owns FOUR CONSECUTIVE rows 4g .. 4g+3: they share one keep-bit word
+    const int c = blockIdx.y * 512 + 4 * lane;               // lane moves columns c .. c+3 and c+256 .. c+259 (rows up to 512 wide
+    const int c2 = c + 256;                                  // per blockIdx.y: a 300-float GloVe row is one wave's work)
+    const bool in = c < width, in2 = c2 < width;
     const float dinv = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
-    for (int r0 = wave; r0 < rows; r0 += U * n_waves) {
-        f32x4 v[U];
-        uint32_t kw[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int r = r0 + u * n_waves;
-            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            kw[u] = 0x0f0f0f0fu;
-            if (r < rows && in) {
-                v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)inv[r] * ld_src + c);
-                if (drop.p > 0.f) {
-                    if (drop.mask != nullptr) kw[u] = *reinterpret_cast<const uint32_t*>(drop.mask + (uint64_t)(r >> 2) * (uint64_t)width + (uint64_t)c);
-                    else kw[u] = dropout_draw4(drop, r & ~3, c, width) | (dropout_draw4(drop, r & ~3, c + 1, width) << 8) |
-                                 (dropout_draw4(drop, r & ~3, c + 2, width) << 16) | (dropout_draw4(drop, r & ~3, c + 3, width) << 24);
-                }
+    const bool dropping = drop.p > 0.f;
+    for (int g = wave; 4 * g < rows; g += n_waves) {
+        const int r0 = 4 * g;
+        f32x4 v[U], v2[U];
+        uint32_t kw = 0x0f0f0f0fu, kw2 = 0x0f0f0f0fu;
+        if (dropping) {
+            if (drop.mask != nullptr) {
+                if (in) kw = *reinterpret_cast<const uint32_t*>(drop.mask + (uint64_t)g * (uint64_t)width + (uint64_t)c);
+                if (in2) kw2 = *reinterpret_cast<const uint32_t*>(drop.mask + (uint64_t)g * (uint64_t)width + (uint64_t)c2);
+            } else {
+                if (in) kw = dropout_draw4(drop, r0, c, width) | (dropout_draw4(drop, r0, c + 1, width) << 8) |
+                             (dropout_draw4(drop, r0, c + 2, width) << 16) | (dropout_draw4(drop, r0, c + 3, width) << 24);
+                if (in2) kw2 = dropout_draw4(drop, r0, c2, width) | (dropout_draw4(drop, r0, c2 + 1, width) << 8) |
+                               (dropout_draw4(drop, r0, c2 + 2, width) << 16) | (dropout_draw4(drop, r0, c2 + 3, width) << 24);
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int r = r0 + u * n_waves;
-            if (r >= rows || !in) continue;
-            const uint32_t k = kw[u] >> (r & 3);
-            f32x4 o;
+            const int r = r0 + u;
+            v[u] = v2[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r < rows) {
+                const float* row = src + (size_t)inv[r] * ld_src;               // inv[r]: wave-uniform
+                if (in) v[u] = *reinterpret_cast<const f32x4*>(row + c);
+                if (in2) v2[u] = *reinterpret_cast<const f32x4*>(row + c2);
+            }
+        }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = (k >> (8 * i)) & 1u ? v[u][i] * dinv : 0.f;
-            *reinterpret_cast<f32x4*>(out + (size_t)r * ld_out + c) = o;
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + u;
+            if (r >= rows) break;
+            float* dst = out + (size_t)r * ld_out;
+            if (in) {
+                f32x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (kw >> (8 * i + u)) & 1u ? v[u][i] * dinv : 0.f;
+                *reinterpret_cast<f32x4*>(dst + c) = o;
+            }
+            if (in2) {
+                f32x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (kw2 >> (8 * i + u)) & 1u ? v2[u][i] * dinv : 0.f;
+                *reinterpret_cast<f32x4*>(dst + c2) = o;
+            }
         }
     }
 }
@@ -1470,8 +1488,8 @@ extern "C" int lego_expand_rows(const float* src, int ld_src, const int32_t* inv
                                 const lego_dropout* drop, float* out, int ld_out, void* stream) {
     LEGO_REQUIRE((width & 3) == 0 && (ld_src & 3) == 0 && (ld_out & 3) == 0, "lego_expand_rows: width=%d must be a multiple of 4", width);
     if (rows_cap <= 0) return 0;
-    const int want = (rows_cap + 15) / 16;
-    hipLaunchKernelGGL(expand_rows_kernel, dim3(want < 1024 ? want : 1024, (width + 255) / 256), dim3(256), 0, ST, src, ld_src, inv, rows_cap, rows_dyn, width,
+    const int want = (rows_cap + 15) / 16;                 // four waves per block, four consecutive rows per wave and iteration
+    hipLaunchKernelGGL(expand_rows_kernel, dim3(want < 2048 ? want : 2048, (width + 511) / 512), dim3(256), 0, ST, src, ld_src, inv, rows_cap, rows_dyn, width,
                        make_dropout(drop), out, ld_out);
     return check_launch("lego_expand_rows");
 }
