@@ -1074,6 +1074,10 @@ class NrmsEngine(_Base):
                 call("lego_small_rows_matmul_add", _ptr(ws["S_sep"]), 1, _ptr(g_spec, 2 * D), D, _ptr(ws["S_cat"]), n_cat, _ptr(g_cat), D,
                      _ptr(W_in), 3 * D, D, spp)
             self._deferred.append(side_special)
+        elif n_cat > 32:                             # category tables beyond the segment kernel's 32-row LDS image: two generic
+            # scatters over the sequence rows (the segment kernel replaced them and hard-failed above 32 rows)
+            call("lego_scatter_add_rows", _ptr(g_cat), D, D, n_cat, _ptr(self.idx_cat), self.Rc, self.cnt(0), _ptr(self.dE), D, st)
+            call("lego_scatter_add_rows", _ptr(g_spec), D, D, 3, _ptr(self.idx_spec), self.Rc, self.cnt(0), _ptr(self.dE), D, st)
         else:
             call("lego_nrms_special_grads", _ptr(self.seg_off), self.NIc, self.cnt(1), _ptr(self.idx_cat), _ptr(self.dE), D, D,
                  _ptr(g_spec, 2 * D), _ptr(g_cat), D, n_cat, st)
