@@ -86,9 +86,12 @@ int64_t lego_sort_rows_temp_bytes(int n);
 int lego_expand_rows(const float* src, int ld_src, const int32_t* inv, int rows_cap, const int32_t* rows_dyn, int width,
                      const lego_dropout* drop, float* out, int ld_out, void* stream);
 /* out[u,:] = sum over rows r with inv[r] == u of g[r,:] (u < U; perm = the rows grouped by inv): the per-token sums the
- * projection's weight gradient is formed from.  Clears out[0:U] first. */
+ * projection's weight gradient is formed from.  out[0:U] must be zero on entry: zero_first = 1 clears it here, 0 = the caller
+ * has (lego_zero_rows, e.g. on another stream ahead of time). */
 int lego_segment_sum_rows(const float* g, int ld_g, int width, const int32_t* perm, const int32_t* inv, int R_cap,
-                          const int32_t* R_dyn, float* out, int ld_out, int U_cap, const int32_t* U_dyn, void* stream);
+                          const int32_t* sorted_keys /*nullable: inv[perm[p]] per position, lego_sort_rows' key output*/,
+                          const int32_t* R_dyn, float* out, int ld_out, int U_cap, const int32_t* U_dyn, int zero_first, void* stream);
+int lego_zero_rows(float* out, int ld_out, int width, int rows_cap, const int32_t* rows_dyn /*nullable*/, void* stream);
 /* backward of a TRAINABLE table (embed/null.yaml): grad_table[idx[r]] += g[r] (dense grad semantics) */
 int lego_scatter_add_rows(float* grad_table, int ld_table, int width, int table_rows /*<= 32: LDS pre-reduction*/,
                           const int32_t* idx, int rows_cap, const int32_t* rows_dyn, const float* g, int ld_g, void* stream);

@@ -476,7 +476,7 @@ static int launch_tn(int M, int N, int K_cap, const int* k_dyn, const AL& a, con
         const int tm = (M + 63) / 64, tn = (N + 63) / 64;
         const int deal = split % 8 == 0;
         TnDims d{M, N, K_cap, k_dyn, split, taps, 0, tm, tn, deal};
-        if (K_cap >= TN_LONG) d.min_chunk = 512;       // (the de-duplicated projection: 4.6 k distinct tokens under a 105 k capacity)
+        if (K_cap >= TN_LONG) d.min_chunk = 256;       // (the de-duplicated projection: 4.6 k distinct tokens under a 105 k capacity)
         auto k = tn_kernel<AL, BL, false, 2, 2, 1>;
         constexpr size_t lds = tn_lds_bytes(TN_BM_S, TN_BN_S, false);
         hipLaunchKernelGGL(k, deal ? dim3(tm * tn * taps * split) : dim3(tm, tn, taps * split), dim3(TN_THREADS_S), lds, st, d, a, b, e);

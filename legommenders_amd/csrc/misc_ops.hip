@@ -470,56 +470,76 @@ __global__ void zero_rows_kernel(float* out, int ld, int width, int rows_cap, co
     }
 }
 
-constexpr int kSegRows = 16;         // positions of `perm` per wave: all 16 row loads are issued before the first add
+constexpr int kSegRows = 32;         // positions of `perm` per wave, as two batches of 16 row loads in flight
+constexpr int kSegBatch = 16;
+
+// add a wave's f32x4-per-lane row (lane = 4 consecutive columns) to out_row with float atomics whose every instruction covers 256
+// CONTIGUOUS bytes (instruction i: columns 64 i + lane; fetched from lane 16 i + lane / 4): the memory-side atomic units take a
+// 256-B wave-instruction as four 64-B requests, the 16-B-per-lane layout as sixteen (MI355X_MICROARCH.md, "Global float atomics")
+__device__ __forceinline__ void atomic_add_row(float* out_row, int col0, int width, const f32x4& acc, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int src = 16 * i + (lane >> 2);
+        const float t0 = __shfl(acc[0], src, 64), t1 = __shfl(acc[1], src, 64), t2 = __shfl(acc[2], src, 64), t3 = __shfl(acc[3], src, 64);
+        const int e = lane & 3;
+        const float v = e == 0 ? t0 : (e == 1 ? t1 : (e == 2 ? t2 : t3));
+        const int c = col0 + 64 * i + lane;
+        if (c < width) atomicAdd(out_row + c, v);
+    }
+}
+
 __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float* __restrict__ g, int ld_g, int width, const int* __restrict__ perm,
-                                                               const int* __restrict__ inv, int R_cap, const int* __restrict__ R_dyn,
-                                                               float* out, int ld_out) {
+                                                               const int* __restrict__ inv, const int* __restrict__ sorted_keys,
+                                                               int R_cap, const int* __restrict__ R_dyn, float* out, int ld_out) {
     const int R = R_dyn != nullptr ? min(R_cap, *R_dyn) : R_cap;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     const int p0 = wave * kSegRows;
     if (p0 >= R) return;
     const int n = min(kSegRows, R - p0);
-    const int c = blockIdx.y * 256 + 4 * lane;
+    const int col0 = blockIdx.y * 256;
+    const int c = col0 + 4 * lane;
     const bool in = c < width;
     // lanes 0 .. kSegRows + 1: position p0 - 1 + lane (one before and one past the chunk, for the two boundary decisions)
     const int pp = p0 - 1 + lane;
     int my_row = 0, my_u = -1;
-    if (lane < kSegRows + 2 && pp >= 0 && pp < R) { my_row = perm[pp]; my_u = inv[my_row]; }
+    if (lane < kSegRows + 2 && pp >= 0 && pp < R) {              // sorted_keys (the sort's key output) saves the dependent inv[] load
+        my_row = perm[pp];
+        my_u = sorted_keys != nullptr ? sorted_keys[pp] : inv[my_row];
+    }
     const int u_before = __shfl(my_u, 0, 64);                     // -1 when p0 == 0
     int cur = __shfl(my_u, 1, 64);
     bool began_here = cur != u_before;
-    f32x4 v[kSegRows];
-    int uu[kSegRows];
-#pragma unroll
-    for (int j = 0; j < kSegRows; ++j) {
-        const int row = __shfl(my_row, 1 + min(j, n - 1), 64);
-        uu[j] = __shfl(my_u, 1 + min(j, n - 1), 64);
-        v[j] = (j < n && in) ? *reinterpret_cast<const f32x4*>(g + (size_t)row * ld_g + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b0 = 0; b0 < n; b0 += kSegBatch) {
+        f32x4 v[kSegBatch];
+        int uu[kSegBatch];
 #pragma unroll
-    for (int j = 0; j < kSegRows; ++j) {
-        if (j < n) {
-            if (uu[j] != cur) {                                    // wave-uniform: the group ended inside the chunk
-                if (in) {
-                    float* dst = out + (size_t)cur * ld_out + c;
-                    if (began_here) *reinterpret_cast<f32x4*>(dst) = acc;
-                    else { atomicAdd(dst, acc[0]); atomicAdd(dst + 1, acc[1]); atomicAdd(dst + 2, acc[2]); atomicAdd(dst + 3, acc[3]); }
+        for (int j = 0; j < kSegBatch; ++j) {
+            const int i = min(b0 + j, n - 1);
+            const int row = __shfl(my_row, 1 + i, 64);
+            uu[j] = __shfl(my_u, 1 + i, 64);
+            v[j] = (b0 + j < n && in) ? *reinterpret_cast<const f32x4*>(g + (size_t)row * ld_g + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < kSegBatch; ++j) {
+            if (b0 + j < n) {
+                if (uu[j] != cur) {                                // wave-uniform: the group ended inside the chunk
+                    float* dst = out + (size_t)cur * ld_out;
+                    if (began_here) { if (in) *reinterpret_cast<f32x4*>(dst + c) = acc; }
+                    else atomic_add_row(dst, col0, width, acc, lane);
+                    acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                    cur = uu[j];
+                    began_here = true;
                 }
-                acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                cur = uu[j];
-                began_here = true;
+                acc += v[j];
             }
-            acc += v[j];
         }
     }
     const int u_after = __shfl(my_u, 1 + n, 64);                   // -1 past the end of the rows
-    if (in) {
-        float* dst = out + (size_t)cur * ld_out + c;
-        if (began_here && (p0 + n >= R || u_after != cur)) *reinterpret_cast<f32x4*>(dst) = acc;
-        else { atomicAdd(dst, acc[0]); atomicAdd(dst + 1, acc[1]); atomicAdd(dst + 2, acc[2]); atomicAdd(dst + 3, acc[3]); }
-    }
+    float* dst = out + (size_t)cur * ld_out;
+    if (began_here && (p0 + n >= R || u_after != cur)) { if (in) *reinterpret_cast<f32x4*>(dst + c) = acc; }
+    else atomic_add_row(dst, col0, width, acc, lane);
 }
 
 // NRMS sequence rows: the plan's row_tok word encodes token id (>= 0), SEP (-2) or category (-(3+cat))
@@ -1494,13 +1514,24 @@ extern "C" int lego_expand_rows(const float* src, int ld_src, const int32_t* inv
     return check_launch("lego_expand_rows");
 }
 
+extern "C" int lego_zero_rows(float* out, int ld_out, int width, int rows_cap, const int32_t* rows_dyn, void* stream) {
+    LEGO_REQUIRE((width & 3) == 0 && (ld_out & 3) == 0, "lego_zero_rows: width=%d ld=%d must be multiples of 4", width, ld_out);
+    if (rows_cap <= 0) return 0;
+    const long long tot = (long long)rows_cap * (width / 4);
+    hipLaunchKernelGGL(zero_rows_kernel, dim3((int)((tot + 255) / 256 < 2048 ? (tot + 255) / 256 : 2048)), dim3(256), 0, ST, out, ld_out, width, rows_cap, rows_dyn);
+    return check_launch("lego_zero_rows");
+}
+
 extern "C" int lego_segment_sum_rows(const float* g, int ld_g, int width, const int32_t* perm, const int32_t* inv, int R_cap,
-                                     const int32_t* R_dyn, float* out, int ld_out, int U_cap, const int32_t* U_dyn, void* stream) {
+                                     const int32_t* sorted_keys, const int32_t* R_dyn, float* out, int ld_out, int U_cap,
+                                     const int32_t* U_dyn, int zero_first, void* stream) {
     LEGO_REQUIRE((width & 3) == 0 && (ld_g & 3) == 0 && (ld_out & 3) == 0, "lego_segment_sum_rows: width=%d must be a multiple of 4", width);
     if (R_cap <= 0) return 0;
-    const long long tot = (long long)U_cap * (width / 4);
-    hipLaunchKernelGGL(zero_rows_kernel, dim3((int)((tot + 255) / 256 < 2048 ? (tot + 255) / 256 : 2048)), dim3(256), 0, ST, out, ld_out, width, U_cap, U_dyn);
-    hipLaunchKernelGGL(segment_sum_rows_kernel, dim3((R_cap + 4 * kSegRows - 1) / (4 * kSegRows), (width + 255) / 256), dim3(256), 0, ST, g, ld_g, width, perm, inv, R_cap, R_dyn, out, ld_out);
+    if (zero_first) {
+        const long long tot = (long long)U_cap * (width / 4);
+        hipLaunchKernelGGL(zero_rows_kernel, dim3((int)((tot + 255) / 256 < 2048 ? (tot + 255) / 256 : 2048)), dim3(256), 0, ST, out, ld_out, width, U_cap, U_dyn);
+    }
+    hipLaunchKernelGGL(segment_sum_rows_kernel, dim3((R_cap + 4 * kSegRows - 1) / (4 * kSegRows), (width + 255) / 256), dim3(256), 0, ST, g, ld_g, width, perm, inv, sorted_keys, R_cap, R_dyn, out, ld_out);
     return check_launch("lego_segment_sum_rows");
 }
 

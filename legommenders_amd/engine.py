@@ -246,11 +246,13 @@ class NamlEngine(_Base):
         # with the site's per-row dropout (H), and its weight gradient is formed from per-token sums of dH (dHu).  Exact up
         # to fp32 summation order; LEGO_DEDUP=0 keeps the row-by-row projection (X -> H).
         self.dedup = os.environ.get("LEGO_DEDUP", "1") != "0" and self.Rc > 0
-        # the weight gradient from per-token sums of dH (lego_sort_rows + lego_segment_sum_rows + a product over the distinct
-        # tokens) is built and tested, but measured SLOWER on the bench world: its Zipf head puts a fifth of the rows into one
-        # group, whose partial sums meet in one 1-KB row (46 us for the sums + 25 for the product against 54 for the product over
-        # the token rows) -- off by default
-        self.dedup_bwd = self.dedup and os.environ.get("LEGO_DEDUP_BWD", "0") == "1"
+        # ... and the weight gradient from per-token sums of dH: rows grouped by token with a radix sort on the prefetch stream
+        # (lego_sort_rows), lego_segment_sum_rows (32 sorted rows per wave; groups inside a wave's rows are stored, groups that
+        # span waves -- a Zipf head holds a fifth of the rows -- are added with 256-B-contiguous float atomics onto rows cleared
+        # ahead of time on the side stream), then the product over the distinct tokens: 18 + 21 us against 55 for the product over
+        # the token rows.  (First version: 16 rows per wave, 16-B-strided atomics, a counting sort with an atomic cursor: 46 + 25 us
+        # and 2 x 64 us of serialised int atomics on the prefetch stream -- slower than not de-duplicating.)  LEGO_DEDUP_BWD=0: off
+        self.dedup_bwd = self.dedup and os.environ.get("LEGO_DEDUP_BWD", "1") != "0"
         V = P["embedding_vocab_table.glove.embedding.weight"].shape[0]
         self.V = V
         self.Uc = min(self.Rc, V) if self.dedup else 0
@@ -264,7 +266,7 @@ class NamlEngine(_Base):
             self.inv = torch.zeros(self.Rc, **i32)
             self.perm = torch.zeros(self.Rc, **i32)
             self.uq_keys = torch.zeros(self.Rc, **i32)
-            self.uq_keys_sorted = torch.zeros(self.Rc, **i32)
+            self.keys_sorted = torch.zeros(self.Rc, **i32)                        # per plan slot, like perm
             self.uq_temp = torch.zeros(max(int(_lib.lib().lego_sort_rows_temp_bytes(self.Rc)), 256), dtype=torch.uint8, device=self.dev)
             self.Xu = self._f(self.Uc, E0)
             self.Hu = self._f(self.Uc, D)
@@ -305,7 +307,7 @@ class NamlEngine(_Base):
     # The GloVe table is frozen, so the gathered rows X of a batch depend on its plan only: with plan slots enabled
     # (TrainStep) the gather of step N+1 runs right after its plan on the prefetch stream, off the critical path.
     _PLAN_FIELDS = _Base._PLAN_FIELDS + ("X", "pair_info", "mask_proj", "mask_conv", "inst_cat")
-    _DEDUP_FIELDS = ("Xu", "uniq", "inv", "perm")
+    _DEDUP_FIELDS = ("Xu", "uniq", "inv", "perm", "keys_sorted")
 
     def enable_plan_slots(self):
         if getattr(self, "_slots", None) is None and self.dedup:
@@ -347,7 +349,7 @@ class NamlEngine(_Base):
                     self._uq_epoch, _ptr(self.uq_rank), _ptr(self.uq_bsum), _ptr(b["uniq"]), _ptr(b["inv"]), _ptr(self.uq_cnt),
                     _ptr(self.uq_start), None, _ptr(self.uq_keys) if self.dedup_bwd else None, _ptr(b["counters"], 6))
             if self.dedup_bwd:                       # rows grouped by distinct token: perm (the weight gradient sums dH per token)
-                self.kk(s, None, "lego_sort_rows", _ptr(self.uq_keys), self.Rc, _ptr(self.uq_keys_sorted), _ptr(b["perm"]),
+                self.kk(s, None, "lego_sort_rows", _ptr(self.uq_keys), self.Rc, _ptr(b["keys_sorted"]), _ptr(b["perm"]),
                         _ptr(self.uq_temp), self.uq_temp.numel())
             self.kk(s, tag, "lego_gather_rows", _ptr(self.P["embedding_vocab_table.glove.embedding.weight"]), self.E0, self.E0,
                     _ptr(b["uniq"]), self.Uc, _ptr(b["counters"], 6), _ptr(b["Xu"]), self.E0, 0)
@@ -453,6 +455,8 @@ class NamlEngine(_Base):
         P, D, A, E0 = self.P, self.D, self.A, self.E0
         m, sb, sc = self._lanes()
         ev = self._evs
+        if not gathered:                             # un-planned call: the token rows (and, de-duplicated, the distinct-token count in
+            self.gather_tokens()                     # counters[6] that the side chain's lego_zero_rows reads) BEFORE the fork
         if fork_ev is not None and sb is not m:
             sb.wait_event(fork_ev)
         else:
@@ -470,6 +474,9 @@ class NamlEngine(_Base):
         if zero_loss:
             with torch.cuda.stream(sb):
                 self.loss.zero_()
+        if training and self.dedup_bwd:              # the per-token gradient sums start from zero rows: cleared here, on the side
+            self.kk(sb, None, "lego_zero_rows", _ptr(self.dHu), D, D, self.Uc, self.cnt(6))      # chain the conv waits for anyway
+            self._dhu_zeroed = True
         self.kk(sb, None, "lego_gather_rows", _ptr(P["embedding_vocab_table.category.weight"]), D, D, _ptr(self.inst_cat),
                 self.NIc, self.cnt(1), _ptr(self.cat_emb), D, 0)
         self.kk(sb, None, "lego_linear_fwd", _ptr(self.cat_emb), D, _ptr(P["item_op.linear.weight"]), D,
@@ -478,8 +485,6 @@ class NamlEngine(_Base):
         if sb is not m:
             ev[1].record(sb)
         # main stream: k1 frozen GloVe row gather, then Transformation = Dropout(Linear(.)) (embedding_hub.py:95-96)
-        if not gathered:                             # else: done with the plan on the prefetch stream (plan_on)
-            self.gather_tokens()
         if self.dedup:
             self.kk(m, "proj_fwd", "lego_linear_fwd", _ptr(self.Xu), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
                     _ptr(P["embedding_vocab_table.glove.linear.bias"]), _ptr(self.Hu), D, self.Uc, self.cnt(6), D, E0, 0,
@@ -598,8 +603,10 @@ class NamlEngine(_Base):
                     _ptr(self.dwt), self.Rc, self.cnt(0), D, D)
             self.kk(m, None, "lego_conv3_unpack_add", _ptr(self.dwt), _ptr(G["item_op.cnn.weight"]), D, D)
         if self.dedup_bwd:                           # per-token sums of dH, then the product over the distinct tokens only
-            self.kk(m, "proj_bwd_segsum", "lego_segment_sum_rows", _ptr(self.dH), D, D, _ptr(self.perm), _ptr(self.inv), self.Rc, self.cnt(0),
-                    _ptr(self.dHu), D, self.Uc, self.cnt(6))
+            self.kk(m, "proj_bwd_segsum", "lego_segment_sum_rows", _ptr(self.dH), D, D, _ptr(self.perm), _ptr(self.inv), self.Rc,
+                    _ptr(self.keys_sorted), self.cnt(0), _ptr(self.dHu), D, self.Uc, self.cnt(6),
+                    0 if getattr(self, "_dhu_zeroed", False) else 1)
+            self._dhu_zeroed = False
             self.kk(m, "proj_bwd_weight", "lego_linear_bwd_weight", _ptr(self.dHu), D, _ptr(self.Xu), E0,
                     _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Uc, self.cnt(6), D, E0, None, None)
         else:

@@ -428,7 +428,7 @@ def test_fused_user_tower_matches_unfused():
 
 
 @pytest.mark.parametrize("env", [{"LEGO_SERIAL": "1"}, {"LEGO_WINO": "0"}, {"LEGO_SERIAL": "1", "LEGO_WINO": "0"}, {"LEGO_DEDUP": "0"},
-                                 {"LEGO_DMA": "0"}, {"LEGO_EPI_ROWS": "0"}, {"LEGO_WINO_DMA": "1"}, {"LEGO_DEDUP_BWD": "1"}])
+                                 {"LEGO_DMA": "0"}, {"LEGO_EPI_ROWS": "0"}, {"LEGO_WINO_DMA": "1"}, {"LEGO_DEDUP_BWD": "0"}])
 def test_switches_keep_the_result(env, monkeypatch):
     """the two environment switches the product still reads (tools/README.md): single-stream launch order for profiling and
     the direct three-tap conv instead of the Winograd form -- same logits, loss and gradients as the reference fixture"""
@@ -514,7 +514,12 @@ def test_unique_tokens_expand_and_segment_sum():
     # per-token sums
     gr = torch.randn(R_cap, D, generator=g).to(dev)
     seg = torch.full((Uc, D), 3.0, device=dev)
-    call("lego_segment_sum_rows", P(gr), D, D, P(perm), P(inv), R_cap, P(R_dyn), P(seg), D, Uc, P(n_u), None)
+    call("lego_segment_sum_rows", P(gr), D, D, P(perm), P(inv), R_cap, None, P(R_dyn), P(seg), D, Uc, P(n_u), 1, None)
+    seg2 = torch.full((Uc, D), 3.0, device=dev)
+    call("lego_zero_rows", P(seg2), D, D, Uc, P(n_u), None)
+    call("lego_segment_sum_rows", P(gr), D, D, P(perm), P(inv), R_cap, P(ks), P(R_dyn), P(seg2), D, Uc, P(n_u), 0, None)
+    torch.cuda.synchronize()
+    assert float((seg2[:U] - seg[:U]).abs().max()) <= 1e-4 * float(seg[:U].abs().max()) and bool((seg2[U:] == 3.0).all())
     torch.cuda.synchronize()
     want = torch.zeros(U, D, dtype=torch.float64).index_add_(0, want_inv, gr[:R].cpu().double())
     err = (seg[:U].cpu().double() - want).abs().max() / want.abs().max()
