@@ -348,11 +348,12 @@ class NamlEngine(_Base):
             self.kk(s, None, "lego_unique_tokens", _ptr(b["row_tok"]), self.Rc, _ptr(b["counters"], 0), self.V, _ptr(self.uq_stamp),
                     self._uq_epoch, _ptr(self.uq_rank), _ptr(self.uq_bsum), _ptr(b["uniq"]), _ptr(b["inv"]), _ptr(self.uq_cnt),
                     _ptr(self.uq_start), None, _ptr(self.uq_keys) if self.dedup_bwd else None, _ptr(b["counters"], 6))
-            if self.dedup_bwd:                       # rows grouped by distinct token: perm (the weight gradient sums dH per token)
-                self.kk(s, None, "lego_sort_rows", _ptr(self.uq_keys), self.Rc, _ptr(b["keys_sorted"]), _ptr(b["perm"]),
-                        _ptr(self.uq_temp), self.uq_temp.numel())
             self.kk(s, tag, "lego_gather_rows", _ptr(self.P["embedding_vocab_table.glove.embedding.weight"]), self.E0, self.E0,
                     _ptr(b["uniq"]), self.Uc, _ptr(b["counters"], 6), _ptr(b["Xu"]), self.E0, 0)
+            if self.dedup_bwd:                       # rows grouped by distinct token: perm (the weight gradient sums dH per token).
+                # Behind the table gather: the sort's ~10 small launches would push the gather into the backward's HBM-heavy phase
+                self.kk(s, None, "lego_sort_rows", _ptr(self.uq_keys), self.Rc, _ptr(b["keys_sorted"]), _ptr(b["perm"]),
+                        _ptr(self.uq_temp), self.uq_temp.numel())
             if not self.dedup_bwd:                   # the weight gradient still runs over the token rows: X[r] = Xu[inv[r]]
                 self.kk(s, "expand_rows_in_step" if stream is not None else None, "lego_expand_rows", _ptr(b["Xu"]), self.E0, _ptr(b["inv"]),
                         self.Rc, _ptr(b["counters"], 0), self.E0, None, _ptr(b["X"]), self.E0)
