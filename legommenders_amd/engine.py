@@ -183,7 +183,11 @@ class _Base:
         dummy = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self._training = False
         self._plan(cand, dummy, dummy)
-        self._forward_items(False)
+        self._eval_only = True                       # no backward follows: the de-duplicated path skips its row sort
+        try:
+            self._forward_items(False)
+        finally:
+            self._eval_only = False
         return self.items[:n].clone()
 
     def user_vectors(self, item_repr: torch.Tensor, hist: torch.Tensor, hist_len: torch.Tensor) -> torch.Tensor:
@@ -337,7 +341,7 @@ class NamlEngine(_Base):
             d.mask = (self.mask_proj if site == SITE_PROJ else self.mask_conv).data_ptr()
         return ctypes.byref(d)
 
-    def gather_tokens(self, stream=None, into=None):
+    def gather_tokens(self, stream=None, into=None, need_perm=True):
         """k1: X[r, :] = glove[row_tok[r], :] for the planned token rows (embedding_hub.py:95, frozen table)"""
         b = self.__dict__ if into is None else into
         s = torch.cuda.current_stream() if stream is None else stream
@@ -350,7 +354,7 @@ class NamlEngine(_Base):
                     _ptr(self.uq_start), None, _ptr(self.uq_keys) if self.dedup_bwd else None, _ptr(b["counters"], 6))
             self.kk(s, tag, "lego_gather_rows", _ptr(self.P["embedding_vocab_table.glove.embedding.weight"]), self.E0, self.E0,
                     _ptr(b["uniq"]), self.Uc, _ptr(b["counters"], 6), _ptr(b["Xu"]), self.E0, 0)
-            if self.dedup_bwd:                       # rows grouped by distinct token: perm (the weight gradient sums dH per token).
+            if self.dedup_bwd and need_perm:         # rows grouped by distinct token: perm (the weight gradient sums dH per token).
                 # Behind the table gather: the sort's ~10 small launches would push the gather into the backward's HBM-heavy phase
                 self.kk(s, None, "lego_sort_rows", _ptr(self.uq_keys), self.Rc, _ptr(b["keys_sorted"]), _ptr(b["perm"]),
                         _ptr(self.uq_temp), self.uq_temp.numel())
@@ -457,7 +461,7 @@ class NamlEngine(_Base):
         m, sb, sc = self._lanes()
         ev = self._evs
         if not gathered:                             # un-planned call: the token rows (and, de-duplicated, the distinct-token count in
-            self.gather_tokens()                     # counters[6] that the side chain's lego_zero_rows reads) BEFORE the fork
+            self.gather_tokens(need_perm=not getattr(self, "_eval_only", False))   # counters[6], read by the side chain's lego_zero_rows
         if fork_ev is not None and sb is not m:
             sb.wait_event(fork_ev)
         else:
