@@ -21,6 +21,8 @@ def bench(fn, n=20):
     return e0.elapsed_time(e1) / n
 names = {0: "128x128 4w(2x2)", 1: "128x128 8w(2x4)", 2: "256x128 8w(4x2)", 3: "128x256 8w(2x4)", 4: "64x128 4w(1x4)", 5: "128x128 8w(4x2)", 6: "64x256 4w(1x4)", 7: "128x128 8w(4x2) stag", 8: "128x128 8w(2x4) stag", 9: "strip 16x16x4", 10: "strip LDS-DMA", 13: "LDS-DMA 4 waves"}
 SHAPES = [(26368, 256, 768), (24000, 256, 768), (28672, 256, 768), (32768, 256, 768), (65536, 256, 768), (26368, 256, 256), (26368, 256, 300), (26368, 200, 256), (1000, 256, 768), (26368+5, 240, 96), (3200, 200, 256), (3200, 256, 256), (3520, 256, 256), (6400, 256, 256), (26368, 768, 256), (30720, 768, 300), (105600, 256, 256), (26368, 256, 32), (26368, 256, 4), (26368, 256, 36)]
+if len(sys.argv) > 2 and sys.argv[2] == 'small':
+    SHAPES = [(4530, 256, 300), (4530, 256, 256), (8000, 256, 300)]
 if len(sys.argv) > 2 and sys.argv[2] == 'short':
     SHAPES = [(26368, 256, 768), (26368, 256, 256), (26368, 256, 300), (30720, 768, 256), (105600, 256, 256), (6400, 256, 256)]
 for (M, N, Kd) in SHAPES:
