@@ -14,6 +14,8 @@ from __future__ import annotations
 
 from typing import List, Tuple
 
+import os
+
 import torch
 from torch import nn
 
@@ -192,10 +194,35 @@ class Legommender(nn.Module):
         if self.user_repr is not None:
             return self.user_repr[batch[self.cm.user_col].to(Env.device)]
         if self.config.use_item_content and not self.flatten_mode:
-            clicks = self.get_item_content(batch, self.cm.history_col)
+            hist = batch[self.cm.history_col]
+            if self.skip_pad_items and self.item_repr is None and isinstance(hist, torch.Tensor) and hist.dim() == 2:
+                clicks = self._encode_live_history(hist, batch[self.cm.mask_col])
+            else:
+                clicks = self.get_item_content(batch, self.cm.history_col)
         else:
             clicks = self.user_op.inputer.get_embeddings(batch[self.cm.history_col])
         return self.user_op(clicks, mask=batch[self.cm.mask_col].to(Env.device))
+
+    # The reference pads every history to `max_click_num` slots with item 0 and ENCODES the pads (resampler.py:222-223; the
+    # user operator then masks them).  On an id-only batch the pads are known before anything is encoded: only the live slots
+    # go through the item operator (for the BERT news encoder that is ~1 500 of the 3 520 items of a B = 64 batch), the pad slots
+    # get zero vectors.  Exact: a masked slot has attention / pooling weight exactly 0 in the user operators, so neither the
+    # output nor any gradient depends on what the slot holds.  LEGO_SKIP_PAD_ITEMS=0 encodes them as the reference does.
+    skip_pad_items = os.environ.get("LEGO_SKIP_PAD_ITEMS", "1") != "0"
+
+    def _encode_live_history(self, hist: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        ids = hist.to(Env.device)
+        B, S = ids.shape
+        live = mask.to(Env.device).reshape(-1) != 0
+        idx = live.nonzero(as_tuple=False).squeeze(1)
+        col = self.cm.history_col
+        out = None
+        if idx.numel() > 0:
+            vec = self.get_item_content({col: ids.reshape(-1)[idx].unsqueeze(1)}, col)[:, 0]           # [n_live, D]
+            out = torch.zeros(B * S, vec.shape[-1], dtype=vec.dtype, device=vec.device).index_copy(0, idx, vec)
+        else:
+            out = torch.zeros(B * S, int(self.config.hidden_size), dtype=torch.float32, device=Env.device)
+        return out.view(B, S, -1)
 
     def forward(self, batch: dict):
         if self.engine is not None and isinstance(batch[self.cm.item_col], torch.Tensor) \
