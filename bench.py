@@ -495,11 +495,13 @@ def main():
                 r = bert_naml_bench.run(batch=B, steps=st, warmup=1, layers=12, hidden=D, tune_from=tf)
                 bsec[name] = {"steps": st, "warmup": 1, "ms_per_step": round(r["s_per_step"] * 1e3, 2), "value": r["impressions_per_s"],
                               "unit": "impressions/s", "bert_blocks_run": r["bert_layers_run"], "trainable_params": r["trainable_params"],
-                              "layer_cache_s": r["layer_cache_s"], "layer_cache_GB": r["layer_cache_GB"], "final_loss": round(r["loss"], 4)}
+                              "layer_cache_s": r["layer_cache_s"], "layer_cache_GB": r["layer_cache_GB"], "final_loss": round(r["loss"], 4),
+                              "item_page_size_yaml": r["item_page_size"], "item_page_effective": r["effective_item_page"]}
                 torch.cuda.empty_cache()
             Env.set_lm_cache(False)
             sec["bert_naml_base"] = dict(bsec, workload=f"MIND-small-shaped BERT-NAML (BASELINE config 5): BertConfig() defaults "
-                                         f"(768 x 12 blocks x 12 heads, random init), item_page_size 64 in the yaml, hidden={D} bs={B}, "
+                                         f"(768 x 12 blocks x 12 heads, random init), item_page_size 64 in the yaml (raised to the engine's floor of 256 items per "
+                                         f"call: same values, fuller launches; only the LIVE history slots are encoded), hidden={D} bs={B}, "
                                          f"5 000-item world, full plug-in train step (device sampler ids, fwd, bwd, torch Adam), fp32")
         extra["secondary"] = sec
 

@@ -171,16 +171,27 @@ class Legommender(nn.Module):
         if Env.lm_cache:                                             # legommender.py:166-169,187-188: ids go to the operator
             ids = content.to(Env.device)
             flat = ids.reshape(-1)
-            page = self.config.item_page_size or flat.numel()
+            page = self._item_page(flat.numel())
+            order = None
+            if getattr(self.item_op, "trim_pads", False) and flat.numel() > page:      # pages of similar live length (see BertOperator)
+                order = torch.argsort(self.item_op.attention_mask[flat.long()].sum(1), stable=True)
+                flat = flat[order]
             outs = [self.item_op(flat[s:s + page], mask=None) for s in range(0, flat.numel(), page)]
-            return (outs[0] if len(outs) == 1 else torch.cat(outs, 0)).view(*ids.shape, -1)
+            rep = outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+            if order is not None:
+                rep = torch.zeros_like(rep).index_copy(0, order, rep)
+            return rep.view(*ids.shape, -1)
         if isinstance(content, torch.Tensor):                        # id-only batch: expand through the item table
             content = self.expand_item_ids(content)
         item_content, B, C = _flatten(content)
         mask = self.item_op.inputer.get_mask(item_content)
         emb = self.item_op.inputer.get_embeddings(item_content)
         n = B * C
-        page = self.config.item_page_size or n
+        page = self._item_page(n)
+        order = None
+        if getattr(self.item_op, "trim_pads", False) and n > page and isinstance(emb, torch.Tensor) and isinstance(mask, torch.Tensor):
+            order = torch.argsort(mask.sum(1), stable=True)          # pages of similar live length: each is cut to its own longest
+            emb, mask = emb[order], mask[order]                      # sequence inside the operator (BertOperator._trim)
         outs = []
         for s in range(0, n, page):                                  # item_page_size chunking (legommender.py:174-184)
             sl = slice(s, min(s + page, n))
@@ -188,6 +199,8 @@ class Legommender(nn.Module):
             sub_m = {k: v[sl] for k, v in mask.items()} if isinstance(mask, dict) else mask[sl]
             outs.append(self.item_op(sub_e, mask=sub_m))
         item_repr = outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+        if order is not None:
+            item_repr = torch.zeros_like(item_repr).index_copy(0, order, item_repr)
         return item_repr.view(B, C, -1)
 
     def get_user_content(self, batch: dict):
@@ -209,6 +222,15 @@ class Legommender(nn.Module):
     # get zero vectors.  Exact: a masked slot has attention / pooling weight exactly 0 in the user operators, so neither the
     # output nor any gradient depends on what the slot holds.  LEGO_SKIP_PAD_ITEMS=0 encodes them as the reference does.
     skip_pad_items = os.environ.get("LEGO_SKIP_PAD_ITEMS", "1") != "0"
+    # `item_page_size` (64 in config/model/bert-naml.yaml, trainer.py:311) chunks the item operator's calls to bound the
+    # reference's GPU memory; a 64-item call is 2 k token rows -- too few to fill an MI355X (BERT-base: 175 impressions/s at 64,
+    # 318 at 256), and 288 GB of HBM do not need the bound.  The chunking changes no value, so a configured page is raised to this
+    # floor (LEGO_ITEM_PAGE_FLOOR=0: exactly the yaml's page).
+    item_page_floor = int(os.environ.get("LEGO_ITEM_PAGE_FLOOR", "256"))
+
+    def _item_page(self, n: int) -> int:
+        page = int(self.config.item_page_size or 0)
+        return max(page, self.item_page_floor) if page else n
 
     def _encode_live_history(self, hist: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
         ids = hist.to(Env.device)

@@ -194,6 +194,20 @@ class BertOperator(LMOperator, abc.ABC):
         ext = (1.0 - attention_mask[:, None, None, :].to(hidden_states.dtype)) * torch.finfo(hidden_states.dtype).min
         return self.transformer.encoder(hidden_states=hidden_states, attention_mask=ext, return_dict=True).last_hidden_state
 
+    # The reference runs every item at the inputer's full sequence length (title cap + category: 31 positions for MIND) with the
+    # pad positions masked.  The live positions of a ConcatInputer sequence are a PREFIX, so a call can drop the trailing
+    # positions that are pads in ALL of its items: masked keys never enter a softmax and the pool after the blocks skips masked
+    # positions, so the live outputs are the same numbers (up to the GEMM library's summation order for another row count).
+    # `Legommender.get_item_content` sorts the items of a batch by live length before paging, so a page of 64 items is cut to its
+    # own longest sequence: 18.5 instead of 31 positions on average.  LEGO_BERT_TRIM=0: the full length, as the reference.
+    trim_pads = os.environ.get("LEGO_BERT_TRIM", "1") != "0"
+
+    @staticmethod
+    def _trim(states, mask):
+        live = int(mask.sum(1).max().item()) if mask.numel() else 0
+        live = max(1, min(int(mask.shape[1]), live))
+        return states[:, :live], mask[:, :live]
+
     # ---- forward (once_operator.py:173-193, tune_from falsy)
     def forward(self, embeddings, mask=None, **kwargs):
         if self.config.tune_from:                                     # once_operator.py:182-188: `embeddings` are item ids
@@ -202,9 +216,14 @@ class BertOperator(LMOperator, abc.ABC):
                                    f"call Legommender.attach_item_table(...) first")
             indices = embeddings.to(Env.device).long().reshape(-1)
             mask = self.attention_mask[indices]
-            outputs = self._loop_forward(self.hidden_weights[indices], mask.float())
+            states = self.hidden_weights[indices]
+            if self.trim_pads:
+                states, mask = self._trim(states, mask)
+            outputs = self._loop_forward(states, mask.float())
         else:
             mask = mask.to(Env.device)
+            if self.trim_pads and isinstance(embeddings, torch.Tensor):
+                embeddings, mask = self._trim(embeddings, mask)
             outputs = self.transformer(inputs_embeds=embeddings.float(), attention_mask=mask.float(),
                                        return_dict=True).last_hidden_state
         outputs = F_hip.linear(outputs.float().contiguous(), self.linear.weight, self.linear.bias)

@@ -88,7 +88,7 @@ def run(batch=64, steps=5, warmup=2, layers=12, hidden=256, tune_from=0, n_items
     n_par = sum(p.numel() for p in model.parameters() if p.requires_grad)
     return ({"model": "BERT-NAML plug-in route", "batch": B, "bert_layers_run": len(model.item_op.transformer.encoder.layer),
            "trainable_params": n_par, "s_per_step": round(dt, 4), "impressions_per_s": round(B / dt, 1), "loss": float(loss.detach()),
-           "item_page_size": item_page_size, "tune_from": a.tune_from, "layer_cache_s": round(t_cache, 3) if a.tune_from else None,
+           "item_page_size": item_page_size, "effective_item_page": model._item_page(10 ** 9), "tune_from": a.tune_from, "layer_cache_s": round(t_cache, 3) if a.tune_from else None,
            "layer_cache_GB": round(model.item_op.hidden_weights.numel() * 4 / 1e9, 3) if a.tune_from else None})
 
 
