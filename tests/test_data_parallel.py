@@ -26,7 +26,8 @@ def _free_port():
 def _worker(rank, world, port, out_dir):
     from legommenders_amd.train_step import FlatParams
     from oracle import lego_oracle as O
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                            timeout=__import__("datetime").timedelta(seconds=180))     # a lost rendezvous / dead peer fails in minutes
     meta, P, G, tables, batch, _, _ = load_model_fixture("naml_glove_d64")
     B = batch["cand"].shape[0]
     sl = slice(rank * B // world, (rank + 1) * B // world)               # equal shards of the global batch
@@ -100,7 +101,8 @@ def test_batch_schedule_keeps_the_short_last_batch():
 def _sync_worker(rank, world, port, out_dir):
     """TrainStep.sync_gradients itself (not a copy of it) over gloo, single buffer and bucket train"""
     from legommenders_amd.train_step import FlatParams, TrainStep
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                            timeout=__import__("datetime").timedelta(seconds=180))     # a lost rendezvous / dead peer fails in minutes
     P = {"a": torch.zeros(7, 5), "b": torch.zeros(33), "embedding_vocab_table.glove.weight": torch.zeros(50, 8)}
     for buckets in (1 << 30, 64 * 4):              # one all-reduce; a train of 64-float buckets
         ts = TrainStep.__new__(TrainStep)
@@ -161,7 +163,8 @@ def test_linear_schedule_matches_oracle():
 
 def _eval_shard_worker(rank, world, port, out_dir):
     from legommenders_amd.evaluate import gather_shards, shard_bounds
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                            timeout=__import__("datetime").timedelta(seconds=180))     # a lost rendezvous / dead peer fails in minutes
     n, D = 11, 3                                                          # 11 rows over 2 ranks: shards of 6 and 5
     full = torch.arange(n * D, dtype=torch.float32).view(n, D)
     lo, hi, per = shard_bounds(n, rank, world)

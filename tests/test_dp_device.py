@@ -173,7 +173,8 @@ def _gloo_rank(rank, world, port, out_dir, steps):
     import torch.distributed as dist
     from legommenders_amd.synthetic import init_naml_params
     from legommenders_amd.train_step import DeviceData, TrainStep
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                            timeout=__import__("datetime").timedelta(seconds=180))     # a lost rendezvous / dead peer fails in minutes
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     w = _world(n_rows=202)
@@ -208,7 +209,8 @@ def _gloo_rank_table(rank, world, port, out_dir, steps):
     import torch.distributed as dist
     from legommenders_amd.synthetic import init_nrms_params
     from legommenders_amd.train_step import DeviceData, TrainStep
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                            timeout=__import__("datetime").timedelta(seconds=180))     # a lost rendezvous / dead peer fails in minutes
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     w = _world(n_rows=202)
@@ -259,7 +261,8 @@ def _plugin_rank(rank, world, port, out_dir, steps):
     from legommenders_amd.engine import ItemTables
     from legommenders_amd.train_step import DeviceData
     from legommenders_amd.trainer import build_model, load_world  # noqa: E402
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                            timeout=__import__("datetime").timedelta(seconds=180))     # a lost rendezvous / dead peer fails in minutes
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     from legommenders_amd.loader.env import Env
