@@ -852,6 +852,65 @@ __global__ __launch_bounds__(256) void additive_pool_fwd_kernel(
     if (l < cnt) wrow[l < len ? beg + l : extra] = stash * inv;
 }
 
+// Fast forms for D, A <= 256 (lane = 4 columns, one f32x4 per row and lane): a wave loads ALL of its rows of a batch of 32 segment
+// rows -- the tanh rows and the value rows, eight of each -- before the first reduction, instead of one dependent row after the
+// other (a 31-row item segment was eight dependent global round trips per wave; these kernels sit on the latency-bound neck of the
+// step between the item tower and the user tower).  Same arithmetic, same summation order across the waves.
+constexpr int kPoolRW = 8;          // rows per wave and batch
+__global__ __launch_bounds__(256) void additive_pool_fwd_fast_kernel(
+    const float* __restrict__ t, int ldt, const float* __restrict__ x, int ldx, const float* __restrict__ w2,
+    const int* __restrict__ seg_off, const int* __restrict__ rowinfo, const int* __restrict__ extra_off_dyn,
+    int n_cap, const int* __restrict__ n_dyn, int D, int A, float* __restrict__ out, int ldo, float* __restrict__ wrow) {
+    __shared__ float red_acc[4][256];
+    __shared__ float red_s[4];
+    const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x;
+    if (i >= n) return;
+    const int beg = seg_off[i], len = seg_off[i + 1] - beg;
+    const int extra = extra_off_dyn != nullptr ? *extra_off_dyn + i : -1;
+    const int cnt = len + (extra >= 0 ? 1 : 0);
+    const int c = 4 * lane;
+    const bool inD = c < D, inA = c < A;
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 w2v = inA ? *reinterpret_cast<const f32x4*>(w2 + c) : zero4;
+    f32x4 acc = zero4;
+    float stash = 0.f, s = 0.f;
+    int it = 0;
+    for (int b0 = 0; b0 < cnt; b0 += 4 * kPoolRW) {
+        f32x4 tv[kPoolRW], xv[kPoolRW];
+        bool live[kPoolRW];
+#pragma unroll
+        for (int u = 0; u < kPoolRW; ++u) {
+            const int l = b0 + wave + 4 * u;
+            const bool ok = l < cnt;
+            const int row = l < len ? beg + l : extra;
+            tv[u] = (ok && inA) ? *reinterpret_cast<const f32x4*>(t + (size_t)row * ldt + c) : zero4;
+            xv[u] = (ok && inD) ? *reinterpret_cast<const f32x4*>(x + (size_t)row * ldx + c) : zero4;
+            live[u] = ok && ((l < len && rowinfo != nullptr) ? (rowinfo[row] & RI_LIVE) != 0 : true);
+        }
+#pragma unroll
+        for (int u = 0; u < kPoolRW; ++u) {
+            if (b0 + wave + 4 * u < cnt) {                   // wave-uniform
+                const float a = wave_sum((tv[u][0] * w2v[0] + tv[u][1] * w2v[1]) + (tv[u][2] * w2v[2] + tv[u][3] * w2v[3]));
+                const float e = live[u] ? expf(a) : 0.f;
+                s += e;
+                acc += e * xv[u];
+                if (it == lane) stash = e;
+                ++it;
+            }
+        }
+    }
+    if (inD) *reinterpret_cast<f32x4*>(&red_acc[wave][c]) = acc;
+    if (lane == 0) red_s[wave] = s;
+    __syncthreads();
+    const float inv = 1.f / ((red_s[0] + red_s[1]) + (red_s[2] + red_s[3]) + kEps);
+    for (int cc = threadIdx.x; cc < D; cc += 256)
+        out[(size_t)i * ldo + cc] = ((red_acc[0][cc] + red_acc[1][cc]) + (red_acc[2][cc] + red_acc[3][cc])) * inv;
+    const int l = wave + 4 * lane;                       // the row this lane stashed
+    if (l < cnt) wrow[l < len ? beg + l : extra] = stash * inv;
+}
+
 constexpr int kPoolReplicas = 32;
 __global__ __launch_bounds__(256) void additive_pool_bwd_kernel(
     float* __restrict__ t, int ldt, const float* __restrict__ x, int ldx, const float* __restrict__ w2,
@@ -924,6 +983,105 @@ __global__ __launch_bounds__(256) void additive_pool_bwd_kernel(
     for (int c = threadIdx.x; c < A; c += 256) {
         atomicAdd(gw2 + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
         atomicAdd(gb1 + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
+    }
+}
+
+// fast backward (D, A <= 256): segments of up to 32 rows keep every row of both passes in registers (one round of loads); longer
+// segments (click histories of up to 50 items on the un-fused user side) run the row-by-row passes of the generic kernel
+__global__ __launch_bounds__(256) void additive_pool_bwd_fast_kernel(
+    float* __restrict__ t, int ldt, const float* __restrict__ x, int ldx, const float* __restrict__ w2,
+    const int* __restrict__ seg_off, const int* __restrict__ extra_off_dyn, int n_cap, const int* __restrict__ n_dyn,
+    int D, int A, const float* __restrict__ gout, int ldgo, const float* __restrict__ wrow,
+    float* __restrict__ dx, int lddx, float* gw2, float* gb1, float* scratch) {
+    __shared__ float red[2][4][256];
+    __shared__ float red_s[2][4];
+    const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = 4 * lane;
+    const bool inD = c < D, inA = c < A;
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 w2v = inA ? *reinterpret_cast<const f32x4*>(w2 + c) : zero4;
+    f32x4 aw2 = zero4, ab1 = zero4;
+    int par = 0;
+    for (int i = blockIdx.x; i < n; i += gridDim.x, par ^= 1) {
+        const int beg = seg_off[i], len = seg_off[i + 1] - beg;
+        const int extra = extra_off_dyn != nullptr ? *extra_off_dyn + i : -1;
+        const int cnt = len + (extra >= 0 ? 1 : 0);
+        const f32x4 gov = inD ? *reinterpret_cast<const f32x4*>(gout + (size_t)i * ldgo + c) : zero4;
+        if (cnt <= 4 * kPoolRW) {                            // block-uniform
+            f32x4 tv[kPoolRW], xv[kPoolRW];
+            float wv[kPoolRW], dwv[kPoolRW];
+            int rows[kPoolRW];
+#pragma unroll
+            for (int u = 0; u < kPoolRW; ++u) {
+                const int l = wave + 4 * u;
+                const bool ok = l < cnt;
+                rows[u] = ok ? (l < len ? beg + l : extra) : -1;
+                xv[u] = (ok && inD) ? *reinterpret_cast<const f32x4*>(x + (size_t)rows[u] * ldx + c) : zero4;
+                tv[u] = (ok && inA) ? *reinterpret_cast<const f32x4*>(t + (size_t)rows[u] * ldt + c) : zero4;
+                wv[u] = ok ? wrow[rows[u]] : 0.f;
+            }
+            float sdw = 0.f;
+#pragma unroll
+            for (int u = 0; u < kPoolRW; ++u) {
+                dwv[u] = wave_sum((gov[0] * xv[u][0] + gov[1] * xv[u][1]) + (gov[2] * xv[u][2] + gov[3] * xv[u][3]));
+                sdw += wv[u] * dwv[u];
+            }
+            if (lane == 0) red_s[par][wave] = sdw;
+            __syncthreads();
+            sdw = (red_s[par][0] + red_s[par][1]) + (red_s[par][2] + red_s[par][3]);
+#pragma unroll
+            for (int u = 0; u < kPoolRW; ++u) {
+                if (rows[u] < 0) continue;                   // wave-uniform
+                const float w = wv[u];
+                const float da = w * (dwv[u] - sdw);
+                if (inD) *reinterpret_cast<f32x4*>(dx + (size_t)rows[u] * lddx + c) = w * gov;
+                if (inA) {
+                    const f32x4 dpre = da * w2v * (1.f - tv[u] * tv[u]);
+                    aw2 += da * tv[u];
+                    ab1 += dpre;
+                    *reinterpret_cast<f32x4*>(t + (size_t)rows[u] * ldt + c) = dpre;
+                }
+            }
+        } else {
+            float stash = 0.f, sdw = 0.f;
+            for (int l = wave, it = 0; l < cnt; l += 4, ++it) {
+                const int row = l < len ? beg + l : extra;
+                const f32x4 xr = inD ? *reinterpret_cast<const f32x4*>(x + (size_t)row * ldx + c) : zero4;
+                const float dw = wave_sum((gov[0] * xr[0] + gov[1] * xr[1]) + (gov[2] * xr[2] + gov[3] * xr[3]));
+                sdw += wrow[row] * dw;
+                if (it == lane) stash = dw;
+            }
+            if (lane == 0) red_s[par][wave] = sdw;
+            __syncthreads();
+            sdw = (red_s[par][0] + red_s[par][1]) + (red_s[par][2] + red_s[par][3]);
+            for (int l = wave, it = 0; l < cnt; l += 4, ++it) {
+                const int row = l < len ? beg + l : extra;
+                const float dw = __shfl(stash, it, 64);
+                const float w = wrow[row];
+                const float da = w * (dw - sdw);
+                if (inD) *reinterpret_cast<f32x4*>(dx + (size_t)row * lddx + c) = w * gov;
+                if (inA) {
+                    f32x4* tp = reinterpret_cast<f32x4*>(t + (size_t)row * ldt + c);
+                    const f32x4 tvv = *tp;
+                    const f32x4 dpre = da * w2v * (1.f - tvv * tvv);
+                    aw2 += da * tvv;
+                    ab1 += dpre;
+                    *tp = dpre;
+                }
+            }
+        }
+    }
+    *reinterpret_cast<f32x4*>(&red[0][wave][c]) = aw2;
+    *reinterpret_cast<f32x4*>(&red[1][wave][c]) = ab1;
+    __syncthreads();
+    if (scratch != nullptr) {
+        gw2 = scratch + (size_t)(blockIdx.x % kPoolReplicas) * 2 * A;
+        gb1 = gw2 + A;
+    }
+    for (int cc = threadIdx.x; cc < A; cc += 256) {
+        atomicAdd(gw2 + cc, (red[0][0][cc] + red[0][1][cc]) + (red[0][2][cc] + red[0][3][cc]));
+        atomicAdd(gb1 + cc, (red[1][0][cc] + red[1][1][cc]) + (red[1][2][cc] + red[1][3][cc]));
     }
 }
 
@@ -1644,8 +1802,14 @@ extern "C" int lego_additive_pool_fwd(const float* t, int ldt, const float* x, i
                  "lego_additive_pool_fwd: D=%d A=%d must be multiples of 4 and <= %d", D, A, 256 * kMaxChunks);
     LEGO_REQUIRE((ldt & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0, "lego_additive_pool_fwd: strides must be multiples of 4");
     if (n_cap <= 0) return 0;
-    hipLaunchKernelGGL(additive_pool_fwd_kernel, dim3(n_cap), dim3(256), 0, ST, t, ldt, x, ldx, w2, seg_off, rowinfo,
-                       extra_off_dyn, n_cap, n_dyn, D, A, out, ldo, wrow);
+    static int fast = -1;                            // LEGO_POOL_FAST=0: the row-by-row kernels (A/B)
+    if (fast < 0) { const char* v = getenv("LEGO_POOL_FAST"); fast = (v != nullptr && v[0] == '0') ? 0 : 1; }
+    if (fast && D <= 256 && A <= 256)
+        hipLaunchKernelGGL(additive_pool_fwd_fast_kernel, dim3(n_cap), dim3(256), 0, ST, t, ldt, x, ldx, w2, seg_off, rowinfo,
+                           extra_off_dyn, n_cap, n_dyn, D, A, out, ldo, wrow);
+    else
+        hipLaunchKernelGGL(additive_pool_fwd_kernel, dim3(n_cap), dim3(256), 0, ST, t, ldt, x, ldx, w2, seg_off, rowinfo,
+                           extra_off_dyn, n_cap, n_dyn, D, A, out, ldo, wrow);
     return check_launch("lego_additive_pool_fwd");
 }
 
@@ -1659,8 +1823,14 @@ extern "C" int lego_additive_pool_bwd(float* t_dpre, int ldt, const float* x, in
     const int cap = 1024;
     int blocks = n_cap;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(additive_pool_bwd_kernel, dim3(blocks), dim3(256), 0, ST, t_dpre, ldt, x, ldx, w2, seg_off, extra_off_dyn,
-                       n_cap, n_dyn, D, A, gout, ldgo, wrow, dx, lddx, gw2, gb1, scratch);
+    static int fast = -1;
+    if (fast < 0) { const char* v = getenv("LEGO_POOL_FAST"); fast = (v != nullptr && v[0] == '0') ? 0 : 1; }
+    if (fast && D <= 256 && A <= 256 && (ldt & 3) == 0 && (ldx & 3) == 0 && (lddx & 3) == 0 && (ldgo & 3) == 0)
+        hipLaunchKernelGGL(additive_pool_bwd_fast_kernel, dim3(blocks), dim3(256), 0, ST, t_dpre, ldt, x, ldx, w2, seg_off, extra_off_dyn,
+                           n_cap, n_dyn, D, A, gout, ldgo, wrow, dx, lddx, gw2, gb1, scratch);
+    else
+        hipLaunchKernelGGL(additive_pool_bwd_kernel, dim3(blocks), dim3(256), 0, ST, t_dpre, ldt, x, ldx, w2, seg_off, extra_off_dyn,
+                           n_cap, n_dyn, D, A, gout, ldgo, wrow, dx, lddx, gw2, gb1, scratch);
     return check_launch("lego_additive_pool_bwd");
 }
 
