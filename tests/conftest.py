@@ -24,3 +24,18 @@ def _fresh_hip_library():
     failure mode ctypes cannot detect.  `make` is a no-op when everything is up to date."""
     from legommenders_amd import _lib
     _lib.build()
+
+
+def spawn_ranks(fn, args, nprocs, deadline=420.0):
+    """`torch.multiprocessing.spawn` with a wall-clock bound: ranks that neither finish nor fail within `deadline`
+    seconds are killed by PID and the test fails, instead of the suite waiting on a stuck child for ever."""
+    import time
+    import torch.multiprocessing as mp
+    ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
+    t0 = time.time()
+    while not ctx.join(timeout=5.0):                                  # raises when a rank failed
+        if time.time() - t0 > deadline:
+            for proc in ctx.processes:
+                if proc.is_alive():
+                    proc.kill()
+            pytest.fail(f"{fn.__name__}: {nprocs} ranks still running after {deadline:.0f} s (killed)")

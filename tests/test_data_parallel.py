@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
-import torch.multiprocessing as mp
+from tests.conftest import spawn_ranks
 
 from tests.golden_util import load_model_fixture
 
@@ -45,7 +45,7 @@ def _worker(rank, world, port, out_dir):
 
 def test_two_rank_allreduce_equals_global_batch(tmp_path):
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    spawn_ranks(_worker, (world, port, str(tmp_path)), world)
     got = np.load(os.path.join(str(tmp_path), "dp.npz"))
     _, _, G, _, _, _, _ = load_model_fixture("naml_glove_d64")           # reference gradient of the FULL batch
     for k, g in G.items():
@@ -146,7 +146,7 @@ def _sync_worker(rank, world, port, out_dir):
 
 def test_train_step_sync_gradients_over_gloo():
     world, port = 2, _free_port()
-    mp.spawn(_sync_worker, args=(world, port, ""), nprocs=world, join=True)
+    spawn_ranks(_sync_worker, (world, port, ""), world)
 
 
 def test_linear_schedule_matches_oracle():
@@ -184,7 +184,7 @@ def test_eval_cache_shards_gather_to_the_whole_table():
             assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
             assert all(hi - lo <= per for lo, hi, per in b) and len({per for _, _, per in b}) == 1
     world, port = 2, _free_port()
-    mp.spawn(_eval_shard_worker, args=(world, port, ""), nprocs=world, join=True)
+    spawn_ranks(_eval_shard_worker, (world, port, ""), world)
 
 
 def test_optimizer_and_scheduler_state_are_torch_state_dicts():

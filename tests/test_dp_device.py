@@ -15,6 +15,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.conftest import spawn_ranks
+
 pytestmark = pytest.mark.gpu
 
 
@@ -189,11 +191,9 @@ def _gloo_rank(rank, world, port, out_dir, steps):
 
 
 def test_train_step_two_processes_on_one_gpu_over_gloo(tmp_path):
-    import torch.multiprocessing as mp
     from legommenders_amd.synthetic import init_naml_params
     steps = 15
-    mp.get_context("spawn")
-    mp.spawn(_gloo_rank, args=(2, _free_port(), str(tmp_path), steps), nprocs=2, join=True)
+    spawn_ranks(_gloo_rank, (2, _free_port(), str(tmp_path), steps), 2)
     r0, r1 = (torch.load(os.path.join(str(tmp_path), f"rank{r}.pt")) for r in range(2))
     for k in r0:
         assert torch.equal(r0[k], r1[k]), k                          # replicas stay bit-identical
@@ -227,10 +227,9 @@ def _gloo_rank_table(rank, world, port, out_dir, steps):
 
 
 def test_overlapped_table_exchange_two_processes(tmp_path):
-    import torch.multiprocessing as mp
     from legommenders_amd.synthetic import init_nrms_params
     steps = 10
-    mp.spawn(_gloo_rank_table, args=(2, _free_port(), str(tmp_path), steps), nprocs=2, join=True)
+    spawn_ranks(_gloo_rank_table, (2, _free_port(), str(tmp_path), steps), 2)
     r0, r1 = (torch.load(os.path.join(str(tmp_path), f"table{r}.pt")) for r in range(2))
     for k in r0:
         assert torch.equal(r0[k], r1[k]), k
@@ -286,8 +285,7 @@ def _plugin_rank(rank, world, port, out_dir, steps):
 
 
 def test_plugin_step_two_ranks_with_dropout(tmp_path):
-    import torch.multiprocessing as mp
-    mp.spawn(_plugin_rank, args=(2, _free_port(), str(tmp_path), 4), nprocs=2, join=True)
+    spawn_ranks(_plugin_rank, (2, _free_port(), str(tmp_path), 4), 2)
     r0, r1 = (torch.load(os.path.join(str(tmp_path), f"plugin{r}.pt")) for r in range(2))
     for k in r0["P"]:
         assert torch.equal(r0["P"][k], r1["P"][k]), k                # the averaged gradient keeps the replicas identical
