@@ -257,6 +257,7 @@ class NamlEngine(_Base):
         # the token rows.  (First version: 16 rows per wave, 16-B-strided atomics, a counting sort with an atomic cursor: 46 + 25 us
         # and 2 x 64 us of serialised int atomics on the prefetch stream -- slower than not de-duplicating.)  LEGO_DEDUP_BWD=0: off
         self.dedup_bwd = self.dedup and os.environ.get("LEGO_DEDUP_BWD", "1") != "0"
+        self.proj_side = os.environ.get("LEGO_PROJ_SIDE", "0") == "1"
         V = P["embedding_vocab_table.glove.embedding.weight"].shape[0]
         self.V = V
         self.Uc = min(self.Rc, V) if self.dedup else 0
@@ -598,6 +599,12 @@ class NamlEngine(_Base):
             self.kk(m, "conv3_bwd_data", "lego_conv3_bwd_data", _ptr(self.dY), D, _ptr(self.wt), _ptr(self.rowinfo), _ptr(self.dH), D,
                     self.Rc, self.cnt(0), D, D, self.drop(self.p_proj, SITE_PROJ, training),
                     _ptr(G["embedding_vocab_table.glove.linear.bias"]), 0)
+        # A/B (LEGO_PROJ_SIDE=1): the projection's weight-gradient tail (segment sums + product over the distinct tokens) on the
+        # side stream beside the conv weight gradient instead of behind it on the main stream
+        pst = m
+        if self.proj_side:
+            self._fork(ev[7], m, sb)
+            pst = sb
         # ---- conv weight gradient after the data gradient on the main stream (a third stream measured 1-1.5 % slower)
         if self.wino:
             self.kk(m, "conv3_bwd_weight", "lego_conv3_wino_bwd_weight", _ptr(self.dY), D, _ptr(self.H), D,
@@ -608,14 +615,14 @@ class NamlEngine(_Base):
                     _ptr(self.dwt), self.Rc, self.cnt(0), D, D)
             self.kk(m, None, "lego_conv3_unpack_add", _ptr(self.dwt), _ptr(G["item_op.cnn.weight"]), D, D)
         if self.dedup_bwd:                           # per-token sums of dH, then the product over the distinct tokens only
-            self.kk(m, "proj_bwd_segsum", "lego_segment_sum_rows", _ptr(self.dH), D, D, _ptr(self.perm), _ptr(self.inv), self.Rc,
+            self.kk(pst, "proj_bwd_segsum", "lego_segment_sum_rows", _ptr(self.dH), D, D, _ptr(self.perm), _ptr(self.inv), self.Rc,
                     _ptr(self.keys_sorted), self.cnt(0), _ptr(self.dHu), D, self.Uc, self.cnt(6),
                     0 if getattr(self, "_dhu_zeroed", False) else 1)
             self._dhu_zeroed = False
-            self.kk(m, "proj_bwd_weight", "lego_linear_bwd_weight", _ptr(self.dHu), D, _ptr(self.Xu), E0,
+            self.kk(pst, "proj_bwd_weight", "lego_linear_bwd_weight", _ptr(self.dHu), D, _ptr(self.Xu), E0,
                     _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Uc, self.cnt(6), D, E0, None, None)
         else:
-            self.kk(m, "proj_bwd_weight", "lego_linear_bwd_weight", _ptr(self.dH), D, _ptr(self.X), E0,
+            self.kk(pst, "proj_bwd_weight", "lego_linear_bwd_weight", _ptr(self.dH), D, _ptr(self.X), E0,
                     _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Rc, self.cnt(0), D, E0, None, None)
         self._fork(ev[6], sb, m)
         self.step = step_save
