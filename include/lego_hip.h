@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LEGO_ABI_VERSION 3
+#define LEGO_ABI_VERSION 4
 #define LEGO_COUNTERS 8
 
 const char* lego_last_error(void);
@@ -81,10 +81,11 @@ int lego_unique_tokens(const int32_t* row_tok, int R_cap, const int32_t* R_dyn, 
  * through hipCUB: a utility on the prefetch stream, not a hot kernel).  temp: lego_sort_rows_temp_bytes(n) bytes. */
 int lego_sort_rows(const int32_t* keys, int n, int32_t* keys_sorted, int32_t* perm, void* temp, int64_t temp_bytes, void* stream);
 int64_t lego_sort_rows_temp_bytes(int n);
-/* out[r,:] = dropout_r(src[inv[r],:]) for r < rows: expands per-token projections to token rows, the site's Dropout applied
- * per ROW (embedding_hub.py:95-96: Dropout(Linear(.))) */
+/* out[r,:] = live_r * dropout_r(src[inv[r],:]) for r < rows: expands per-token projections to token rows, the site's Dropout
+ * applied per ROW (embedding_hub.py:95-96: Dropout(Linear(.))); rows whose live bit is 0 in rowinfo are written as zeros (the
+ * [SEP] / category positions of a ConcatInputer sequence, concat_inputer.py:96-114: their token look-up is masked) */
 int lego_expand_rows(const float* src, int ld_src, const int32_t* inv, int rows_cap, const int32_t* rows_dyn, int width,
-                     const lego_dropout* drop, float* out, int ld_out, void* stream);
+                     const lego_dropout* drop, const int32_t* rowinfo /*nullable*/, float* out, int ld_out, void* stream);
 /* out[u,:] = sum over rows r with inv[r] == u of g[r,:] (u < U; perm = the rows grouped by inv): the per-token sums the
  * projection's weight gradient is formed from.  out[0:U] must be zero on entry: zero_first = 1 clears it here, 0 = the caller
  * has (lego_zero_rows, e.g. on another stream ahead of time). */

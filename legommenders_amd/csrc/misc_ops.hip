@@ -399,8 +399,8 @@ __global__ void uq_fill_kernel(const int* __restrict__ inv, int R_cap, const int
 // the per-token projections are expanded to the batch's token rows.  One wave per row, lane = 4 columns (width <= 256), four
 // rows in flight; the keep bits are the site's precomputed mask (byte [(r / 4) * width + col], bit r % 4) or Philox draws.
 __global__ __launch_bounds__(256) void expand_rows_kernel(const float* __restrict__ src, int ld_src, const int* __restrict__ inv, int rows_cap,
-                                                          const int* __restrict__ rows_dyn, int width, Dropout drop, float* __restrict__ out,
-                                                          int ld_out) {
+                                                          const int* __restrict__ rows_dyn, int width, Dropout drop,
+                                                          const int* __restrict__ rowinfo, float* __restrict__ out, int ld_out) {
     const int rows = rows_dyn != nullptr ? min(rows_cap, *rows_dyn) : rows_cap;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void expand_rows_kernel(const float* __restric
         for (int u = 0; u < U; ++u) {
             const int r = r0 + u;
             v[u] = v2[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (r < rows) {
+            if (r < rows && (rowinfo == nullptr || (rowinfo[r] & RI_LIVE) != 0)) {      // a row without the live bit is written as zeros
                 const float* row = src + (size_t)inv[r] * ld_src;               // inv[r]: wave-uniform
                 if (in) v[u] = *reinterpret_cast<const f32x4*>(row + c);
                 if (in2) v2[u] = *reinterpret_cast<const f32x4*>(row + c2);
@@ -1663,12 +1663,12 @@ extern "C" int lego_unique_tokens(const int32_t* row_tok, int R_cap, const int32
 }
 
 extern "C" int lego_expand_rows(const float* src, int ld_src, const int32_t* inv, int rows_cap, const int32_t* rows_dyn, int width,
-                                const lego_dropout* drop, float* out, int ld_out, void* stream) {
+                                const lego_dropout* drop, const int32_t* rowinfo, float* out, int ld_out, void* stream) {
     LEGO_REQUIRE((width & 3) == 0 && (ld_src & 3) == 0 && (ld_out & 3) == 0, "lego_expand_rows: width=%d must be a multiple of 4", width);
     if (rows_cap <= 0) return 0;
     const int want = (rows_cap + 15) / 16;                 // four waves per block, four consecutive rows per wave and iteration
     hipLaunchKernelGGL(expand_rows_kernel, dim3(want < 2048 ? want : 2048, (width + 511) / 512), dim3(256), 0, ST, src, ld_src, inv, rows_cap, rows_dyn, width,
-                       make_dropout(drop), out, ld_out);
+                       make_dropout(drop), rowinfo, out, ld_out);
     return check_launch("lego_expand_rows");
 }
 

@@ -361,7 +361,7 @@ class NamlEngine(_Base):
                         _ptr(self.uq_temp), self.uq_temp.numel())
             if not self.dedup_bwd:                   # the weight gradient still runs over the token rows: X[r] = Xu[inv[r]]
                 self.kk(s, "expand_rows_in_step" if stream is not None else None, "lego_expand_rows", _ptr(b["Xu"]), self.E0, _ptr(b["inv"]),
-                        self.Rc, _ptr(b["counters"], 0), self.E0, None, _ptr(b["X"]), self.E0)
+                        self.Rc, _ptr(b["counters"], 0), self.E0, None, None, _ptr(b["X"]), self.E0)
             return
         # with timers on (bench.py) the launch is bracketed by HIP events on the stream it runs on: on the prefetch stream
         # that is the gather's duration INSIDE the step, overlapped with the previous step's user-side chain
@@ -496,7 +496,7 @@ class NamlEngine(_Base):
                     _ptr(P["embedding_vocab_table.glove.linear.bias"]), _ptr(self.Hu), D, self.Uc, self.cnt(6), D, E0, 0,
                     None, None, None, None)
             self.kk(m, "proj_expand", "lego_expand_rows", _ptr(self.Hu), D, _ptr(self.inv), self.Rc, self.cnt(0), D,
-                    self.drop(self.p_proj, SITE_PROJ, training), _ptr(self.H), D)
+                    self.drop(self.p_proj, SITE_PROJ, training), None, _ptr(self.H), D)
         else:
             self.kk(m, "proj_fwd", "lego_linear_fwd", _ptr(self.X), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
                     _ptr(P["embedding_vocab_table.glove.linear.bias"]), _ptr(self.H), D, self.Rc, self.cnt(0), D, E0, 0,
@@ -704,7 +704,31 @@ class NrmsEngine(_Base):
         self.idx_spec = torch.zeros(self.Rc, **i32)
         self.idx_cat = torch.zeros(self.Rc, **i32)
         self.tokinfo = torch.zeros(self.Rc, **i32)
-        self.X = self._f(self.Rc, self.E0) if glove else None
+        # GloVe variant: the projection of a token row depends on the token id alone (Dropout(Linear(frozen table)), embedding_hub.py:95-96),
+        # so it runs once per DISTINCT token of the batch and is expanded to the sequence rows with the per-row dropout and the token
+        # mask; its weight gradient comes from per-token sums of dE (NamlEngine has the same scheme).  The [SEP] / category positions
+        # (row_tok < 0) fall into group 0 of the inverse map: the expansion writes them as zeros (tokinfo's live bit) and their dE
+        # rows are zero when the sums are formed (lego_mask_dropout_rows runs first).  LEGO_NRMS_DEDUP=0: row-by-row projection.
+        self.dedup = bool(glove) and self.Rc > 0 and os.environ.get("LEGO_NRMS_DEDUP", "1") != "0"
+        if self.dedup:
+            V = P["embedding_vocab_table.glove.embedding.weight"].shape[0]
+            self.V, self.Uc = V, min(self.Rc, V)
+            self.uq_stamp = torch.zeros(V, **i32)
+            self.uq_rank = torch.zeros(V, **i32)
+            self.uq_bsum = torch.zeros((V + 1023) // 1024 + 1, **i32)
+            self.uq_cnt = torch.zeros(self.Uc + 1, **i32)
+            self.uq_start = torch.zeros(self.Uc + 1, **i32)
+            self.uniq = torch.zeros(self.Uc, **i32)
+            self.inv = torch.zeros(self.Rc, **i32)
+            self.perm = torch.zeros(self.Rc, **i32)
+            self.uq_keys = torch.zeros(self.Rc, **i32)
+            self.keys_sorted = torch.zeros(self.Rc, **i32)
+            self.uq_temp = torch.zeros(max(int(_lib.lib().lego_sort_rows_temp_bytes(self.Rc)), 256), dtype=torch.uint8, device=self.dev)
+            self.Xu = self._f(self.Uc, self.E0)
+            self.Hu = self._f(self.Uc, D)
+            self.dHu = self._f(self.Uc, D)
+            self._uq_epoch = 0
+        self.X = (self._f(1, self.E0) if self.dedup else self._f(self.Rc, self.E0)) if glove else None
         self.E = self._f(self.Rc, D)
         self.dE = self._f(self.Rc, D)
         self.items = self._f(self.NIc, D)
@@ -720,7 +744,7 @@ class NrmsEngine(_Base):
 
     def enable_plan_slots(self):
         if getattr(self, "_slots", None) is None and self.glove:
-            self._PLAN_FIELDS = NrmsEngine._PLAN_FIELDS + ("X",)
+            self._PLAN_FIELDS = NrmsEngine._PLAN_FIELDS + (("Xu", "uniq", "inv", "perm", "keys_sorted") if self.dedup else ("X",))
         return super().enable_plan_slots()
 
     def plan_on(self, stream, slot, cand, hist, hist_len, nb=None):
@@ -731,7 +755,17 @@ class NrmsEngine(_Base):
     def _decode_gather(self, b, st):
         call("lego_nrms_decode_rows", _ptr(b["row_tok"]), self.Rc, _ptr(b["counters"], 0), _ptr(b["idx_tok"]), _ptr(b["idx_spec"]),
              _ptr(b["idx_cat"]), _ptr(b["tokinfo"]), st)
-        if self.glove:
+        if self.glove and self.dedup:
+            E0 = self.E0
+            self._uq_epoch = self._uq_epoch % 0x7FFFFFF0 + 1
+            call("lego_unique_tokens", _ptr(b["row_tok"]), self.Rc, _ptr(b["counters"], 0), self.V, _ptr(self.uq_stamp), self._uq_epoch,
+                 _ptr(self.uq_rank), _ptr(self.uq_bsum), _ptr(b["uniq"]), _ptr(b["inv"]), _ptr(self.uq_cnt), _ptr(self.uq_start), None,
+                 _ptr(self.uq_keys), _ptr(b["counters"], 6), st)
+            call("lego_gather_rows", _ptr(self.P["embedding_vocab_table.glove.embedding.weight"]), E0, E0, _ptr(b["uniq"]),
+                 self.Uc, _ptr(b["counters"], 6), _ptr(b["Xu"]), E0, 0, st)
+            call("lego_sort_rows", _ptr(self.uq_keys), self.Rc, _ptr(b["keys_sorted"]), _ptr(b["perm"]), _ptr(self.uq_temp),
+                 self.uq_temp.numel(), st)
+        elif self.glove:
             E0 = self.E0
             call("lego_gather_rows", _ptr(self.P["embedding_vocab_table.glove.embedding.weight"]), E0, E0, _ptr(b["idx_tok"]),
                  self.Rc, _ptr(b["counters"], 0), _ptr(b["X"]), E0, 0, st)
@@ -1016,7 +1050,14 @@ class NrmsEngine(_Base):
         self._folds_fresh = True
         if not (planned and getattr(self, "_slots", None) is not None):      # else: done with the plan (plan_on)
             self._decode_gather(self.__dict__, st)
-        if self.glove:
+        if self.glove and self.dedup:
+            E0 = self.E0
+            call("lego_linear_fwd", _ptr(self.Xu), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
+                 _ptr(P["embedding_vocab_table.glove.linear.bias"]), _ptr(self.Hu), D, self.Uc, self.cnt(6), D, E0, 0,
+                 None, None, None, None, st)
+            call("lego_expand_rows", _ptr(self.Hu), D, _ptr(self.inv), self.Rc, self.cnt(0), D, self.drop(self.p_proj, SITE_PROJ, training),
+                 _ptr(self.tokinfo), _ptr(self.E), D, st)
+        elif self.glove:
             E0 = self.E0
             call("lego_linear_fwd", _ptr(self.X), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
                  _ptr(P["embedding_vocab_table.glove.linear.bias"]), _ptr(self.E), D, self.Rc, self.cnt(0), D, E0, 0,
@@ -1105,8 +1146,14 @@ class NrmsEngine(_Base):
             if not fused:                            # the three-pass form (kept as the cross-check of the fused epilogue)
                 call("lego_mask_dropout_rows", _ptr(self.dE), D, self.Rc, self.cnt(0), D, _ptr(self.tokinfo),
                      self.drop(self.p_proj, SITE_PROJ, training), _ptr(G["embedding_vocab_table.glove.linear.bias"]), st)
-            call("lego_linear_bwd_weight", _ptr(self.dE), D, _ptr(self.X), E0,
-                 _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Rc, self.cnt(0), D, E0, None, None, st)
+            if self.dedup:                           # per-token sums of the masked dE, then the product over the distinct tokens
+                call("lego_segment_sum_rows", _ptr(self.dE), D, D, _ptr(self.perm), _ptr(self.inv), self.Rc, _ptr(self.keys_sorted),
+                     self.cnt(0), _ptr(self.dHu), D, self.Uc, self.cnt(6), 1, st)
+                call("lego_linear_bwd_weight", _ptr(self.dHu), D, _ptr(self.Xu), E0,
+                     _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Uc, self.cnt(6), D, E0, None, None, st)
+            else:
+                call("lego_linear_bwd_weight", _ptr(self.dE), D, _ptr(self.X), E0,
+                     _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Rc, self.cnt(0), D, E0, None, None, st)
         else:
             V = G["embedding_vocab_table.glove.weight"].shape[0]
             if self.touched_rows is not None:       # TrainStep: rows that have ever had a gradient (row-skipping dense Adam)

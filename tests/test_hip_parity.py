@@ -501,10 +501,15 @@ def test_unique_tokens_expand_and_segment_sum():
     d = LegoDropout(0.1, 99, 7, None)
     call("lego_dropout_mask", ctypes.byref(d), R_cap, None, D, P(mask), None)
     out_m, out_p, out_0 = (torch.full((R_cap, D), 7.0, device=dev) for _ in range(3))
-    call("lego_expand_rows", P(src), D, P(inv), R_cap, P(R_dyn), D, ctypes.byref(LegoDropout(0.1, 99, 7, mask.data_ptr())), P(out_m), D, None)
-    call("lego_expand_rows", P(src), D, P(inv), R_cap, P(R_dyn), D, ctypes.byref(d), P(out_p), D, None)
-    call("lego_expand_rows", P(src), D, P(inv), R_cap, P(R_dyn), D, None, P(out_0), D, None)
+    call("lego_expand_rows", P(src), D, P(inv), R_cap, P(R_dyn), D, ctypes.byref(LegoDropout(0.1, 99, 7, mask.data_ptr())), None, P(out_m), D, None)
+    call("lego_expand_rows", P(src), D, P(inv), R_cap, P(R_dyn), D, ctypes.byref(d), None, P(out_p), D, None)
+    call("lego_expand_rows", P(src), D, P(inv), R_cap, P(R_dyn), D, None, None, P(out_0), D, None)
+    # rows without the live bit (the [SEP] / category positions of a ConcatInputer sequence) come out as zeros
+    live = torch.tensor((rs.rand(R_cap) < 0.8).astype(np.int32) * 4).to(dev)          # RI_LIVE = 4
+    out_l = torch.full((R_cap, D), 7.0, device=dev)
+    call("lego_expand_rows", P(src), D, P(inv), R_cap, P(R_dyn), D, ctypes.byref(d), P(live), P(out_l), D, None)
     torch.cuda.synchronize()
+    assert torch.equal(out_l[:R], out_p[:R] * (live[:R, None] != 0)) and bool((out_l[R:] == 7.0).all())
     plain = src[inv[:R].long()]
     assert torch.equal(out_0[:R], plain) and bool((out_0[R:] == 7.0).all())
     assert torch.equal(out_m, out_p)
@@ -1068,6 +1073,58 @@ def test_nrms_folded_linear_equals_unfolded(glove):
                 continue
             d = float((g1[k] - g0[k]).abs().max())
             assert d <= 2e-5 * gmax + 2e-5 * float(g0[k].abs().max()), (level, k, d, gmax)
+
+
+@pytest.mark.parametrize("planned", [False, True])
+def test_nrms_projection_once_per_distinct_token(planned, monkeypatch):
+    """NrmsEngine (GloVe variant): Dropout(Linear(glove[tok])) computed once per DISTINCT token of the batch and expanded to the
+    sequence rows (per-row dropout draws, [SEP] / category positions written as zeros), weight gradient from per-token sums of dE,
+    against the row-by-row projection (LEGO_NRMS_DEDUP=0) with dropout ON: same draws, so the same scores, loss and gradients up to
+    fp32 summation order -- two training steps, un-planned and through the plan slots TrainStep uses."""
+    from legommenders_amd import engine as E
+    from legommenders_amd.synthetic import glove_like, init_nrms_params, make_world
+    dev = _dev()
+    D, B, C, S, V = 128, 16, 5, 50, 3000
+    w = make_world(seed=9, n_items=700, n_users=300, n_rows=400, V=V)
+    P = init_nrms_params(D=D, V=V, n_cat=w["n_cat"], heads=8, glove=glove_like(V, 300, seed=4, device=dev), seed=6)
+    for k in P:
+        if k.endswith("bias"):
+            P[k] = torch.randn_like(P[k]) * 0.1
+    Pd = {k: v.to(dev).contiguous() for k, v in P.items()}
+    tb = E.ItemTables(w["title_tok"], w["title_len"], w["cat"], dev)
+    rs = np.random.RandomState(3)
+    batches = []
+    for _ in range(2):
+        users = rs.randint(0, 300, size=B)
+        batches.append([torch.tensor(np.ascontiguousarray(a)).int().to(dev).contiguous() for a in
+                        (rs.randint(0, w["n_items"], size=(B, C)), w["user_hist"][users], np.maximum(w["user_hist_len"][users], 1))])
+    out = {}
+    for dedup in ("0", "1"):
+        monkeypatch.setenv("LEGO_NRMS_DEDUP", dedup)
+        eng = E.NrmsEngine(Pd, tb, B, C, S, heads=8, glove=True, seed=77)
+        assert eng.dedup == (dedup == "1")
+        G = eng.grads_like()
+        if planned:
+            eng.enable_plan_slots()
+        res = []
+        for i, ids in enumerate(batches):
+            if planned:
+                eng.plan_on(torch.cuda.current_stream(), i % 2, *ids)
+                eng.use_slot(i % 2)
+            scores, loss = eng.forward(*ids, training=True, planned=planned)
+            eng.backward(G)
+            res.append((scores.clone(), float(loss)))
+        torch.cuda.synchronize()
+        out[dedup] = (res, {k: v.clone() for k, v in G.items()})
+    (r0, g0), (r1, g1) = out["0"], out["1"]
+    for (s0, l0), (s1, l1) in zip(r0, r1):
+        _close(s1.cpu(), s0.cpu(), rtol=2e-5, what="scores")
+        assert abs(l0 - l1) < 2e-6
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    for k in g0:
+        d = float((g1[k] - g0[k]).abs().max())
+        assert d <= 2e-5 * gmax + 2e-5 * float(g0[k].abs().max()), (k, d, gmax)
+    assert float(g0["embedding_vocab_table.glove.linear.weight"].abs().max()) > 0
 
 
 @pytest.mark.parametrize("D,A", [(256, 256), (96, 40), (32, 0)])
