@@ -84,8 +84,11 @@ int64_t lego_sort_rows_temp_bytes(int n);
 /* out[r,:] = live_r * dropout_r(src[inv[r],:]) for r < rows: expands per-token projections to token rows, the site's Dropout
  * applied per ROW (embedding_hub.py:95-96: Dropout(Linear(.))); rows whose live bit is 0 in rowinfo are written as zeros (the
  * [SEP] / category positions of a ConcatInputer sequence, concat_inputer.py:96-114: their token look-up is masked) */
+/* add_a / idx_a, add_b / idx_b (nullable pairs): out[r,:] += add_a[idx_a[r],:] where idx_a[r] >= 0, the same for b -- the special-id and
+ * category look-ups ConcatInputer.get_embeddings sums with the token look-up (concat_inputer.py:96-114) */
 int lego_expand_rows(const float* src, int ld_src, const int32_t* inv, int rows_cap, const int32_t* rows_dyn, int width,
-                     const lego_dropout* drop, const int32_t* rowinfo /*nullable*/, float* out, int ld_out, void* stream);
+                     const lego_dropout* drop, const int32_t* rowinfo /*nullable*/, const float* add_a, int ld_a, const int32_t* idx_a,
+                     const float* add_b, int ld_b, const int32_t* idx_b, float* out, int ld_out, void* stream);
 /* out[u,:] = sum over rows r with inv[r] == u of g[r,:] (u < U; perm = the rows grouped by inv): the per-token sums the
  * projection's weight gradient is formed from.  out[0:U] must be zero on entry: zero_first = 1 clears it here, 0 = the caller
  * has (lego_zero_rows, e.g. on another stream ahead of time). */
@@ -226,13 +229,19 @@ int lego_relu_bwd(float* g, int ldg, const float* ref, int ldr, int rows, int wi
 #define LEGO_MHSA_ALL 0
 #define LEGO_MHSA_SHORT 1
 #define LEGO_MHSA_LONG 2
+/* long_list / long_count (nullable, together): the segments of more than 32 rows and their number, from lego_mhsa_long_segments on
+ * the same seg_off -- the long-segment launch then gives every (segment, head) pair its own workgroup instead of searching for them */
+int lego_mhsa_long_segments(const int32_t* seg_off, int n_cap, const int32_t* n_dyn, int32_t* list /*[n_cap]*/, int32_t* count /*[1]*/,
+                            void* stream);
 int lego_mhsa_core_fwd(const float* qkv, int ldq, const int32_t* seg_off, int n_cap, const int32_t* n_dyn,
                        int D, int heads, float* out, int ldo, float* probs /*[rows,heads,Lmax] saved*/,
-                       int Lmax, const lego_dropout* drop, int rows_cap, int part, void* stream);
+                       int Lmax, const lego_dropout* drop, int rows_cap, int part, const int32_t* long_list, const int32_t* long_count,
+                       void* stream);
 int lego_mhsa_core_bwd(const float* qkv, int ldq, const int32_t* seg_off, int n_cap, const int32_t* n_dyn,
                        int D, int heads, const float* gout, int ldgo, const float* probs, int Lmax,
                        const lego_dropout* drop, int rows_cap, float* gqkv, int ldgq,
-                       float* colsum /*nullable [3*D]: += column sums of gqkv = the in_proj_bias gradient*/, int part, void* stream);
+                       float* colsum /*nullable [3*D]: += column sums of gqkv = the in_proj_bias gradient*/, int part,
+                       const int32_t* long_list, const int32_t* long_count, void* stream);
 
 /* ---- a8 (engine route): the two affine layers behind the attention core -- nn.MultiheadAttention's out_proj and
  * AttentionOperator.linear (attention_operator.py:49-56, nothing between them) -- and the hidden layer of the additive attention

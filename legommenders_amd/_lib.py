@@ -44,7 +44,7 @@ SIGNATURES = {
     "lego_scatter_add_rows": [P, I, I, I, P, I, P, P, I, P],
     "lego_unique_tokens": [P, I, P, I, P, U32, P, P, P, P, P, P, P, P, P, P],
     "lego_sort_rows": [P, I, P, P, P, I64, P],
-    "lego_expand_rows": [P, I, P, I, P, I, P, P, P, I, P],
+    "lego_expand_rows": [P, I, P, I, P, I, P, P, P, I, P, P, I, P, P, I, P],
     "lego_segment_sum_rows": [P, I, I, P, P, I, P, P, P, I, I, P, I, P],
     "lego_zero_rows": [P, I, I, I, P, P],
     "lego_scatter_add_rows_range": [P, I, I, P, I, P, P, I, I, I, P],
@@ -69,8 +69,9 @@ SIGNATURES = {
     "lego_additive_pool_bwd": [P, I, P, I, P, P, P, I, P, I, I, P, I, P, P, I, P, P, P, P],
     "lego_dot_ce_fwd": [P, I, P, I, I, I, I, P, P, P],
     "lego_dot_ce_bwd": [P, I, P, I, P, I, I, I, F, P, I, P, I, P],
-    "lego_mhsa_core_fwd": [P, I, P, I, P, I, I, P, I, P, I, P, I, I, P],
-    "lego_mhsa_core_bwd": [P, I, P, I, P, I, I, P, I, P, I, P, I, P, I, P, I, P],
+    "lego_mhsa_long_segments": [P, I, P, P, P, P],
+    "lego_mhsa_core_fwd": [P, I, P, I, P, I, I, P, I, P, I, P, I, I, P, P, P],
+    "lego_mhsa_core_bwd": [P, I, P, I, P, I, I, P, I, P, I, P, I, P, I, P, I, P, P, P],
     "lego_user_tower_train": [P, I, P, I, P, P, I, I, I, I, I, F, P, P, P, P, I, P, P, P],
     "lego_rowdot_fwd": [P, I, P, I, I, I, P, P],
     "lego_rowdot_bwd": [P, I, P, I, P, I, I, P, I, P, I, P],

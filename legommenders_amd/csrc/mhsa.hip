@@ -107,6 +107,22 @@ __device__ __forceinline__ void col_add(const f32x16 (&t)[(HD + 31) / 32], float
     }
 }
 
+// Segments of more than 32 rows, listed once per plan (lego_mhsa_long_segments): with the list the long-segment launch gives every
+// (segment, head) pair its own workgroup.  Without it a workgroup finds its pairs by a strided ballot over ALL pairs and walks the
+// two or three it happens to own one after the other -- the launch then lasts as long as the unluckiest workgroup's chain
+// (21 us forward / 55 us backward for the 4 % of news items whose sequence has 33 rows).
+__global__ __launch_bounds__(1024) void mhsa_long_segments_kernel(const int* __restrict__ seg_off, int n_cap, const int* __restrict__ n_dyn,
+                                                                  int* __restrict__ list, int* __restrict__ count) {
+    __shared__ int fill;
+    if (threadIdx.x == 0) fill = 0;
+    __syncthreads();
+    const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
+    for (int s = threadIdx.x; s < n; s += blockDim.x)
+        if (seg_off[s + 1] - seg_off[s] > 32) list[atomicAdd(&fill, 1)] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *count = fill;
+}
+
 // The (segment, head) pairs a workgroup visits.  JT == 1 (segments of <= 32 rows, the bulk): one wave per workgroup, a grid stride
 // over all pairs.  JT == 2 (33..64 rows: 4 % of the news items, a fifth of the users): TWO waves per workgroup, wave t owns row
 // tile t of the pair.  Lane l of every wave looks at pair blockIdx.x + l * gridDim.x -- one round trip for up to 64 candidates, a
@@ -118,6 +134,13 @@ __device__ __forceinline__ void col_add(const f32x16 (&t)[(HD + 31) / 32], float
             const int seg = w / heads, h = w - seg * heads;                                                       \
             const int beg = seg_off[seg], L = seg_off[seg + 1] - beg;                                             \
             if (L <= 0 || L > 32) continue;                                                                       \
+            __VA_ARGS__;                                                                                          \
+        }                                                                                                         \
+    } else if (long_list != nullptr) {                                                                            \
+        const int cnt_ = min(*long_count, n) * heads;        /* the long segments were listed ahead of time */    \
+        for (int w = blockIdx.x; w < cnt_; w += gridDim.x) {                                                      \
+            const int seg = long_list[w / heads], h = w - (w / heads) * heads;                                    \
+            const int beg = seg_off[seg], L = seg_off[seg + 1] - beg;                                             \
             __VA_ARGS__;                                                                                          \
         }                                                                                                         \
     } else {                                                                                                      \
@@ -221,7 +244,8 @@ __device__ __forceinline__ void mhsa_fwd_pair(const float* __restrict__ qkv, int
 template <int HD, int JT>
 __global__ __launch_bounds__(64 * JT) __attribute__((amdgpu_waves_per_eu(JT == 1 && HD <= 32 ? 4 : 2))) void mhsa_fwd_kernel(
     const float* __restrict__ qkv, int ldq, const int* __restrict__ seg_off, int n_cap, const int* __restrict__ n_dyn, int D,
-    int heads, float* __restrict__ out, int ldo, float* __restrict__ probs, int Lmax, Dropout drop) {
+    int heads, float* __restrict__ out, int ldo, float* __restrict__ probs, int Lmax, Dropout drop,
+    const int* __restrict__ long_list, const int* __restrict__ long_count) {
     const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
     const int t0 = JT == 1 ? 0 : (int)(threadIdx.x >> 6);           // JT == 2: wave t owns query tile t
     LEGO_MHSA_WALK(mhsa_fwd_pair<HD, JT>(qkv, ldq, D, heads, out, ldo, probs, Lmax, drop, h, beg, L, t0, t0 + 1))
@@ -336,7 +360,7 @@ template <int HD, int JT>
 __global__ __launch_bounds__(64 * JT) __attribute__((amdgpu_waves_per_eu(JT == 1 ? (HD == 32 ? 3 : 2) : 1))) void mhsa_bwd_kernel(
     const float* __restrict__ qkv, int ldq, const int* __restrict__ seg_off, int n_cap, const int* __restrict__ n_dyn, int D,
     int heads, const float* __restrict__ gout, int ldgo, const float* __restrict__ probs, int Lmax, float keep_scale,
-    float* __restrict__ gqkv, int ldgq, float* colsum) {
+    float* __restrict__ gqkv, int ldgq, float* colsum, const int* __restrict__ long_list, const int* __restrict__ long_count) {
     constexpr int LT = 32 * JT;
     __shared__ float Pd[LT * (LT + 1)];                       // dropped-and-rescaled probabilities [key j][query i]
     __shared__ float Ds[LT * (LT + 1)];                       // dS^T [key j][query i]
@@ -369,12 +393,20 @@ static Dropout to_drop(const lego_dropout* d) {
 
 using namespace lego;
 
+extern "C" int lego_mhsa_long_segments(const int32_t* seg_off, int n_cap, const int32_t* n_dyn, int32_t* list, int32_t* count, void* stream) {
+    if (n_cap <= 0) return hipMemsetAsync(count, 0, sizeof(int32_t), (hipStream_t)stream) == hipSuccess ? 0 : set_error("lego_mhsa_long_segments: memset failed");
+    hipLaunchKernelGGL(mhsa_long_segments_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, seg_off, n_cap, n_dyn, list, count);
+    return check_launch("lego_mhsa_long_segments");
+}
+
 extern "C" int lego_mhsa_core_fwd(const float* qkv, int ldq, const int32_t* seg_off, int n_cap, const int32_t* n_dyn,
                                   int D, int heads, float* out, int ldo, float* probs, int Lmax,
-                                  const lego_dropout* drop, int rows_cap, int part, void* stream) {
+                                  const lego_dropout* drop, int rows_cap, int part, const int32_t* long_list,
+                                  const int32_t* long_count, void* stream) {
     LEGO_REQUIRE(heads > 0 && D % heads == 0, "lego_mhsa_core_fwd: D=%d not divisible by heads=%d", D, heads);
     LEGO_REQUIRE(Lmax <= kMaxL, "lego_mhsa_core_fwd: Lmax=%d exceeds %d", Lmax, kMaxL);
     LEGO_REQUIRE((ldq & 3) == 0 && (D & 3) == 0, "lego_mhsa_core_fwd: ldq=%d and D=%d must be multiples of 4", ldq, D);
+    LEGO_REQUIRE((long_list == nullptr) == (long_count == nullptr), "lego_mhsa_core_fwd: long_list and long_count go together");
     if (n_cap <= 0) return 0;
     (void)rows_cap;
     const int hd = D / heads;
@@ -382,9 +414,9 @@ extern "C" int lego_mhsa_core_fwd(const float* qkv, int ldq, const int32_t* seg_
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(HD) do { \
         if (part != LEGO_MHSA_LONG) \
-            hipLaunchKernelGGL((mhsa_fwd_kernel<HD, 1>), dim3(short_grid(n_cap, heads)), dim3(64), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, out, ldo, probs, Lmax, dr); \
+            hipLaunchKernelGGL((mhsa_fwd_kernel<HD, 1>), dim3(short_grid(n_cap, heads)), dim3(64), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, out, ldo, probs, Lmax, dr, nullptr, nullptr); \
         if (Lmax > 32 && part != LEGO_MHSA_SHORT) \
-            hipLaunchKernelGGL((mhsa_fwd_kernel<HD, 2>), dim3(long_grid(n_cap, heads)), dim3(128), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, out, ldo, probs, Lmax, dr); \
+            hipLaunchKernelGGL((mhsa_fwd_kernel<HD, 2>), dim3(long_grid(n_cap, heads)), dim3(128), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, out, ldo, probs, Lmax, dr, long_list, long_count); \
     } while (0)
     switch (hd) {
         case 8: LAUNCH(8); break;
@@ -399,7 +431,8 @@ extern "C" int lego_mhsa_core_fwd(const float* qkv, int ldq, const int32_t* seg_
 
 extern "C" int lego_mhsa_core_bwd(const float* qkv, int ldq, const int32_t* seg_off, int n_cap, const int32_t* n_dyn,
                                   int D, int heads, const float* gout, int ldgo, const float* probs, int Lmax,
-                                  const lego_dropout* drop, int rows_cap, float* gqkv, int ldgq, float* colsum, int part, void* stream) {
+                                  const lego_dropout* drop, int rows_cap, float* gqkv, int ldgq, float* colsum, int part,
+                                  const int32_t* long_list, const int32_t* long_count, void* stream) {
     LEGO_REQUIRE(heads > 0 && D % heads == 0, "lego_mhsa_core_bwd: D=%d not divisible by heads=%d", D, heads);
     LEGO_REQUIRE(Lmax <= kMaxL, "lego_mhsa_core_bwd: Lmax=%d exceeds %d", Lmax, kMaxL);
     LEGO_REQUIRE((ldq & 3) == 0 && (ldgo & 3) == 0 && (D & 3) == 0, "lego_mhsa_core_bwd: ldq=%d, ldgo=%d and D=%d must be multiples of 4", ldq, ldgo, D);
@@ -411,9 +444,9 @@ extern "C" int lego_mhsa_core_bwd(const float* qkv, int ldq, const int32_t* seg_
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(HD) do { \
         if (part != LEGO_MHSA_LONG) \
-            hipLaunchKernelGGL((mhsa_bwd_kernel<HD, 1>), dim3(short_grid(n_cap, heads)), dim3(64), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, gout, ldgo, probs, Lmax, ks, gqkv, ldgq, colsum); \
+            hipLaunchKernelGGL((mhsa_bwd_kernel<HD, 1>), dim3(short_grid(n_cap, heads)), dim3(64), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, gout, ldgo, probs, Lmax, ks, gqkv, ldgq, colsum, nullptr, nullptr); \
         if (Lmax > 32 && part != LEGO_MHSA_SHORT) \
-            hipLaunchKernelGGL((mhsa_bwd_kernel<HD, 2>), dim3(long_grid(n_cap, heads)), dim3(128), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, gout, ldgo, probs, Lmax, ks, gqkv, ldgq, colsum); \
+            hipLaunchKernelGGL((mhsa_bwd_kernel<HD, 2>), dim3(long_grid(n_cap, heads)), dim3(128), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, gout, ldgo, probs, Lmax, ks, gqkv, ldgq, colsum, long_list, long_count); \
     } while (0)
     switch (hd) {
         case 8: LAUNCH(8); break;

@@ -398,9 +398,13 @@ __global__ void uq_fill_kernel(const int* __restrict__ inv, int R_cap, const int
 // out[r, :] = keep(r, :) / (1 - p) * src[inv[r], :] (rows r < R): Dropout(Linear(.)) of embedding_hub.py:95-96 applied while
 // the per-token projections are expanded to the batch's token rows.  One wave per row, lane = 4 columns (width <= 256), four
 // rows in flight; the keep bits are the site's precomputed mask (byte [(r / 4) * width + col], bit r % 4) or Philox draws.
+// rows of up to two small tables added to the expanded row: out[r] += tab_a[idx_a[r]] (idx >= 0) + tab_b[idx_b[r]] -- ConcatInputer sums the
+// token look-up with the special-id and the category look-up (concat_inputer.py:96-114); the [SEP] / category positions get theirs here
+struct ExpandAdd { const float* tab_a; const int* idx_a; int ld_a; const float* tab_b; const int* idx_b; int ld_b; };
+
 __global__ __launch_bounds__(256) void expand_rows_kernel(const float* __restrict__ src, int ld_src, const int* __restrict__ inv, int rows_cap,
                                                           const int* __restrict__ rows_dyn, int width, Dropout drop,
-                                                          const int* __restrict__ rowinfo, float* __restrict__ out, int ld_out) {
+                                                          const int* __restrict__ rowinfo, ExpandAdd add, float* __restrict__ out, int ld_out) {
     const int rows = rows_dyn != nullptr ? min(rows_cap, *rows_dyn) : rows_cap;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
@@ -441,16 +445,21 @@ __global__ __launch_bounds__(256) void expand_rows_kernel(const float* __restric
             const int r = r0 + u;
             if (r >= rows) break;
             float* dst = out + (size_t)r * ld_out;
+            const int ia = add.idx_a != nullptr ? add.idx_a[r] : -1, ib = add.idx_b != nullptr ? add.idx_b[r] : -1;   // wave-uniform
             if (in) {
                 f32x4 o;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[i] = (kw >> (8 * i + u)) & 1u ? v[u][i] * dinv : 0.f;
+                if (ia >= 0) o += *reinterpret_cast<const f32x4*>(add.tab_a + (size_t)ia * add.ld_a + c);
+                if (ib >= 0) o += *reinterpret_cast<const f32x4*>(add.tab_b + (size_t)ib * add.ld_b + c);
                 *reinterpret_cast<f32x4*>(dst + c) = o;
             }
             if (in2) {
                 f32x4 o;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[i] = (kw2 >> (8 * i + u)) & 1u ? v2[u][i] * dinv : 0.f;
+                if (ia >= 0) o += *reinterpret_cast<const f32x4*>(add.tab_a + (size_t)ia * add.ld_a + c2);
+                if (ib >= 0) o += *reinterpret_cast<const f32x4*>(add.tab_b + (size_t)ib * add.ld_b + c2);
                 *reinterpret_cast<f32x4*>(dst + c2) = o;
             }
         }
@@ -1663,12 +1672,15 @@ extern "C" int lego_unique_tokens(const int32_t* row_tok, int R_cap, const int32
 }
 
 extern "C" int lego_expand_rows(const float* src, int ld_src, const int32_t* inv, int rows_cap, const int32_t* rows_dyn, int width,
-                                const lego_dropout* drop, const int32_t* rowinfo, float* out, int ld_out, void* stream) {
+                                const lego_dropout* drop, const int32_t* rowinfo, const float* add_a, int ld_a, const int32_t* idx_a,
+                                const float* add_b, int ld_b, const int32_t* idx_b, float* out, int ld_out, void* stream) {
     LEGO_REQUIRE((width & 3) == 0 && (ld_src & 3) == 0 && (ld_out & 3) == 0, "lego_expand_rows: width=%d must be a multiple of 4", width);
+    LEGO_REQUIRE((add_a == nullptr) == (idx_a == nullptr) && (add_b == nullptr) == (idx_b == nullptr) && (add_a == nullptr || (ld_a & 3) == 0) &&
+                 (add_b == nullptr || (ld_b & 3) == 0), "lego_expand_rows: an added table needs its index list and a row stride that is a multiple of 4");
     if (rows_cap <= 0) return 0;
     const int want = (rows_cap + 15) / 16;                 // four waves per block, four consecutive rows per wave and iteration
     hipLaunchKernelGGL(expand_rows_kernel, dim3(want < 2048 ? want : 2048, (width + 511) / 512), dim3(256), 0, ST, src, ld_src, inv, rows_cap, rows_dyn, width,
-                       make_dropout(drop), rowinfo, out, ld_out);
+                       make_dropout(drop), rowinfo, ExpandAdd{add_a, idx_a, ld_a, add_b, idx_b, ld_b}, out, ld_out);
     return check_launch("lego_expand_rows");
 }
 

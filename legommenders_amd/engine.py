@@ -361,7 +361,7 @@ class NamlEngine(_Base):
                         _ptr(self.uq_temp), self.uq_temp.numel())
             if not self.dedup_bwd:                   # the weight gradient still runs over the token rows: X[r] = Xu[inv[r]]
                 self.kk(s, "expand_rows_in_step" if stream is not None else None, "lego_expand_rows", _ptr(b["Xu"]), self.E0, _ptr(b["inv"]),
-                        self.Rc, _ptr(b["counters"], 0), self.E0, None, None, _ptr(b["X"]), self.E0)
+                        self.Rc, _ptr(b["counters"], 0), self.E0, None, None, None, 0, None, None, 0, None, _ptr(b["X"]), self.E0)
             return
         # with timers on (bench.py) the launch is bracketed by HIP events on the stream it runs on: on the prefetch stream
         # that is the gather's duration INSIDE the step, overlapped with the previous step's user-side chain
@@ -496,7 +496,7 @@ class NamlEngine(_Base):
                     _ptr(P["embedding_vocab_table.glove.linear.bias"]), _ptr(self.Hu), D, self.Uc, self.cnt(6), D, E0, 0,
                     None, None, None, None)
             self.kk(m, "proj_expand", "lego_expand_rows", _ptr(self.Hu), D, _ptr(self.inv), self.Rc, self.cnt(0), D,
-                    self.drop(self.p_proj, SITE_PROJ, training), None, _ptr(self.H), D)
+                    self.drop(self.p_proj, SITE_PROJ, training), None, None, 0, None, None, 0, None, _ptr(self.H), D)
         else:
             self.kk(m, "proj_fwd", "lego_linear_fwd", _ptr(self.X), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
                     _ptr(P["embedding_vocab_table.glove.linear.bias"]), _ptr(self.H), D, self.Rc, self.cnt(0), D, E0, 0,
@@ -737,10 +737,15 @@ class NrmsEngine(_Base):
         self.d_user = self._f(B, D)
         self.item_ws = self._att_ws(self.Rc, self.L, max(self.NIc, 1))
         self.user_ws = self._att_ws(B * S, S, B)
+        # segments of more than 32 rows (an item whose title fills all T positions, a user with more than 32 clicks), listed with the
+        # plan: the long-segment attention launch gives each (segment, head) pair of the list its own workgroup (csrc/mhsa.hip)
+        self.long_items = torch.zeros(max(self.NIc, 1), **i32)
+        self.long_users = torch.zeros(max(B, 1), **i32)
+        self.long_cnt = torch.zeros(2, **i32)
 
     # with the plan (TrainStep's prefetch stream): the decoded index rows and, GloVe variant, the gathered token rows X -- the table is
     # frozen, so the 20 us gather and the 6 us decode of batch N+1 run beside batch N instead of at the head of its own step
-    _PLAN_FIELDS = _Base._PLAN_FIELDS + ("idx_tok", "idx_spec", "idx_cat", "tokinfo")
+    _PLAN_FIELDS = _Base._PLAN_FIELDS + ("idx_tok", "idx_spec", "idx_cat", "tokinfo", "long_items", "long_users", "long_cnt")
 
     def enable_plan_slots(self):
         if getattr(self, "_slots", None) is None and self.glove:
@@ -749,8 +754,15 @@ class NrmsEngine(_Base):
 
     def plan_on(self, stream, slot, cand, hist, hist_len, nb=None):
         super().plan_on(stream, slot, cand, hist, hist_len, nb)
+        self._long_lists(self._slots[slot], ctypes.c_void_p(stream.cuda_stream), nb)
         if self.Rc > 0:
             self._decode_gather(self._slots[slot], ctypes.c_void_p(stream.cuda_stream))
+
+    def _long_lists(self, b, st, nb=None):
+        if self.L > 32 and self.Rc > 0:
+            call("lego_mhsa_long_segments", _ptr(b["seg_off"]), self.NIc, _ptr(b["counters"], 1), _ptr(b["long_items"]), _ptr(b["long_cnt"], 0), st)
+        if self.S > 32:
+            call("lego_mhsa_long_segments", _ptr(b["hist_off"]), (nb or self.B) if b is not self.__dict__ else self.nb, None, _ptr(b["long_users"]), _ptr(b["long_cnt"], 1), st)
 
     def _decode_gather(self, b, st):
         call("lego_nrms_decode_rows", _ptr(b["row_tok"]), self.Rc, _ptr(b["counters"], 0), _ptr(b["idx_tok"]), _ptr(b["idx_spec"]),
@@ -794,7 +806,7 @@ class NrmsEngine(_Base):
                 None, None, None, None)
         core = ("lego_mhsa_core_fwd", _ptr(ws["qkv"]), 3 * D, _ptr(seg_off), n_cap, n_dyn, D, self.heads,
                 _ptr(ws["o"]), D, _ptr(ws["probs"]), ws["Lmax"], self.drop(self.p_att, site, training), rows)
-        self.kk(m, "mhsa_core_fwd_" + tg, *core, 0)
+        self.kk(m, "mhsa_core_fwd_" + tg, *core, 0, *self._long(pre, ws))
         if self.fold and self._fold_ev is not None:          # the folded weights come from the side stream (_prepare_folds)
             m.wait_event(self._fold_ev)
             self._fold_ev = None
@@ -826,6 +838,13 @@ class NrmsEngine(_Base):
              _ptr(out), D, _ptr(ws["wrow"]), st)
 
     _fold_ev = None
+
+    def _long(self, pre, ws):
+        """(list, count) of the operator's segments of more than 32 rows, or (None, None) when it cannot have any"""
+        if ws["Lmax"] <= 32:
+            return None, None
+        user = pre == "user_op."
+        return _ptr(self.long_users if user else self.long_items), _ptr(self.long_cnt, 1 if user else 0)
 
     def _prepare_folds(self):
         """Wc = Wl Wo, bc = Wl bo + bl (and, level 2, W2 = W1 Wc, b2 = W1 bc + b1) of both operators: D x D work that only needs the
@@ -884,7 +903,7 @@ class NrmsEngine(_Base):
                 n_cap, n_dyn, D, self.heads, _ptr(ws["d_o"]), D, _ptr(ws["probs"]), ws["Lmax"],
                 self.drop(self.p_att, site, training), rows, _ptr(ws["d_qkv"]), 3 * D,
                 _ptr(G[pre + "multi_head_attention.in_proj_bias"]))      # bias gradient = column sums of d_qkv, fused
-        self.kk(m, "mhsa_core_bwd_" + pre[:4], *core, 0)
+        self.kk(m, "mhsa_core_bwd_" + pre[:4], *core, 0, *self._long(pre, ws))
         if sw is not m:
             ev[1].record(m)
 
@@ -1035,6 +1054,7 @@ class NrmsEngine(_Base):
              _ptr(self.seq_tok), _ptr(self.seq_len), self.L,
              _ptr(self.counters), _ptr(self.inst_item), _ptr(self.seg_off), _ptr(self.hist_off),
              _ptr(self.rowinfo), _ptr(self.row_tok), _stream())
+        self._long_lists(self.__dict__, _stream())
 
     _folds_fresh = False
     # GloVe variant: mask + Dropout backward and the projection bias gradient in the epilogue of dx = d_qkv W_in, [SEP] / category
@@ -1055,8 +1075,13 @@ class NrmsEngine(_Base):
             call("lego_linear_fwd", _ptr(self.Xu), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
                  _ptr(P["embedding_vocab_table.glove.linear.bias"]), _ptr(self.Hu), D, self.Uc, self.cnt(6), D, E0, 0,
                  None, None, None, None, st)
+            # ... and the two other look-ups ConcatInputer sums in (the [SEP] / category rows) added by the same kernel
             call("lego_expand_rows", _ptr(self.Hu), D, _ptr(self.inv), self.Rc, self.cnt(0), D, self.drop(self.p_proj, SITE_PROJ, training),
-                 _ptr(self.tokinfo), _ptr(self.E), D, st)
+                 _ptr(self.tokinfo), _ptr(P["embedding_vocab_table.__cat_inputer_special_ids.weight"]), D, _ptr(self.idx_spec),
+                 _ptr(P["embedding_vocab_table.category.weight"]), D, _ptr(self.idx_cat), _ptr(self.E), D, st)
+            self._att_fwd("item_op.", self.item_ws, _ptr(self.E), self.cnt(0), self.seg_off, self.NIc, self.cnt(1),
+                          self.items, SITE_ITEM_ATT, training, st)
+            return
         elif self.glove:
             E0 = self.E0
             call("lego_linear_fwd", _ptr(self.X), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
@@ -1143,12 +1168,15 @@ class NrmsEngine(_Base):
                  _ptr(g_spec, 2 * D), _ptr(g_cat), D, n_cat, st)
         if self.glove:
             E0 = self.E0
+            gb = _ptr(G["embedding_vocab_table.glove.linear.bias"])
             if not fused:                            # the three-pass form (kept as the cross-check of the fused epilogue)
                 call("lego_mask_dropout_rows", _ptr(self.dE), D, self.Rc, self.cnt(0), D, _ptr(self.tokinfo),
-                     self.drop(self.p_proj, SITE_PROJ, training), _ptr(G["embedding_vocab_table.glove.linear.bias"]), st)
+                     self.drop(self.p_proj, SITE_PROJ, training), None if self.dedup else gb, st)
             if self.dedup:                           # per-token sums of the masked dE, then the product over the distinct tokens
                 call("lego_segment_sum_rows", _ptr(self.dE), D, D, _ptr(self.perm), _ptr(self.inv), self.Rc, _ptr(self.keys_sorted),
                      self.cnt(0), _ptr(self.dHu), D, self.Uc, self.cnt(6), 1, st)
+                if not fused:                        # the bias gradient = column sums of the masked dE = column sums of the per-token sums
+                    call("lego_colsum", _ptr(self.dHu), D, self.Uc, self.cnt(6), None, D, gb, st)
                 call("lego_linear_bwd_weight", _ptr(self.dHu), D, _ptr(self.Xu), E0,
                      _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Uc, self.cnt(6), D, E0, None, None, st)
             else:

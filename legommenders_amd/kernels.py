@@ -245,7 +245,7 @@ def mhsa_fwd(x, mask, in_w, in_b, out_w, out_b, heads, drop=None):
     o = torch.empty(R, D, dtype=torch.float32, device=x.device)
     probs = torch.zeros(R, heads, L, dtype=torch.float32, device=x.device)   # slots past a segment's length are never written
     call("lego_mhsa_core_fwd", _ptr(qkv), 3 * D, _ptr(seg_off), n, None, D, heads, _ptr(o), D, _ptr(probs), L,
-         _drop(drop), R, 0, _stream())
+         _drop(drop), R, 0, None, None, _stream())
     yc = linear_fwd(o, out_w, out_b)
     y = torch.zeros(n * L, D, dtype=torch.float32, device=x.device)
     y.index_copy_(0, idx.long(), yc)
@@ -267,7 +267,7 @@ def mhsa_bwd(ctx, gy):
     go = linear_bwd_data(gyc, ctx.out_w)
     gqkv = torch.empty(R, 3 * D, dtype=torch.float32, device=dev)
     call("lego_mhsa_core_bwd", _ptr(ctx.qkv), 3 * D, _ptr(ctx.seg_off), n, None, D, ctx.heads, _ptr(go), D, _ptr(ctx.probs), L,
-         _drop(ctx.drop), R, _ptr(gqkv), 3 * D, None, 0, _stream())
+         _drop(ctx.drop), R, _ptr(gqkv), 3 * D, None, 0, None, None, _stream())
     gin_w = torch.zeros(3 * D, D, dtype=torch.float32, device=dev)
     gin_b = torch.zeros(3 * D, dtype=torch.float32, device=dev)
     linear_bwd_weight(gqkv, ctx.xc, gin_w)

@@ -501,15 +501,24 @@ def test_unique_tokens_expand_and_segment_sum():
     d = LegoDropout(0.1, 99, 7, None)
     call("lego_dropout_mask", ctypes.byref(d), R_cap, None, D, P(mask), None)
     out_m, out_p, out_0 = (torch.full((R_cap, D), 7.0, device=dev) for _ in range(3))
-    call("lego_expand_rows", P(src), D, P(inv), R_cap, P(R_dyn), D, ctypes.byref(LegoDropout(0.1, 99, 7, mask.data_ptr())), None, P(out_m), D, None)
-    call("lego_expand_rows", P(src), D, P(inv), R_cap, P(R_dyn), D, ctypes.byref(d), None, P(out_p), D, None)
-    call("lego_expand_rows", P(src), D, P(inv), R_cap, P(R_dyn), D, None, None, P(out_0), D, None)
+    NOADD = (None, 0, None, None, 0, None)
+    call("lego_expand_rows", P(src), D, P(inv), R_cap, P(R_dyn), D, ctypes.byref(LegoDropout(0.1, 99, 7, mask.data_ptr())), None, *NOADD, P(out_m), D, None)
+    call("lego_expand_rows", P(src), D, P(inv), R_cap, P(R_dyn), D, ctypes.byref(d), None, *NOADD, P(out_p), D, None)
+    call("lego_expand_rows", P(src), D, P(inv), R_cap, P(R_dyn), D, None, None, *NOADD, P(out_0), D, None)
     # rows without the live bit (the [SEP] / category positions of a ConcatInputer sequence) come out as zeros
     live = torch.tensor((rs.rand(R_cap) < 0.8).astype(np.int32) * 4).to(dev)          # RI_LIVE = 4
     out_l = torch.full((R_cap, D), 7.0, device=dev)
-    call("lego_expand_rows", P(src), D, P(inv), R_cap, P(R_dyn), D, ctypes.byref(d), P(live), P(out_l), D, None)
+    call("lego_expand_rows", P(src), D, P(inv), R_cap, P(R_dyn), D, ctypes.byref(d), P(live), *NOADD, P(out_l), D, None)
+    # ... and get the rows of two small tables added where their index is >= 0 (ConcatInputer's special-id and category look-ups)
+    ta, tb_ = torch.randn(3, D, generator=g).to(dev), torch.randn(18, D + 4, generator=g).to(dev)
+    ia = torch.tensor(np.where(rs.rand(R_cap) < 0.1, rs.randint(0, 3, size=R_cap), -1).astype(np.int32)).to(dev)
+    ib = torch.tensor(np.where(rs.rand(R_cap) < 0.1, rs.randint(0, 18, size=R_cap), -1).astype(np.int32)).to(dev)
+    out_a = torch.full((R_cap, D), 7.0, device=dev)
+    call("lego_expand_rows", P(src), D, P(inv), R_cap, P(R_dyn), D, ctypes.byref(d), P(live), P(ta), D, P(ia), P(tb_), D + 4, P(ib), P(out_a), D, None)
     torch.cuda.synchronize()
     assert torch.equal(out_l[:R], out_p[:R] * (live[:R, None] != 0)) and bool((out_l[R:] == 7.0).all())
+    want_a = out_l[:R] + ta[ia[:R].clamp(min=0).long()] * (ia[:R, None] >= 0) + tb_[ib[:R].clamp(min=0).long(), :D] * (ib[:R, None] >= 0)
+    assert torch.allclose(out_a[:R], want_a, rtol=0, atol=1e-6) and bool((out_a[R:] == 7.0).all())
     plain = src[inv[:R].long()]
     assert torch.equal(out_0[:R], plain) and bool((out_0[R:] == 7.0).all())
     assert torch.equal(out_m, out_p)
@@ -956,8 +965,9 @@ def test_trainable_token_table_full_vocabulary():
         assert float((a - b).norm()) <= max(5e-2 * float((b - p0).norm()), floor) + 1e-7, k
 
 
+@pytest.mark.parametrize("listed", [False, True])
 @pytest.mark.parametrize("hd,heads,p", [(32, 8, 0.0), (32, 8, 0.2), (16, 4, 0.1), (8, 2, 0.0), (64, 2, 0.3)])
-def test_mhsa_core_ragged_segments_with_dropout(hd, heads, p):
+def test_mhsa_core_ragged_segments_with_dropout(hd, heads, p, listed):
     """lego_mhsa_core_fwd / _bwd against float64 autograd on ragged segments of 1..64 rows (both tile instantiations, empty segments,
     the 32/33-row boundary).  With dropout on, the keep decisions are read back from the sign bits of the saved probabilities:
     the forward output and all three gradients must be those of softmax(QK^T/sqrt(hd)) * keep / (1-p) @ V with exactly that mask,
@@ -975,11 +985,19 @@ def test_mhsa_core_ragged_segments_with_dropout(hd, heads, p):
     out = torch.full((R, D), float("nan"), device=dev)
     probs = torch.zeros(R, heads, Lmax, device=dev)
     drop = (p, 99, 3) if p > 0 else None
-    call("lego_mhsa_core_fwd", _ptr(qkv), 3 * D, _ptr(seg), n, None, D, heads, _ptr(out), D, _ptr(probs), Lmax, _drop(drop), R, 0, _stream())
+    ll = lc = None                                   # `listed`: the long segments from lego_mhsa_long_segments (one workgroup per pair)
+    if listed:
+        ll, lc = torch.full((n,), -1, dtype=torch.int32, device=dev), torch.full((1,), -1, dtype=torch.int32, device=dev)
+        call("lego_mhsa_long_segments", _ptr(seg), n, None, _ptr(ll), _ptr(lc), _stream())
+        torch.cuda.synchronize()
+        want_long = [i for i, L in enumerate(lens) if L > 32]
+        assert int(lc) == len(want_long) and sorted(ll[:int(lc)].cpu().tolist()) == want_long
+    call("lego_mhsa_core_fwd", _ptr(qkv), 3 * D, _ptr(seg), n, None, D, heads, _ptr(out), D, _ptr(probs), Lmax, _drop(drop), R, 0,
+         _ptr(ll), _ptr(lc), _stream())
     gqkv = torch.full((R, 3 * D), float("nan"), device=dev)
     colsum = torch.zeros(3 * D, device=dev)
     call("lego_mhsa_core_bwd", _ptr(qkv), 3 * D, _ptr(seg), n, None, D, heads, _ptr(go), D, _ptr(probs), Lmax, _drop(drop), R,
-         _ptr(gqkv), 3 * D, _ptr(colsum), 0, _stream())
+         _ptr(gqkv), 3 * D, _ptr(colsum), 0, _ptr(ll), _ptr(lc), _stream())
     torch.cuda.synchronize()
     pr, q64, g64 = probs.cpu().double().reshape(-1), qkv.cpu().double(), go.cpu().double()
     kept = total = 0
