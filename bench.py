@@ -451,6 +451,9 @@ def main():
             "workload": f"MIND-small-shaped {other.upper()} hidden={D} bs={B} GloVe, full train step (BASELINE config 3)",
             "steps": 60, "warmup": 10, "ms_per_step": round(d2 / 60 * 1e3, 4), "value": round(B * 60 / d2, 1), "unit": "impressions/s",
             "live_token_rows_per_step": round(c2[0] / 60, 1),
+            **({"distinct_tokens_per_step": round(c2[6] / 60, 1),
+                "projection": "once per DISTINCT token of the batch, expanded to the sequence rows (LEGO_NRMS_DEDUP=0: row by row)"}
+               if other == "nrms" and getattr(t2.engine, "dedup", False) else {}),
             "roofline": dominant(k2, f2, tuple(f2), {}),
             "kernels": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in k2.items()}}
         del t2
