@@ -94,7 +94,10 @@ int lego_expand_rows(const float* src, int ld_src, const int32_t* inv, int rows_
  * has (lego_zero_rows, e.g. on another stream ahead of time). */
 int lego_segment_sum_rows(const float* g, int ld_g, int width, const int32_t* perm, const int32_t* inv, int R_cap,
                           const int32_t* sorted_keys /*nullable: inv[perm[p]] per position, lego_sort_rows' key output*/,
-                          const int32_t* R_dyn, float* out, int ld_out, int U_cap, const int32_t* U_dyn, int zero_first, void* stream);
+                          const int32_t* R_dyn, float* out, int ld_out, int U_cap, const int32_t* U_dyn, int zero_first,
+                          const lego_dropout* drop /*nullable; must carry lego_dropout_mask's keep bits: g[r,:] is multiplied by
+                                                     keep(r,:) / (1 - p) as it is read -- the Dropout backward of the rows*/,
+                          const int32_t* rowinfo /*nullable: rows whose live bit is 0 add nothing*/, void* stream);
 int lego_zero_rows(float* out, int ld_out, int width, int rows_cap, const int32_t* rows_dyn /*nullable*/, void* stream);
 /* backward of a TRAINABLE table (embed/null.yaml): grad_table[idx[r]] += g[r] (dense grad semantics) */
 int lego_scatter_add_rows(float* grad_table, int ld_table, int width, int table_rows /*<= 32: LDS pre-reduction*/,

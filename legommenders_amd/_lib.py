@@ -45,7 +45,7 @@ SIGNATURES = {
     "lego_unique_tokens": [P, I, P, I, P, U32, P, P, P, P, P, P, P, P, P, P],
     "lego_sort_rows": [P, I, P, P, P, I64, P],
     "lego_expand_rows": [P, I, P, I, P, I, P, P, P, I, P, P, I, P, P, I, P],
-    "lego_segment_sum_rows": [P, I, I, P, P, I, P, P, P, I, I, P, I, P],
+    "lego_segment_sum_rows": [P, I, I, P, P, I, P, P, P, I, I, P, I, P, P, P],
     "lego_zero_rows": [P, I, I, I, P, P],
     "lego_scatter_add_rows_range": [P, I, I, P, I, P, P, I, I, I, P],
     "lego_linear_fwd": [P, I, P, I, P, P, I, I, P, I, I, I, P, P, P, P, P],

@@ -499,7 +499,9 @@ __device__ __forceinline__ void atomic_add_row(float* out_row, int col0, int wid
 
 __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float* __restrict__ g, int ld_g, int width, const int* __restrict__ perm,
                                                                const int* __restrict__ inv, const int* __restrict__ sorted_keys,
-                                                               int R_cap, const int* __restrict__ R_dyn, float* out, int ld_out) {
+                                                               int R_cap, const int* __restrict__ R_dyn, float* out, int ld_out,
+                                                               const uint8_t* __restrict__ keep_mask, float keep_scale,
+                                                               const int* __restrict__ rowinfo) {
     const int R = R_dyn != nullptr ? min(R_cap, *R_dyn) : R_cap;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
@@ -528,7 +530,14 @@ __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float* __re
             const int i = min(b0 + j, n - 1);
             const int row = __shfl(my_row, 1 + i, 64);
             uu[j] = __shfl(my_u, 1 + i, 64);
-            v[j] = (b0 + j < n && in) ? *reinterpret_cast<const f32x4*>(g + (size_t)row * ld_g + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            bool take = b0 + j < n && in;
+            if (rowinfo != nullptr && (rowinfo[row] & RI_LIVE) == 0) take = false;          // wave-uniform: a masked row adds nothing
+            v[j] = take ? *reinterpret_cast<const f32x4*>(g + (size_t)row * ld_g + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (keep_mask != nullptr && take) {      // Dropout backward of the row: byte [(row / 4) * width + col], bit row % 4
+                const uint32_t kw = *reinterpret_cast<const uint32_t*>(keep_mask + (uint64_t)(row >> 2) * (uint64_t)width + (uint64_t)c);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[j][i] = (kw >> (8 * i + (row & 3))) & 1u ? v[j][i] * keep_scale : 0.f;
+            }
         }
 #pragma unroll
         for (int j = 0; j < kSegBatch; ++j) {
@@ -1694,14 +1703,18 @@ extern "C" int lego_zero_rows(float* out, int ld_out, int width, int rows_cap, c
 
 extern "C" int lego_segment_sum_rows(const float* g, int ld_g, int width, const int32_t* perm, const int32_t* inv, int R_cap,
                                      const int32_t* sorted_keys, const int32_t* R_dyn, float* out, int ld_out, int U_cap,
-                                     const int32_t* U_dyn, int zero_first, void* stream) {
+                                     const int32_t* U_dyn, int zero_first, const lego_dropout* drop, const int32_t* rowinfo, void* stream) {
     LEGO_REQUIRE((width & 3) == 0 && (ld_g & 3) == 0 && (ld_out & 3) == 0, "lego_segment_sum_rows: width=%d must be a multiple of 4", width);
+    LEGO_REQUIRE(drop == nullptr || drop->p <= 0.f || drop->mask != nullptr, "lego_segment_sum_rows: a dropout site needs its precomputed keep bits (lego_dropout_mask)");
     if (R_cap <= 0) return 0;
+    const Dropout dr = make_dropout(drop);
+    const bool dropping = dr.p > 0.f;
     if (zero_first) {
         const long long tot = (long long)U_cap * (width / 4);
         hipLaunchKernelGGL(zero_rows_kernel, dim3((int)((tot + 255) / 256 < 2048 ? (tot + 255) / 256 : 2048)), dim3(256), 0, ST, out, ld_out, width, U_cap, U_dyn);
     }
-    hipLaunchKernelGGL(segment_sum_rows_kernel, dim3((R_cap + 4 * kSegRows - 1) / (4 * kSegRows), (width + 255) / 256), dim3(256), 0, ST, g, ld_g, width, perm, inv, sorted_keys, R_cap, R_dyn, out, ld_out);
+    hipLaunchKernelGGL(segment_sum_rows_kernel, dim3((R_cap + 4 * kSegRows - 1) / (4 * kSegRows), (width + 255) / 256), dim3(256), 0, ST, g, ld_g, width, perm, inv, sorted_keys, R_cap, R_dyn, out, ld_out,
+                       dropping ? dr.mask : (const uint8_t*)nullptr, dropping ? 1.f / (1.f - dr.p) : 1.f, rowinfo);
     return check_launch("lego_segment_sum_rows");
 }
 

@@ -617,7 +617,7 @@ class NamlEngine(_Base):
         if self.dedup_bwd:                           # per-token sums of dH, then the product over the distinct tokens only
             self.kk(pst, "proj_bwd_segsum", "lego_segment_sum_rows", _ptr(self.dH), D, D, _ptr(self.perm), _ptr(self.inv), self.Rc,
                     _ptr(self.keys_sorted), self.cnt(0), _ptr(self.dHu), D, self.Uc, self.cnt(6),
-                    0 if getattr(self, "_dhu_zeroed", False) else 1)
+                    0 if getattr(self, "_dhu_zeroed", False) else 1, None, None)
             self._dhu_zeroed = False
             self.kk(pst, "proj_bwd_weight", "lego_linear_bwd_weight", _ptr(self.dHu), D, _ptr(self.Xu), E0,
                     _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Uc, self.cnt(6), D, E0, None, None)
@@ -728,6 +728,11 @@ class NrmsEngine(_Base):
             self.Hu = self._f(self.Uc, D)
             self.dHu = self._f(self.Uc, D)
             self._uq_epoch = 0
+            # keep bits of the projection's Dropout, drawn with the plan (lego_dropout_mask: the bits the in-kernel draw would take): the
+            # expansion reads a byte per 4 rows x column, and the per-token sums apply the Dropout backward + the token mask while they
+            # read dE -- the separate mask pass over dE (20 us) is gone
+            self.mask_proj = torch.zeros(((self.Rc + 3) // 4) * D + 4, dtype=torch.uint8, device=self.dev)
+        self._slot_mask_step, self._mask_step = {}, -1
         self.X = (self._f(1, self.E0) if self.dedup else self._f(self.Rc, self.E0)) if glove else None
         self.E = self._f(self.Rc, D)
         self.dE = self._f(self.Rc, D)
@@ -749,8 +754,28 @@ class NrmsEngine(_Base):
 
     def enable_plan_slots(self):
         if getattr(self, "_slots", None) is None and self.glove:
-            self._PLAN_FIELDS = NrmsEngine._PLAN_FIELDS + (("Xu", "uniq", "inv", "perm", "keys_sorted") if self.dedup else ("X",))
+            self._PLAN_FIELDS = NrmsEngine._PLAN_FIELDS + (("Xu", "uniq", "inv", "perm", "keys_sorted", "mask_proj") if self.dedup else ("X",))
         return super().enable_plan_slots()
+
+    def prefetch_masks(self, stream, slot):
+        """TrainStep, after plan_on: the projection site's keep bits of the coming training step (engine.step) into the slot"""
+        if self.dedup and self.p_proj > 0.0 and os.environ.get("LEGO_NRMS_MASK_AHEAD", "1") != "0":      # 0: in-kernel draws + a mask pass over dE
+            b = self._slots[slot]
+            call("lego_dropout_mask", ctypes.byref(LegoDropout(self.p_proj, self.seed, SITE_PROJ + 16 * self.step, None)), self.Rc,
+                 _ptr(b["counters"], 0), self.D, _ptr(b["mask_proj"]), ctypes.c_void_p(stream.cuda_stream))
+            self._slot_mask_step[slot] = self.step
+
+    def use_slot(self, s):
+        super().use_slot(s)
+        self._mask_step = self._slot_mask_step.get(s, -1)
+
+    def drop(self, p, site, training):
+        if not training or p <= 0.0:
+            return None
+        d = LegoDropout(p, self.seed, site + 16 * self.step, None)
+        if site == SITE_PROJ and self.dedup and self._mask_step == self.step:
+            d.mask = self.mask_proj.data_ptr()
+        return ctypes.byref(d)
 
     def plan_on(self, stream, slot, cand, hist, hist_len, nb=None):
         super().plan_on(stream, slot, cand, hist, hist_len, nb)
@@ -1054,6 +1079,7 @@ class NrmsEngine(_Base):
              _ptr(self.seq_tok), _ptr(self.seq_len), self.L,
              _ptr(self.counters), _ptr(self.inst_item), _ptr(self.seg_off), _ptr(self.hist_off),
              _ptr(self.rowinfo), _ptr(self.row_tok), _stream())
+        self._mask_step = -1                         # no keep bits were drawn for an un-planned batch
         self._long_lists(self.__dict__, _stream())
 
     _folds_fresh = False
@@ -1169,12 +1195,16 @@ class NrmsEngine(_Base):
         if self.glove:
             E0 = self.E0
             gb = _ptr(G["embedding_vocab_table.glove.linear.bias"])
-            if not fused:                            # the three-pass form (kept as the cross-check of the fused epilogue)
+            dp = self.drop(self.p_proj, SITE_PROJ, training)
+            # with the keep bits at hand (or nothing to drop) the per-token sums mask and rescale dE as they read it
+            in_sums = self.dedup and not fused and (dp is None or self._mask_step == self.step)
+            if not fused and not in_sums:            # the three-pass form (kept as the cross-check of the fused epilogue)
                 call("lego_mask_dropout_rows", _ptr(self.dE), D, self.Rc, self.cnt(0), D, _ptr(self.tokinfo),
-                     self.drop(self.p_proj, SITE_PROJ, training), None if self.dedup else gb, st)
+                     dp, None if self.dedup else gb, st)
             if self.dedup:                           # per-token sums of the masked dE, then the product over the distinct tokens
                 call("lego_segment_sum_rows", _ptr(self.dE), D, D, _ptr(self.perm), _ptr(self.inv), self.Rc, _ptr(self.keys_sorted),
-                     self.cnt(0), _ptr(self.dHu), D, self.Uc, self.cnt(6), 1, st)
+                     self.cnt(0), _ptr(self.dHu), D, self.Uc, self.cnt(6), 1, dp if in_sums else None,
+                     _ptr(self.tokinfo) if in_sums else None, st)
                 if not fused:                        # the bias gradient = column sums of the masked dE = column sums of the per-token sums
                     call("lego_colsum", _ptr(self.dHu), D, self.Uc, self.cnt(6), None, D, gb, st)
                 call("lego_linear_bwd_weight", _ptr(self.dHu), D, _ptr(self.Xu), E0,

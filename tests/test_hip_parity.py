@@ -528,16 +528,24 @@ def test_unique_tokens_expand_and_segment_sum():
     # per-token sums
     gr = torch.randn(R_cap, D, generator=g).to(dev)
     seg = torch.full((Uc, D), 3.0, device=dev)
-    call("lego_segment_sum_rows", P(gr), D, D, P(perm), P(inv), R_cap, None, P(R_dyn), P(seg), D, Uc, P(n_u), 1, None)
+    call("lego_segment_sum_rows", P(gr), D, D, P(perm), P(inv), R_cap, None, P(R_dyn), P(seg), D, Uc, P(n_u), 1, None, None, None)
     seg2 = torch.full((Uc, D), 3.0, device=dev)
     call("lego_zero_rows", P(seg2), D, D, Uc, P(n_u), None)
-    call("lego_segment_sum_rows", P(gr), D, D, P(perm), P(inv), R_cap, P(ks), P(R_dyn), P(seg2), D, Uc, P(n_u), 0, None)
+    call("lego_segment_sum_rows", P(gr), D, D, P(perm), P(inv), R_cap, P(ks), P(R_dyn), P(seg2), D, Uc, P(n_u), 0, None, None, None)
     torch.cuda.synchronize()
     assert float((seg2[:U] - seg[:U]).abs().max()) <= 1e-4 * float(seg[:U].abs().max()) and bool((seg2[U:] == 3.0).all())
     torch.cuda.synchronize()
     want = torch.zeros(U, D, dtype=torch.float64).index_add_(0, want_inv, gr[:R].cpu().double())
     err = (seg[:U].cpu().double() - want).abs().max() / want.abs().max()
     assert float(err) < 1e-5 and bool((seg[U:] == 3.0).all())
+    # ... with the Dropout backward (precomputed keep bits) and a row mask applied as the rows are read
+    seg3 = torch.full((Uc, D), 3.0, device=dev)
+    call("lego_segment_sum_rows", P(gr), D, D, P(perm), P(inv), R_cap, P(ks), P(R_dyn), P(seg3), D, Uc, P(n_u), 1,
+         ctypes.byref(LegoDropout(0.1, 99, 7, mask.data_ptr())), P(live), None)
+    torch.cuda.synchronize()
+    gm = gr[:R].cpu().double() * keep.cpu().double() / 0.9 * (live[:R, None].cpu() != 0)
+    want3 = torch.zeros(U, D, dtype=torch.float64).index_add_(0, want_inv, gm)
+    assert float((seg3[:U].cpu().double() - want3).abs().max() / want3.abs().max()) < 1e-5 and bool((seg3[U:] == 3.0).all())
 
 
 def test_precomputed_dropout_mask_equals_in_kernel_draw():
@@ -1128,6 +1136,7 @@ def test_nrms_projection_once_per_distinct_token(planned, monkeypatch):
         for i, ids in enumerate(batches):
             if planned:
                 eng.plan_on(torch.cuda.current_stream(), i % 2, *ids)
+                eng.prefetch_masks(torch.cuda.current_stream(), i % 2)     # keep bits with the plan: expansion and per-token sums read them
                 eng.use_slot(i % 2)
             scores, loss = eng.forward(*ids, training=True, planned=planned)
             eng.backward(G)
