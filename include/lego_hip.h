@@ -232,6 +232,7 @@ int lego_relu_bwd(float* g, int ldg, const float* ref, int ldr, int rows, int wi
 #define LEGO_MHSA_ALL 0
 #define LEGO_MHSA_SHORT 1
 #define LEGO_MHSA_LONG 2
+#define LEGO_MHSA_ALL_LONG 3 /* every segment through the two-wave (<= 64 rows) instantiation: one launch; for a few hundred pairs (the user side) */
 /* long_list / long_count (nullable, together): the segments of more than 32 rows and their number, from lego_mhsa_long_segments on
  * the same seg_off -- the long-segment launch then gives every (segment, head) pair its own workgroup instead of searching for them */
 int lego_mhsa_long_segments(const int32_t* seg_off, int n_cap, const int32_t* n_dyn, int32_t* list /*[n_cap]*/, int32_t* count /*[1]*/,

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(1024) void mhsa_long_segments_kernel(const int* __r
         for (int base = blockIdx.x; base < n * heads; base += 64 * gridDim.x) {                                   \
             const int w_ = base + l_ * gridDim.x;                                                                 \
             bool lng_ = false;                                                                                    \
-            if (w_ < n * heads) { const int s_ = w_ / heads; lng_ = seg_off[s_ + 1] - seg_off[s_] > 32; }        \
+            if (w_ < n * heads) { const int s_ = w_ / heads; lng_ = seg_off[s_ + 1] - seg_off[s_] > min_len; }   \
             unsigned long long todo = __ballot(lng_);                                                             \
             while (todo != 0ull) {                                                                                \
                 const int w = base + (__ffsll((long long)todo) - 1) * gridDim.x;                                  \
@@ -245,7 +245,7 @@ template <int HD, int JT>
 __global__ __launch_bounds__(64 * JT) __attribute__((amdgpu_waves_per_eu(JT == 1 && HD <= 32 ? 4 : 2))) void mhsa_fwd_kernel(
     const float* __restrict__ qkv, int ldq, const int* __restrict__ seg_off, int n_cap, const int* __restrict__ n_dyn, int D,
     int heads, float* __restrict__ out, int ldo, float* __restrict__ probs, int Lmax, Dropout drop,
-    const int* __restrict__ long_list, const int* __restrict__ long_count) {
+    const int* __restrict__ long_list, const int* __restrict__ long_count, int min_len) {
     const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
     const int t0 = JT == 1 ? 0 : (int)(threadIdx.x >> 6);           // JT == 2: wave t owns query tile t
     LEGO_MHSA_WALK(mhsa_fwd_pair<HD, JT>(qkv, ldq, D, heads, out, ldo, probs, Lmax, drop, h, beg, L, t0, t0 + 1))
@@ -360,7 +360,7 @@ template <int HD, int JT>
 __global__ __launch_bounds__(64 * JT) __attribute__((amdgpu_waves_per_eu(JT == 1 ? (HD == 32 ? 3 : 2) : 1))) void mhsa_bwd_kernel(
     const float* __restrict__ qkv, int ldq, const int* __restrict__ seg_off, int n_cap, const int* __restrict__ n_dyn, int D,
     int heads, const float* __restrict__ gout, int ldgo, const float* __restrict__ probs, int Lmax, float keep_scale,
-    float* __restrict__ gqkv, int ldgq, float* colsum, const int* __restrict__ long_list, const int* __restrict__ long_count) {
+    float* __restrict__ gqkv, int ldgq, float* colsum, const int* __restrict__ long_list, const int* __restrict__ long_count, int min_len) {
     constexpr int LT = 32 * JT;
     __shared__ float Pd[LT * (LT + 1)];                       // dropped-and-rescaled probabilities [key j][query i]
     __shared__ float Ds[LT * (LT + 1)];                       // dS^T [key j][query i]
@@ -412,11 +412,12 @@ extern "C" int lego_mhsa_core_fwd(const float* qkv, int ldq, const int32_t* seg_
     const int hd = D / heads;
     const Dropout dr = to_drop(drop);
     hipStream_t st = (hipStream_t)stream;
+    const bool all_long = part == LEGO_MHSA_ALL_LONG && Lmax > 32;   // every segment through the two-wave instantiation: ONE launch
 #define LAUNCH(HD) do { \
-        if (part != LEGO_MHSA_LONG) \
-            hipLaunchKernelGGL((mhsa_fwd_kernel<HD, 1>), dim3(short_grid(n_cap, heads)), dim3(64), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, out, ldo, probs, Lmax, dr, nullptr, nullptr); \
+        if (part != LEGO_MHSA_LONG && !all_long) \
+            hipLaunchKernelGGL((mhsa_fwd_kernel<HD, 1>), dim3(short_grid(n_cap, heads)), dim3(64), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, out, ldo, probs, Lmax, dr, nullptr, nullptr, 32); \
         if (Lmax > 32 && part != LEGO_MHSA_SHORT) \
-            hipLaunchKernelGGL((mhsa_fwd_kernel<HD, 2>), dim3(long_grid(n_cap, heads)), dim3(128), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, out, ldo, probs, Lmax, dr, long_list, long_count); \
+            hipLaunchKernelGGL((mhsa_fwd_kernel<HD, 2>), dim3(long_grid(n_cap, heads)), dim3(128), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, out, ldo, probs, Lmax, dr, all_long ? nullptr : long_list, all_long ? nullptr : long_count, all_long ? 0 : 32); \
     } while (0)
     switch (hd) {
         case 8: LAUNCH(8); break;
@@ -442,11 +443,12 @@ extern "C" int lego_mhsa_core_bwd(const float* qkv, int ldq, const int32_t* seg_
     const float ks = dr.p > 0.f ? 1.f / (1.f - dr.p) : 1.f;     // the keep / drop decision itself is the sign of the saved probability
     (void)rows_cap;
     hipStream_t st = (hipStream_t)stream;
+    const bool all_long = part == LEGO_MHSA_ALL_LONG && Lmax > 32;
 #define LAUNCH(HD) do { \
-        if (part != LEGO_MHSA_LONG) \
-            hipLaunchKernelGGL((mhsa_bwd_kernel<HD, 1>), dim3(short_grid(n_cap, heads)), dim3(64), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, gout, ldgo, probs, Lmax, ks, gqkv, ldgq, colsum, nullptr, nullptr); \
+        if (part != LEGO_MHSA_LONG && !all_long) \
+            hipLaunchKernelGGL((mhsa_bwd_kernel<HD, 1>), dim3(short_grid(n_cap, heads)), dim3(64), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, gout, ldgo, probs, Lmax, ks, gqkv, ldgq, colsum, nullptr, nullptr, 32); \
         if (Lmax > 32 && part != LEGO_MHSA_SHORT) \
-            hipLaunchKernelGGL((mhsa_bwd_kernel<HD, 2>), dim3(long_grid(n_cap, heads)), dim3(128), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, gout, ldgo, probs, Lmax, ks, gqkv, ldgq, colsum, long_list, long_count); \
+            hipLaunchKernelGGL((mhsa_bwd_kernel<HD, 2>), dim3(long_grid(n_cap, heads)), dim3(128), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, gout, ldgo, probs, Lmax, ks, gqkv, ldgq, colsum, all_long ? nullptr : long_list, all_long ? nullptr : long_count, all_long ? 0 : 32); \
     } while (0)
     switch (hd) {
         case 8: LAUNCH(8); break;

@@ -831,7 +831,7 @@ class NrmsEngine(_Base):
                 None, None, None, None)
         core = ("lego_mhsa_core_fwd", _ptr(ws["qkv"]), 3 * D, _ptr(seg_off), n_cap, n_dyn, D, self.heads,
                 _ptr(ws["o"]), D, _ptr(ws["probs"]), ws["Lmax"], self.drop(self.p_att, site, training), rows)
-        self.kk(m, "mhsa_core_fwd_" + tg, *core, 0, *self._long(pre, ws))
+        self.kk(m, "mhsa_core_fwd_" + tg, *core, *self._part(pre, ws))
         if self.fold and self._fold_ev is not None:          # the folded weights come from the side stream (_prepare_folds)
             m.wait_event(self._fold_ev)
             self._fold_ev = None
@@ -863,6 +863,16 @@ class NrmsEngine(_Base):
              _ptr(out), D, _ptr(ws["wrow"]), st)
 
     _fold_ev = None
+
+    # user side: a few hundred (user, head) pairs, a fifth of them longer than 32 clicks -- ONE launch of the two-wave (<= 64 rows)
+    # instantiation for all of them instead of a short-segment and a long-segment launch (LEGO_MHSA_ALL_LONG; A/B: LEGO_NRMS_USER_ONE=0)
+    user_one = os.environ.get("LEGO_NRMS_USER_ONE", "1") != "0"
+
+    def _part(self, pre, ws):
+        """(part, long_list, long_count) arguments of lego_mhsa_core_*"""
+        if pre == "user_op." and self.user_one and ws["Lmax"] > 32:
+            return 3, None, None
+        return (0,) + self._long(pre, ws)
 
     def _long(self, pre, ws):
         """(list, count) of the operator's segments of more than 32 rows, or (None, None) when it cannot have any"""
@@ -928,7 +938,7 @@ class NrmsEngine(_Base):
                 n_cap, n_dyn, D, self.heads, _ptr(ws["d_o"]), D, _ptr(ws["probs"]), ws["Lmax"],
                 self.drop(self.p_att, site, training), rows, _ptr(ws["d_qkv"]), 3 * D,
                 _ptr(G[pre + "multi_head_attention.in_proj_bias"]))      # bias gradient = column sums of d_qkv, fused
-        self.kk(m, "mhsa_core_bwd_" + pre[:4], *core, 0, *self._long(pre, ws))
+        self.kk(m, "mhsa_core_bwd_" + pre[:4], *core, *self._part(pre, ws))
         if sw is not m:
             ev[1].record(m)
 

@@ -973,7 +973,7 @@ def test_trainable_token_table_full_vocabulary():
         assert float((a - b).norm()) <= max(5e-2 * float((b - p0).norm()), floor) + 1e-7, k
 
 
-@pytest.mark.parametrize("listed", [False, True])
+@pytest.mark.parametrize("listed", [False, True, "one_launch"])
 @pytest.mark.parametrize("hd,heads,p", [(32, 8, 0.0), (32, 8, 0.2), (16, 4, 0.1), (8, 2, 0.0), (64, 2, 0.3)])
 def test_mhsa_core_ragged_segments_with_dropout(hd, heads, p, listed):
     """lego_mhsa_core_fwd / _bwd against float64 autograd on ragged segments of 1..64 rows (both tile instantiations, empty segments,
@@ -994,18 +994,19 @@ def test_mhsa_core_ragged_segments_with_dropout(hd, heads, p, listed):
     probs = torch.zeros(R, heads, Lmax, device=dev)
     drop = (p, 99, 3) if p > 0 else None
     ll = lc = None                                   # `listed`: the long segments from lego_mhsa_long_segments (one workgroup per pair)
-    if listed:
+    part = 3 if listed == "one_launch" else 0        # LEGO_MHSA_ALL_LONG: every segment through the two-wave instantiation
+    if listed is True:
         ll, lc = torch.full((n,), -1, dtype=torch.int32, device=dev), torch.full((1,), -1, dtype=torch.int32, device=dev)
         call("lego_mhsa_long_segments", _ptr(seg), n, None, _ptr(ll), _ptr(lc), _stream())
         torch.cuda.synchronize()
         want_long = [i for i, L in enumerate(lens) if L > 32]
         assert int(lc) == len(want_long) and sorted(ll[:int(lc)].cpu().tolist()) == want_long
-    call("lego_mhsa_core_fwd", _ptr(qkv), 3 * D, _ptr(seg), n, None, D, heads, _ptr(out), D, _ptr(probs), Lmax, _drop(drop), R, 0,
+    call("lego_mhsa_core_fwd", _ptr(qkv), 3 * D, _ptr(seg), n, None, D, heads, _ptr(out), D, _ptr(probs), Lmax, _drop(drop), R, part,
          _ptr(ll), _ptr(lc), _stream())
     gqkv = torch.full((R, 3 * D), float("nan"), device=dev)
     colsum = torch.zeros(3 * D, device=dev)
     call("lego_mhsa_core_bwd", _ptr(qkv), 3 * D, _ptr(seg), n, None, D, heads, _ptr(go), D, _ptr(probs), Lmax, _drop(drop), R,
-         _ptr(gqkv), 3 * D, _ptr(colsum), 0, _ptr(ll), _ptr(lc), _stream())
+         _ptr(gqkv), 3 * D, _ptr(colsum), part, _ptr(ll), _ptr(lc), _stream())
     torch.cuda.synchronize()
     pr, q64, g64 = probs.cpu().double().reshape(-1), qkv.cpu().double(), go.cpu().double()
     kept = total = 0
