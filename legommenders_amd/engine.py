@@ -754,7 +754,7 @@ class NrmsEngine(_Base):
 
     def enable_plan_slots(self):
         if getattr(self, "_slots", None) is None and self.glove:
-            self._PLAN_FIELDS = NrmsEngine._PLAN_FIELDS + (("Xu", "uniq", "inv", "perm", "keys_sorted", "mask_proj") if self.dedup else ("X",))
+            self._PLAN_FIELDS = NrmsEngine._PLAN_FIELDS + (("Xu", "uniq", "inv", "perm", "keys_sorted", "mask_proj", "dHu") if self.dedup else ("X",))
         return super().enable_plan_slots()
 
     def prefetch_masks(self, stream, slot):
@@ -768,6 +768,9 @@ class NrmsEngine(_Base):
     def use_slot(self, s):
         super().use_slot(s)
         self._mask_step = self._slot_mask_step.get(s, -1)
+        self._dhu_zeroed = self.dedup                # cleared by plan_on (_decode_gather)
+
+    _dhu_zeroed = False
 
     def drop(self, p, site, training):
         if not training or p <= 0.0:
@@ -802,6 +805,8 @@ class NrmsEngine(_Base):
                  self.Uc, _ptr(b["counters"], 6), _ptr(b["Xu"]), E0, 0, st)
             call("lego_sort_rows", _ptr(self.uq_keys), self.Rc, _ptr(b["keys_sorted"]), _ptr(b["perm"]), _ptr(self.uq_temp),
                  self.uq_temp.numel(), st)
+            if b is not self.__dict__:               # a plan slot: its per-token sums start from rows cleared here, off the main stream
+                call("lego_zero_rows", _ptr(b["dHu"]), self.D, self.D, self.Uc, _ptr(b["counters"], 6), st)
         elif self.glove:
             E0 = self.E0
             call("lego_gather_rows", _ptr(self.P["embedding_vocab_table.glove.embedding.weight"]), E0, E0, _ptr(b["idx_tok"]),
@@ -1090,6 +1095,7 @@ class NrmsEngine(_Base):
              _ptr(self.counters), _ptr(self.inst_item), _ptr(self.seg_off), _ptr(self.hist_off),
              _ptr(self.rowinfo), _ptr(self.row_tok), _stream())
         self._mask_step = -1                         # no keep bits were drawn for an un-planned batch
+        self._dhu_zeroed = False
         self._long_lists(self.__dict__, _stream())
 
     _folds_fresh = False
@@ -1213,8 +1219,9 @@ class NrmsEngine(_Base):
                      dp, None if self.dedup else gb, st)
             if self.dedup:                           # per-token sums of the masked dE, then the product over the distinct tokens
                 call("lego_segment_sum_rows", _ptr(self.dE), D, D, _ptr(self.perm), _ptr(self.inv), self.Rc, _ptr(self.keys_sorted),
-                     self.cnt(0), _ptr(self.dHu), D, self.Uc, self.cnt(6), 1, dp if in_sums else None,
+                     self.cnt(0), _ptr(self.dHu), D, self.Uc, self.cnt(6), 0 if self._dhu_zeroed else 1, dp if in_sums else None,
                      _ptr(self.tokinfo) if in_sums else None, st)
+                self._dhu_zeroed = False
                 if not fused:                        # the bias gradient = column sums of the masked dE = column sums of the per-token sums
                     call("lego_colsum", _ptr(self.dHu), D, self.Uc, self.cnt(6), None, D, gb, st)
                 call("lego_linear_bwd_weight", _ptr(self.dHu), D, _ptr(self.Xu), E0,
