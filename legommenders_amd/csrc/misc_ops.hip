@@ -513,10 +513,11 @@ __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float* __re
     const bool in = c < width;
     // lanes 0 .. kSegRows + 1: position p0 - 1 + lane (one before and one past the chunk, for the two boundary decisions)
     const int pp = p0 - 1 + lane;
-    int my_row = 0, my_u = -1;
+    int my_row = 0, my_u = -1, my_live = 1;
     if (lane < kSegRows + 2 && pp >= 0 && pp < R) {              // sorted_keys (the sort's key output) saves the dependent inv[] load
         my_row = perm[pp];
         my_u = sorted_keys != nullptr ? sorted_keys[pp] : inv[my_row];
+        if (rowinfo != nullptr) my_live = (rowinfo[my_row] & RI_LIVE) != 0;      // ONE dependent round trip for the chunk's 32 rows
     }
     const int u_before = __shfl(my_u, 0, 64);                     // -1 when p0 == 0
     int cur = __shfl(my_u, 1, 64);
@@ -530,8 +531,8 @@ __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float* __re
             const int i = min(b0 + j, n - 1);
             const int row = __shfl(my_row, 1 + i, 64);
             uu[j] = __shfl(my_u, 1 + i, 64);
-            bool take = b0 + j < n && in;
-            if (rowinfo != nullptr && (rowinfo[row] & RI_LIVE) == 0) take = false;          // wave-uniform: a masked row adds nothing
+            const int live = __shfl(my_live, 1 + i, 64);                // by every lane: the source lane may have `in` == false
+            const bool take = b0 + j < n && in && live != 0;            // a masked row adds nothing
             v[j] = take ? *reinterpret_cast<const f32x4*>(g + (size_t)row * ld_g + c) : f32x4{0.f, 0.f, 0.f, 0.f};
             if (keep_mask != nullptr && take) {      // Dropout backward of the row: byte [(row / 4) * width + col], bit row % 4
                 const uint32_t kw = *reinterpret_cast<const uint32_t*>(keep_mask + (uint64_t)(row >> 2) * (uint64_t)width + (uint64_t)c);
