@@ -135,7 +135,7 @@ __global__ __launch_bounds__(ONE_THREADS) void oneshot_kernel(GemmDims dims, ALo
 // on a side stream it cannot START while a row-strip / Winograd product (122 KB of LDS, 2 x 212-255 of a SIMD's 512 registers) holds
 // the CU -- a rocprofv3 timeline of the NAML step shows two 11 us launches taking 90 and 69 us of the side stream, which then ends
 // after the main stream.  A single wave with a few registers fits beside anything.
-template <bool B_MC, class ALoad, class BLoad, class Epi>
+template <bool B_MC, class ALoad, class BLoad, class Epi, int U = 2>
 __global__ __launch_bounds__(64) void light_kernel(GemmDims dims, ALoad la, BLoad lb, Epi epi) {
     int M = dims.M;
     if (dims.m_dyn != nullptr) M = min(M, *dims.m_dyn);
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64) void light_kernel(GemmDims dims, ALoad la, BLoa
     lb.tile(0);
     const typename ALoad::Row ra = la.row(m0 + l16);
     f32x4 acc[1][2] = {{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}};
-    constexpr int U = 2;                                     // k groups of 16 whose loads are in flight together
+    // U: k groups of 16 whose loads are in flight together
     for (int k0 = 0; k0 < K; k0 += 16 * U) {
         f32x4 fa[U], fb[U][2];
 #pragma unroll

@@ -394,7 +394,13 @@ template <bool B_MC, class EK, class AL, class BL>
 static int launch_light(const GemmDims& d, const AL& a, const BL& b, const Epi& e0, hipStream_t st, const char* what) {
     EK e;
     static_cast<EpiArgs&>(e) = e0;
-    hipLaunchKernelGGL((light_kernel<B_MC, AL, BL, EK>), dim3((d.M + 15) / 16, (d.N + 31) / 32), dim3(64), 0, st, d, a, b, e);
+    // k groups of 16 in flight per wave: 4 (84-92 VGPRs; a K = 256 product is four dependent round trips) against 2 (56-68 VGPRs, eight):
+    // NAML 0.6297 -> 0.6244 ms, NRMS 1.0363 -> 1.0328 ms (three alternating same-box runs each; 8 groups, 136 VGPRs: no further gain).
+    // LEGO_LIGHT_U=2 keeps the shallower form (A/B).
+    static int u = -1;
+    if (u < 0) { const char* v = getenv("LEGO_LIGHT_U"); u = (v != nullptr && v[0] == '2') ? 2 : 4; }
+    if (u == 2) hipLaunchKernelGGL((light_kernel<B_MC, AL, BL, EK, 2>), dim3((d.M + 15) / 16, (d.N + 31) / 32), dim3(64), 0, st, d, a, b, e);
+    else hipLaunchKernelGGL((light_kernel<B_MC, AL, BL, EK, 4>), dim3((d.M + 15) / 16, (d.N + 31) / 32), dim3(64), 0, st, d, a, b, e);
     return check_launch(what);
 }
 
