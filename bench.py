@@ -19,6 +19,8 @@ steps / ms so the driver's wall clock still bounds them):
   roofline_gather    the GloVe row gather: `frac_in_step` = in-step duration on the prefetch stream (HIP events there,
                      overlapped with the previous step's user-side chain); `frac` = back-to-back standalone launches
                      (cache-assisted: most rows then hit the Infinity Cache)
+  roofline_step      the whole step against the fp32 matrix peak: algorithmic flops of its big products / step time (`frac`), and the
+                     flops the kernels issue (projection per distinct token, Winograd 2/3) the same way (`issued_frac`)
   long_run           2000 steps of the same configuration when --steps is smaller (a 20-step window is 14 ms)
   secondary          NRMS config 3 (with its dominant-kernel roofline), the worst-case dense NAML world (every history
                      50, every title 30 tokens) and a world with MIND-like length statistics are NOT the metric; they are printed so that the number's dependence
@@ -356,7 +358,7 @@ def main():
                     "conv3_fwd": 2.0 * rows * D * 3 * D,
                     "conv3_bwd_data": 2.0 * rows * D * 3 * D,
                     "conv3_bwd_weight": 2.0 * rows * D * 3 * D,
-                    "proj_bwd_weight": 2.0 * rows * D * E0,
+                    "proj_bwd_weight": 2.0 * (rows if (uniq is None or not getattr(eng, "dedup_bwd", False)) else uniq) * D * E0,
                     "additive_fwd_item": 2.0 * yrows * D * 256,
                     "additive_bwd_data": 2.0 * rows * D * 256,
                     "additive_bwd_weight_item": 2.0 * yrows * D * 256}
@@ -530,7 +532,7 @@ def main():
                    "projection": ("once per DISTINCT token of the batch, expanded to the token rows (exact: the frozen-table "
                                   "projection depends on the token id alone); LEGO_DEDUP=0 projects row by row") if dedup else "row by row"},
         "final_loss": round(final_loss, 5),
-        "roofline": roofline, "roofline_gather": roofline_gather,
+        "roofline": roofline, "roofline_gather": roofline_gather, "roofline_step": step_roofline(args.model, flops, dt / args.steps, rows_per_launch, D, E0, wino),
         "kernels": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kern.items()},
     }
     out.update(extra)
@@ -544,6 +546,23 @@ def main():
     _json_out.flush()
     if dist_on:
         torch.distributed.destroy_process_group()
+
+
+def step_roofline(model, flops, step_s, rows, D, E0, wino):
+    """the whole step against the fp32 matrix peak: ALGORITHMIC flops of its products (every token row projected, the
+    direct conv's 2*3*D*D per row) over the measured step time, and beside it the flops the kernels ISSUE (projection once per
+    distinct token, Winograd F(2,3) = 2/3 of the direct conv)"""
+    if not flops or model != "naml":             # (the NRMS table prices forward products only)
+        return None
+    alg = dict(flops)
+    alg["proj_fwd"] = alg["proj_bwd_weight"] = 2.0 * rows * D * E0
+    issued = {k: v * (WINO_ISSUE if k in wino else 1.0) for k, v in flops.items()}
+    a, i = sum(alg.values()), sum(issued.values())
+    return {"bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_F32_MFMA_TFLOPS,
+            "achieved": round(a / step_s / 1e12, 2), "frac": round(a / step_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "algorithmic_flops_per_step": a, "issued_flops_per_step": i, "issued_frac": round(i / step_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "products": sorted(alg), "note": "the big products only (the small user-side / category products add < 2 %); frac = algorithmic "
+            "flops / step time / peak, issued_frac = what the matrix pipe is asked to do"}
 
 
 def nrms_flops(rows, D, E0):
