@@ -709,9 +709,11 @@ class NrmsEngine(_Base):
         # mask; its weight gradient comes from per-token sums of dE (NamlEngine has the same scheme).  The [SEP] / category positions
         # (row_tok < 0) fall into group 0 of the inverse map: the expansion writes them as zeros (tokinfo's live bit) and their dE
         # rows are zero when the sums are formed (lego_mask_dropout_rows runs first).  LEGO_NRMS_DEDUP=0: row-by-row projection.
-        self.dedup = bool(glove) and self.Rc > 0 and os.environ.get("LEGO_NRMS_DEDUP", "1") != "0"
+        # Trainable table (embed/null): the same per-token sums feed the table's gradient -- the ~4.5 k DISTINCT rows of a batch are added
+        # once each instead of 30.7 k sequence rows through float atomics (a Zipf head makes them queue on a few rows: 125 us per step).
+        self.dedup = self.Rc > 0 and os.environ.get("LEGO_NRMS_DEDUP", "1") != "0"
         if self.dedup:
-            V = P["embedding_vocab_table.glove.embedding.weight"].shape[0]
+            V = P["embedding_vocab_table.glove.embedding.weight" if glove else "embedding_vocab_table.glove.weight"].shape[0]
             self.V, self.Uc = V, min(self.Rc, V)
             self.uq_stamp = torch.zeros(V, **i32)
             self.uq_rank = torch.zeros(V, **i32)
@@ -724,14 +726,14 @@ class NrmsEngine(_Base):
             self.uq_keys = torch.zeros(self.Rc, **i32)
             self.keys_sorted = torch.zeros(self.Rc, **i32)
             self.uq_temp = torch.zeros(max(int(_lib.lib().lego_sort_rows_temp_bytes(self.Rc)), 256), dtype=torch.uint8, device=self.dev)
-            self.Xu = self._f(self.Uc, self.E0)
-            self.Hu = self._f(self.Uc, D)
+            self.Xu = self._f(self.Uc if glove else 1, self.E0)
+            self.Hu = self._f(self.Uc if glove else 1, D)
             self.dHu = self._f(self.Uc, D)
             self._uq_epoch = 0
             # keep bits of the projection's Dropout, drawn with the plan (lego_dropout_mask: the bits the in-kernel draw would take): the
             # expansion reads a byte per 4 rows x column, and the per-token sums apply the Dropout backward + the token mask while they
             # read dE -- the separate mask pass over dE (20 us) is gone
-            self.mask_proj = torch.zeros(((self.Rc + 3) // 4) * D + 4, dtype=torch.uint8, device=self.dev)
+            self.mask_proj = torch.zeros((((self.Rc + 3) // 4) * D if glove else 0) + 4, dtype=torch.uint8, device=self.dev)
         self._slot_mask_step, self._mask_step = {}, -1
         self.X = (self._f(1, self.E0) if self.dedup else self._f(self.Rc, self.E0)) if glove else None
         self.E = self._f(self.Rc, D)
@@ -753,13 +755,14 @@ class NrmsEngine(_Base):
     _PLAN_FIELDS = _Base._PLAN_FIELDS + ("idx_tok", "idx_spec", "idx_cat", "tokinfo", "long_items", "long_users", "long_cnt")
 
     def enable_plan_slots(self):
-        if getattr(self, "_slots", None) is None and self.glove:
-            self._PLAN_FIELDS = NrmsEngine._PLAN_FIELDS + (("Xu", "uniq", "inv", "perm", "keys_sorted", "mask_proj", "dHu") if self.dedup else ("X",))
+        if getattr(self, "_slots", None) is None and (self.glove or self.dedup):
+            self._PLAN_FIELDS = NrmsEngine._PLAN_FIELDS + (
+                (("Xu", "mask_proj") if self.glove else ()) + ("uniq", "inv", "perm", "keys_sorted", "dHu") if self.dedup else ("X",))
         return super().enable_plan_slots()
 
     def prefetch_masks(self, stream, slot):
         """TrainStep, after plan_on: the projection site's keep bits of the coming training step (engine.step) into the slot"""
-        if self.dedup and self.p_proj > 0.0 and os.environ.get("LEGO_NRMS_MASK_AHEAD", "1") != "0":      # 0: in-kernel draws + a mask pass over dE
+        if self.dedup and self.glove and self.p_proj > 0.0 and os.environ.get("LEGO_NRMS_MASK_AHEAD", "1") != "0":      # 0: in-kernel draws + a mask pass over dE
             b = self._slots[slot]
             call("lego_dropout_mask", ctypes.byref(LegoDropout(self.p_proj, self.seed, SITE_PROJ + 16 * self.step, None)), self.Rc,
                  _ptr(b["counters"], 0), self.D, _ptr(b["mask_proj"]), ctypes.c_void_p(stream.cuda_stream))
@@ -795,14 +798,15 @@ class NrmsEngine(_Base):
     def _decode_gather(self, b, st):
         call("lego_nrms_decode_rows", _ptr(b["row_tok"]), self.Rc, _ptr(b["counters"], 0), _ptr(b["idx_tok"]), _ptr(b["idx_spec"]),
              _ptr(b["idx_cat"]), _ptr(b["tokinfo"]), st)
-        if self.glove and self.dedup:
+        if self.dedup:
             E0 = self.E0
             self._uq_epoch = self._uq_epoch % 0x7FFFFFF0 + 1
             call("lego_unique_tokens", _ptr(b["row_tok"]), self.Rc, _ptr(b["counters"], 0), self.V, _ptr(self.uq_stamp), self._uq_epoch,
                  _ptr(self.uq_rank), _ptr(self.uq_bsum), _ptr(b["uniq"]), _ptr(b["inv"]), _ptr(self.uq_cnt), _ptr(self.uq_start), None,
                  _ptr(self.uq_keys), _ptr(b["counters"], 6), st)
-            call("lego_gather_rows", _ptr(self.P["embedding_vocab_table.glove.embedding.weight"]), E0, E0, _ptr(b["uniq"]),
-                 self.Uc, _ptr(b["counters"], 6), _ptr(b["Xu"]), E0, 0, st)
+            if self.glove:
+                call("lego_gather_rows", _ptr(self.P["embedding_vocab_table.glove.embedding.weight"]), E0, E0, _ptr(b["uniq"]),
+                     self.Uc, _ptr(b["counters"], 6), _ptr(b["Xu"]), E0, 0, st)
             call("lego_sort_rows", _ptr(self.uq_keys), self.Rc, _ptr(b["keys_sorted"]), _ptr(b["perm"]), _ptr(self.uq_temp),
                  self.uq_temp.numel(), st)
             if b is not self.__dict__:               # a plan slot: its per-token sums start from rows cleared here, off the main stream
@@ -1240,9 +1244,17 @@ class NrmsEngine(_Base):
             V = G["embedding_vocab_table.glove.weight"].shape[0]
             if self.touched_rows is not None:       # TrainStep: rows that have ever had a gradient (row-skipping dense Adam)
                 call("lego_mark_rows", _ptr(self.idx_tok), self.Rc, self.cnt(0), V, _ptr(self.touched_rows), st)
+            if self.dedup:                           # per-token sums of dE (the [SEP] / category positions masked out) ...
+                call("lego_segment_sum_rows", _ptr(self.dE), D, D, _ptr(self.perm), _ptr(self.inv), self.Rc, _ptr(self.keys_sorted),
+                     self.cnt(0), _ptr(self.dHu), D, self.Uc, self.cnt(6), 0 if self._dhu_zeroed else 1, None, _ptr(self.tokinfo), st)
+                self._dhu_zeroed = False
             if self.grad_hooks is None:
-                call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.glove.weight"]), D, D, V, _ptr(self.idx_tok),
-                     self.Rc, self.cnt(0), _ptr(self.dE), D, st)
+                if self.dedup:                       # ... added to the DISTINCT table rows: no two rows of this launch share a destination
+                    call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.glove.weight"]), D, D, V, _ptr(self.uniq),
+                         self.Uc, self.cnt(6), _ptr(self.dHu), D, st)
+                else:
+                    call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.glove.weight"]), D, D, V, _ptr(self.idx_tok),
+                         self.Rc, self.cnt(0), _ptr(self.dE), D, st)
         for side in self._deferred:                  # the item operator's side-stream launches, behind its whole main chain
             side()
         self._deferred = ()
@@ -1257,7 +1269,11 @@ class NrmsEngine(_Base):
             dense_ready()
             for lo in range(0, V, per):
                 hi = min(V, lo + per)
-                call("lego_scatter_add_rows_range", _ptr(G["embedding_vocab_table.glove.weight"]), D, D, _ptr(self.idx_tok),
-                     self.Rc, self.cnt(0), _ptr(self.dE), D, lo, hi, st)
+                if self.dedup:
+                    call("lego_scatter_add_rows_range", _ptr(G["embedding_vocab_table.glove.weight"]), D, D, _ptr(self.uniq),
+                         self.Uc, self.cnt(6), _ptr(self.dHu), D, lo, hi, st)
+                else:
+                    call("lego_scatter_add_rows_range", _ptr(G["embedding_vocab_table.glove.weight"]), D, D, _ptr(self.idx_tok),
+                         self.Rc, self.cnt(0), _ptr(self.dE), D, lo, hi, st)
                 bucket_ready(lo, hi)
         self.step = step_save

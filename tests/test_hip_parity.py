@@ -1102,18 +1102,20 @@ def test_nrms_folded_linear_equals_unfolded(glove):
             assert d <= 2e-5 * gmax + 2e-5 * float(g0[k].abs().max()), (level, k, d, gmax)
 
 
+@pytest.mark.parametrize("glove", [True, False])
 @pytest.mark.parametrize("planned", [False, True])
-def test_nrms_projection_once_per_distinct_token(planned, monkeypatch):
+def test_nrms_projection_once_per_distinct_token(planned, glove, monkeypatch):
     """NrmsEngine (GloVe variant): Dropout(Linear(glove[tok])) computed once per DISTINCT token of the batch and expanded to the
     sequence rows (per-row dropout draws, [SEP] / category positions written as zeros), weight gradient from per-token sums of dE,
     against the row-by-row projection (LEGO_NRMS_DEDUP=0) with dropout ON: same draws, so the same scores, loss and gradients up to
-    fp32 summation order -- two training steps, un-planned and through the plan slots TrainStep uses."""
+    fp32 summation order -- two training steps, un-planned and through the plan slots TrainStep uses.  `glove=False`: the trainable
+    table (embed/null), whose gradient takes the same per-token sums and is then added to the DISTINCT table rows."""
     from legommenders_amd import engine as E
     from legommenders_amd.synthetic import glove_like, init_nrms_params, make_world
     dev = _dev()
     D, B, C, S, V = 128, 16, 5, 50, 3000
     w = make_world(seed=9, n_items=700, n_users=300, n_rows=400, V=V)
-    P = init_nrms_params(D=D, V=V, n_cat=w["n_cat"], heads=8, glove=glove_like(V, 300, seed=4, device=dev), seed=6)
+    P = init_nrms_params(D=D, V=V, n_cat=w["n_cat"], heads=8, glove=glove_like(V, 300, seed=4, device=dev) if glove else None, seed=6)
     for k in P:
         if k.endswith("bias"):
             P[k] = torch.randn_like(P[k]) * 0.1
@@ -1128,7 +1130,7 @@ def test_nrms_projection_once_per_distinct_token(planned, monkeypatch):
     out = {}
     for dedup in ("0", "1"):
         monkeypatch.setenv("LEGO_NRMS_DEDUP", dedup)
-        eng = E.NrmsEngine(Pd, tb, B, C, S, heads=8, glove=True, seed=77)
+        eng = E.NrmsEngine(Pd, tb, B, C, S, heads=8, glove=glove, seed=77)
         assert eng.dedup == (dedup == "1")
         G = eng.grads_like()
         if planned:
@@ -1152,7 +1154,7 @@ def test_nrms_projection_once_per_distinct_token(planned, monkeypatch):
     for k in g0:
         d = float((g1[k] - g0[k]).abs().max())
         assert d <= 2e-5 * gmax + 2e-5 * float(g0[k].abs().max()), (k, d, gmax)
-    assert float(g0["embedding_vocab_table.glove.linear.weight"].abs().max()) > 0
+    assert float(g0["embedding_vocab_table.glove.linear.weight" if glove else "embedding_vocab_table.glove.weight"].abs().max()) > 0
 
 
 @pytest.mark.parametrize("D,A", [(256, 256), (96, 40), (32, 0)])
