@@ -372,6 +372,8 @@ def main():
     price(kern, flops_for(rows_tab, inst_tab, uniq_tab if dedup else None), wino)
     flops = flops_for(rows_per_launch, inst_per_launch, uniq_per_launch if dedup else None)
     price(kern_in, flops, wino)
+    if args.model == "nrms":
+        price_hbm(kern, nrms_core_bytes(rows_tab, D))
     for k in kern:
         kern[k]["timed"] = "8 steps after the timed region, every tagged kernel bracketed"
     for k, v in kern_in.items():                   # the kernels bracketed inside the timed region keep those figures
@@ -449,6 +451,8 @@ def main():
         k2 = kernel_table(tm2)
         f2 = nrms_flops(r2, D, E0) if other == "nrms" else {}
         price(k2, f2, ())
+        if other == "nrms":
+            price_hbm(k2, nrms_core_bytes(r2, D))      # the attention core against the HBM roof, not the matrix one
         sec[f"{other}_hidden{D}_bs{B}"] = {
             "workload": f"MIND-small-shaped {other.upper()} hidden={D} bs={B} GloVe, full train step (BASELINE config 3)",
             "steps": 60, "warmup": 10, "ms_per_step": round(d2 / 60 * 1e3, 4), "value": round(B * 60 / d2, 1), "unit": "impressions/s",
@@ -570,8 +574,22 @@ def nrms_flops(rows, D, E0):
     return {"qkv_fwd_item": 2.0 * rows * D * 3 * D, "out_proj_fwd_item": 2.0 * rows * D * D, "linear_fwd_item": 2.0 * rows * D * D,
             "outlin_fwd_item": 2.0 * rows * D * D,       # out-projection and Linear folded into one product (engine.py, fold_linear)
             "additive_fwd_item": 2.0 * rows * D * 256,      # fold level 2: the only product over the rows between the core and the pool
-            # attention core: QK^T and PV, 2 * L * hd MACs per (row, head) with L ~ the segment length (<= 33): priced with L = 21
-            "mhsa_core_fwd_item": 2.0 * rows * 2 * 21 * D}
+            }
+
+
+def nrms_core_bytes(rows, D, heads=8, Lbar=21):
+    """algorithmic HBM bytes per launch of the attention core (it is memory-bound: 2 * L * hd MACs per row and head against 12 KB of
+    operands per (segment, head)): forward reads the Q / K / V rows and writes the output rows and the saved probabilities
+    (~Lbar per row and head); backward reads Q / K / V, d(out) and the probabilities and writes d(qkv)"""
+    qkv, o, pr = rows * 3 * D * 4.0, rows * D * 4.0, rows * heads * Lbar * 4.0
+    return {"mhsa_core_fwd_item": qkv + o + pr, "mhsa_core_bwd_item": qkv + o + pr + qkv}
+
+
+def price_hbm(kern, nbytes):
+    for tag, b in nbytes.items():
+        if tag in kern and kern[tag]["avg_ms"] > 0:
+            gbs = b / (kern[tag]["avg_ms"] * 1e-3) / 1e9
+            kern[tag].update({"bound": "hbm", "gb_per_s": gbs, "frac_of_hbm_peak": gbs / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": b})
 
 
 def price(kern, flops, wino):
