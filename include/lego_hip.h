@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LEGO_ABI_VERSION 4
+#define LEGO_ABI_VERSION 5
 #define LEGO_COUNTERS 8
 
 const char* lego_last_error(void);
@@ -237,12 +237,18 @@ int lego_relu_bwd(float* g, int ldg, const float* ref, int ldr, int rows, int wi
  * the same seg_off -- the long-segment launch then gives every (segment, head) pair its own workgroup instead of searching for them */
 int lego_mhsa_long_segments(const int32_t* seg_off, int n_cap, const int32_t* n_dyn, int32_t* list /*[n_cap]*/, int32_t* count /*[1]*/,
                             void* stream);
+/* ABI v5: two ways to hand the softmax to the backward pass, chosen by which pointer is given (both may be; the backward pass then
+ * uses `probs`):
+ *   lse   [rows, heads]        log-sum-exp of every query row's scaled scores; the backward pass recomputes S = Q K^T / sqrt(hd),
+ *                              p = exp(s - lse) and redraws the dropout keep bits from `drop` (the SAME p / seed / site as the forward call)
+ *   probs [rows, heads, Lmax]  the probabilities themselves: tile of (segment, head) at ((beg * heads + h * L) * Lmax),
+ *                              [key j][query i], sign bit set = dropped; read back by the backward pass (no random numbers there). */
 int lego_mhsa_core_fwd(const float* qkv, int ldq, const int32_t* seg_off, int n_cap, const int32_t* n_dyn,
-                       int D, int heads, float* out, int ldo, float* probs /*[rows,heads,Lmax] saved*/,
+                       int D, int heads, float* out, int ldo, float* lse /*nullable*/, float* probs /*nullable*/,
                        int Lmax, const lego_dropout* drop, int rows_cap, int part, const int32_t* long_list, const int32_t* long_count,
                        void* stream);
 int lego_mhsa_core_bwd(const float* qkv, int ldq, const int32_t* seg_off, int n_cap, const int32_t* n_dyn,
-                       int D, int heads, const float* gout, int ldgo, const float* probs, int Lmax,
+                       int D, int heads, const float* gout, int ldgo, const float* lse /*nullable*/, const float* probs /*nullable*/, int Lmax,
                        const lego_dropout* drop, int rows_cap, float* gqkv, int ldgq,
                        float* colsum /*nullable [3*D]: += column sums of gqkv = the in_proj_bias gradient*/, int part,
                        const int32_t* long_list, const int32_t* long_count, void* stream);
@@ -278,7 +284,9 @@ int lego_small_rows_matmul_add(const float* S_a, int rows_a, float* out_a, int l
 int lego_nrms_user_head_train(const float* pooled, int ldp, const float* Wc, const float* bc, const float* items, int ldi,
                               int B, int C, int D, float gscale /* dloss / B */, float* user, int ldu, float* scores /*[B,C]*/,
                               float* loss /*[1] += mean, nullable*/, float* d_user, int lddu, float* d_items, int lddi,
-                              float* d_pooled, int lddp, void* stream);
+                              float* d_pooled, int lddp,
+                              const int32_t* seg_off /*nullable [B+1]: a user whose segment is EMPTY gets u = 0 and d_user = 0 (what the
+                              un-folded operator yields for it) instead of u = bc*/, void* stream);
 
 /* ---- a13: torch.optim.Adam (defaults, base_lego.py:201-204) over one flat fp32 buffer;
  * grad is multiplied by grad_scale first (1/world after the RCCL all-reduce). step is 1-based.
@@ -347,6 +355,9 @@ int lego_grouped_metrics(const float* scores, const int32_t* labels, const int32
 
 /* small utilities used by the host side */
 int lego_gather_i32(const int32_t* table, const int32_t* idx, int n_cap, const int32_t* n_dyn, int32_t* out, void* stream);
+/* rowinfo[i] = live bit (4) iff segment i of seg_off has rows: with it the live-mask epilogue of lego_linear_fwd zeroes the output
+ * rows of EMPTY segments (folded NRMS user vector of a user without clicked items: 0, as the un-folded operator, not the bias) */
+int lego_segment_live(const int32_t* seg_off, int n_cap, const int32_t* n_dyn, int32_t* rowinfo /*[n_cap]*/, void* stream);
 
 #ifdef __cplusplus
 }

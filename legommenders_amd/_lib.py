@@ -22,7 +22,7 @@ U64 = ctypes.c_uint64
 U32 = ctypes.c_uint32
 
 
-ABI_VERSION = 4      # == LEGO_ABI_VERSION of include/lego_hip.h this binding was written against
+ABI_VERSION = 5      # == LEGO_ABI_VERSION of include/lego_hip.h this binding was written against
 
 
 class LegoDropout(ctypes.Structure):
@@ -38,7 +38,7 @@ SIGNATURES = {
     "lego_nrms_special_grads": [P, I, P, P, P, I, I, P, P, I, I, P],
     "lego_mask_dropout_rows": [P, I, I, P, I, P, P, P, P],
     "lego_small_rows_matmul_add": [P, I, P, I, P, I, P, I, P, I, I, P],
-    "lego_nrms_user_head_train": [P, I, P, P, P, I, I, I, I, F, P, I, P, P, P, I, P, I, P, I, P],
+    "lego_nrms_user_head_train": [P, I, P, P, P, I, I, I, I, F, P, I, P, P, P, I, P, I, P, I, P, P],
     "lego_attn_fold_prepare": [P, P, P, P, P, P, P, P, P, P, I, I, P],
     "lego_attn_fold_grads": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P],
     "lego_scatter_add_rows": [P, I, I, I, P, I, P, P, I, P],
@@ -70,8 +70,8 @@ SIGNATURES = {
     "lego_dot_ce_fwd": [P, I, P, I, I, I, I, P, P, P],
     "lego_dot_ce_bwd": [P, I, P, I, P, I, I, I, F, P, I, P, I, P],
     "lego_mhsa_long_segments": [P, I, P, P, P, P],
-    "lego_mhsa_core_fwd": [P, I, P, I, P, I, I, P, I, P, I, P, I, I, P, P, P],
-    "lego_mhsa_core_bwd": [P, I, P, I, P, I, I, P, I, P, I, P, I, P, I, P, I, P, P, P],
+    "lego_mhsa_core_fwd": [P, I, P, I, P, I, I, P, I, P, P, I, P, I, I, P, P, P],
+    "lego_mhsa_core_bwd": [P, I, P, I, P, I, I, P, I, P, P, I, P, I, P, I, P, I, P, P, P],
     "lego_user_tower_train": [P, I, P, I, P, P, I, I, I, I, I, F, P, P, P, P, I, P, P, P],
     "lego_rowdot_fwd": [P, I, P, I, I, I, P, P],
     "lego_rowdot_bwd": [P, I, P, I, P, I, I, P, I, P, I, P],
@@ -82,6 +82,7 @@ SIGNATURES = {
     "lego_sample_negatives": [P, P, P, P, I, I, I, I, U64, U32, U32, U32, P, P, P],
     "lego_gather_history": [P, P, P, I, I, P, P, P],
     "lego_gather_i32": [P, P, I, P, P, P],
+    "lego_segment_live": [P, I, P, P, P],
     "lego_grouped_metrics": [P, P, P, I, P, I, P, P],
 }
 

@@ -177,12 +177,17 @@ __global__ __launch_bounds__(64 * HW) void nrms_user_head_kernel(
     const float* __restrict__ pooled, int ldp, const float* __restrict__ Wc, const float* __restrict__ bc,
     const float* __restrict__ items, int ldi, int B, int C, int D, float gscale,
     float* __restrict__ user, int ldu, float* __restrict__ scores, float* loss,
-    float* __restrict__ d_user, int lddu, float* __restrict__ d_items, int lddi, float* __restrict__ d_pooled, int lddp) {
+    float* __restrict__ d_user, int lddu, float* __restrict__ d_items, int lddi, float* __restrict__ d_pooled, int lddp,
+    const int* __restrict__ seg_off) {
     __shared__ __attribute__((aligned(16))) float p[kHeadMaxD];
     __shared__ __attribute__((aligned(16))) float red[HW][256];
     __shared__ float u[kHeadMaxD], du[kHeadMaxD], s[kHeadMaxC], g[kHeadMaxC];
     constexpr int NT = 64 * HW;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // a user WITHOUT clicked items: the un-folded operator pools over no rows and yields the zero vector (the reference's
+    // nn.MultiheadAttention yields NaN there: no value to match).  The folded form would give u = bc -- a third answer -- so the
+    // empty segment is made the same constant zero: u = 0, and d_user = 0 keeps it out of the bias gradient (colsum of d_user)
+    const bool empty = seg_off != nullptr && seg_off[b + 1] <= seg_off[b];
     for (int k = tid; k < D; k += NT) p[k] = pooled[(size_t)b * ldp + k];
     __syncthreads();
     // u[n] = Wc[n, :] . p + bc[n]: one wave per row, lanes over k; HR rows' loads in flight per wave (one row at a time is one
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(64 * HW) void nrms_user_head_kernel(
         for (int i = 0; i < HR; ++i) {
             const float v = wave_sum(acc[i]);
             const int n = n0 + i;
-            if (lane == 0 && n < D) { const float x = v + bc[n]; u[n] = x; user[(size_t)b * ldu + n] = x; }
+            if (lane == 0 && n < D) { const float x = empty ? 0.f : v + bc[n]; u[n] = x; user[(size_t)b * ldu + n] = x; }
         }
     }
     __syncthreads();
@@ -230,6 +235,7 @@ __global__ __launch_bounds__(64 * HW) void nrms_user_head_kernel(
             acc += g[c] * items[(size_t)(b * C + c) * ldi + n];
             d_items[(size_t)(b * C + c) * lddi + n] = g[c] * un;
         }
+        if (empty) acc = 0.f;
         du[n] = acc;
         d_user[(size_t)b * lddu + n] = acc;
     }
@@ -263,11 +269,12 @@ __global__ __launch_bounds__(64 * HW) void nrms_user_head_kernel(
 
 extern "C" int lego_nrms_user_head_train(const float* pooled, int ldp, const float* Wc, const float* bc, const float* items, int ldi,
                                          int B, int C, int D, float gscale, float* user, int ldu, float* scores, float* loss,
-                                         float* d_user, int lddu, float* d_items, int lddi, float* d_pooled, int lddp, void* stream) {
+                                         float* d_user, int lddu, float* d_items, int lddi, float* d_pooled, int lddp,
+                                         const int32_t* seg_off, void* stream) {
     LEGO_REQUIRE(D > 0 && (D & 3) == 0 && D <= kHeadMaxD && C > 0 && C <= kHeadMaxC && (lddp & 3) == 0,
                  "lego_nrms_user_head_train: D=%d (multiple of 4, <= %d), C=%d (<= %d), lddp=%d", D, kHeadMaxD, C, kHeadMaxC, lddp);
     if (B <= 0) return 0;
     hipLaunchKernelGGL(nrms_user_head_kernel, dim3(B), dim3(64 * HW), 0, (hipStream_t)stream, pooled, ldp, Wc, bc, items, ldi, B, C, D, gscale,
-                       user, ldu, scores, loss, d_user, lddu, d_items, lddi, d_pooled, lddp);
+                       user, ldu, scores, loss, d_user, lddu, d_items, lddi, d_pooled, lddp, seg_off);
     return check_launch("lego_nrms_user_head_train");
 }

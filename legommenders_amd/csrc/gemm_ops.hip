@@ -345,6 +345,8 @@ static int dma_waves() {           // LEGO_DMA_WAVES=4: one wave per SIMD (4 x 4
 
 template <bool B_MC, class EK, class BL, int NW = 8>
 static int launch_dma_strip(const GemmDims& d, const KcRows& a, const BL& b, const Epi& e0, hipStream_t st, const char* what) {
+    LEGO_REQUIRE(d.K >= 4 && d.K % 4 == 0 && a.ld % 4 == 0 && b.ld % 4 == 0,
+                 "%s: the LDS-DMA row-strip kernel needs K %% 4 == 0 and 16-byte-aligned rows (K=%d, lda=%d, ldb=%d)", what, d.K, a.ld, b.ld);
     if constexpr (NW == 8)
         if (dma_waves() == 4) return launch_dma_strip<B_MC, EK, BL, 4>(d, a, b, e0, st, what);
     EK e;
@@ -409,7 +411,10 @@ static int launch_rows(const GemmDims& d, const AL& a, const BL& b, const Epi& e
     const int tm = (d.M + 127) / 128;
     if (d.M >= 32 * num_cus() && d.N <= 4 * STRIP_BN) {
         if constexpr (std::is_same<AL, KcRows>::value && (std::is_same<BL, KcRows>::value || std::is_same<BL, McRows>::value))
-            if (dma_mode() && d.K >= 4 && (!B_MC || d.N % 4 == 0)) return launch_dma_strip<B_MC, EK>(d, a, b, e, st, what);
+            // the DMA staging moves 16-byte chunks clamped to K - 4 and zeroes tails at 4-element granularity: K % 4 == 0 and
+            // 16-byte-aligned rows on both sides, else the register-staged strip kernel
+            if (dma_mode() && d.K >= 4 && d.K % 4 == 0 && a.ld % 4 == 0 && b.ld % 4 == 0 && (!B_MC || d.N % 4 == 0))
+                return launch_dma_strip<B_MC, EK>(d, a, b, e, st, what);
         return launch_strip<B_MC, EK>(d, a, b, e, st, what);
     }
     if constexpr (std::is_same<AL, KcRows>::value)

@@ -16,8 +16,11 @@
 // -- 4.3 KB per wave, so occupancy is set by registers (3-4 waves per SIMD), not by the 23 KB per wave of staged Q / K / V /
 // dOut tiles the previous version held (6 waves per CU: 134 + 69 us per NRMS step for the item side; this one: see DESIGN).
 // Segments of 33..64 rows run as 2 x 2 tiles in a second instantiation on a small grid (launched only when Lmax > 32).
-// The saved probability carries the dropout decision in its sign bit (p >= 0: kept, stored -p: dropped), so the backward
-// pass needs no random numbers.
+// Round 4: the probabilities are NOT saved.  The forward pass keeps one float per (row, head) -- the log-sum-exp of the row's
+// scaled scores -- and the backward pass recomputes S^T = K Q^T (hd/2 MFMAs per tile, operands the wave reads anyway, in their
+// other register shape) and p = exp(s - lse), and redraws the dropout keep bits from the same Philox counters: the
+// [rows, heads, L] round trip (32 MB written + 32 MB read per NRMS step, a fifth of both kernels' traffic) is gone.  `probs`
+// survives as an optional debug output of the forward (tests read the keep decisions from its sign bits: p >= 0 kept, -p dropped).
 #include "../../include/lego_hip.h"
 #include "common.hpp"
 
@@ -27,32 +30,43 @@ constexpr int kMaxL = 64;
 
 __device__ __forceinline__ int acc_row(int v, int lh) { return (v & 3) + 8 * (v >> 2) + 4 * lh; }   // row of accumulator register v
 
-// Operand rows past the end of a segment are CLAMPED to its last row, never zeroed: every product they enter is multiplied by an
-// exact zero on the other side (a masked probability, a zeroed dS entry) or lands in an accumulator entry that is masked or never
-// stored.  (A select per loaded element made the compiler pair each load with its select -- one register, 16 serial round trips.)
-// Addresses are a wave-uniform base plus a 32-bit BYTE offset per lane: the global_load saddr form, one address register per load.
-__device__ __forceinline__ float ld_f(const float* __restrict__ base, unsigned byte_off) {
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+// Round 4: every operand access of a (segment, head) goes through a BUFFER descriptor with the hardware range check (guide T8 /
+// T20) instead of per-lane clamps (loads) and per-store branches.  A `View` is one matrix seen from row 0 of the segment at the
+// head's first column, valid up to the end of the matrix's row L - 1; an access to a row past the segment is out of range: loads
+// return 0 (every product such a row enters meets an exact zero or lands in an entry that is masked or never stored), stores are
+// dropped.  The wave-uniform part of an address (which of the 16 rows an accumulator register indexes, which third of a qkv row)
+// goes into the descriptor's base and record count -- scalar ALU work -- so the 16 loads / stores of a "column per lane" tile share
+// ONE per-lane byte offset.  (Before: 16 clamped 32-bit offsets per matrix pitch and a branch per store kept ~70 VGPRs alive from
+// the top of the kernel to its last store; the backward with the score recomputation did not fit three waves per SIMD.)
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+struct View { const float* p; int bytes; int ld; };
+__device__ __forceinline__ View make_view(const float* p, int ld, int L, int cols_left) { return {p, ((L - 1) * ld + cols_left) * 4, ld}; }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t view_rsrc(const View& v, int off_floats) {          // off_floats: wave-uniform
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(v.p + off_floats), 0, max(v.bytes - off_floats * 4, 0), 0x00020000);
 }
-// "row per lane" operand: columns [lh * HD/2, (lh + 1) * HD/2) of row min(row, L - 1)
+__device__ __forceinline__ int acc_row0(int s) { return (s & 3) + 8 * (s >> 2); }                     // acc_row(s, lh) - 4 * lh
+// "row per lane" operand: columns [col0 + lh * HD/2, col0 + (lh + 1) * HD/2) of row `row` (zeros past the segment)
 template <int HD>
-__device__ __forceinline__ void load_row(const float* __restrict__ g, int ld, int row, int L, int lh, float (&r)[HD / 2]) {
-    const unsigned off = ((unsigned)min(row, L - 1) * (unsigned)ld + (unsigned)(lh * (HD / 2))) * 4u;
+__device__ __forceinline__ void load_row(const View& v, int col0, int row, int lh, float (&r)[HD / 2]) {
+    const __amdgpu_buffer_rsrc_t rs = view_rsrc(v, col0);
+    const int off = (row * v.ld + lh * (HD / 2)) * 4;
 #pragma unroll
     for (int t = 0; t < HD / 8; ++t) {
-        const f32x4 f = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(g) + (off + 16u * t));
+        // (bit_cast of the WHOLE vector: hipcc 7.2 lowers __builtin_bit_cast(float, v.y) on a vector-element lvalue to a read of element 0)
+        const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16 * t, 0, 0));
         r[4 * t] = f.x; r[4 * t + 1] = f.y; r[4 * t + 2] = f.z; r[4 * t + 3] = f.w;
     }
 }
-// "column per lane" operand: column min(ct * 32 + li, HD - 1) of rows min(tile * 32 + acc_row(s, lh), L - 1), s = 0..15
+// "column per lane" operand: column col0 + min(ct * 32 + li, HD - 1) of rows tile * 32 + acc_row(s, lh), s = 0..15
 template <int HD>
-__device__ __forceinline__ void load_cols(const float* __restrict__ g, int ld, int tile, int L, int li, int lh, float (&r)[(HD + 31) / 32][16]) {
+__device__ __forceinline__ void load_cols(const View& v, int col0, int tile, int li, int lh, float (&r)[(HD + 31) / 32][16]) {
 #pragma unroll
     for (int ct = 0; ct < (HD + 31) / 32; ++ct) {
-        const unsigned c = (unsigned)min(ct * 32 + li, HD - 1);          // lanes past the head dim compute a duplicate column that is never stored
+        const int c = min(ct * 32 + li, HD - 1);                 // lanes past the head dim compute a duplicate column that is never stored
+        const int off = ((tile * 32 + 4 * lh) * v.ld + c) * 4;
 #pragma unroll
         for (int s = 0; s < 16; ++s)
-            r[ct][s] = ld_f(g, ((unsigned)min(tile * 32 + acc_row(s, lh), L - 1) * (unsigned)ld + c) * 4u);
+            r[ct][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(view_rsrc(v, col0 + acc_row0(s) * v.ld), off, 0, 0));
     }
 }
 // acc += A B^T over the head dim, both operands "row per lane"
@@ -76,19 +90,17 @@ __device__ __forceinline__ void zero(f32x16 (&t)[CT]) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) t[ct][v] = 0.f;
 }
-// out[(tile * 32 + acc_row(v, lh)) * ld + ct * 32 + li] = t * scale for the rows inside the segment
+// out[tile * 32 + acc_row(v, lh)][col0 + ct * 32 + li] = t * scale; rows past the segment and columns past the head are dropped by the
+// range check (their offset is out of range)
 template <int HD>
-__device__ __forceinline__ void store_cols(const f32x16 (&t)[(HD + 31) / 32], float scale, float* __restrict__ dst, int ld, int tile, int L,
-                                           int li, int lh) {
+__device__ __forceinline__ void store_cols(const f32x16 (&t)[(HD + 31) / 32], float scale, const View& o, int col0, int tile, int li, int lh) {
 #pragma unroll
     for (int ct = 0; ct < (HD + 31) / 32; ++ct) {
         const int c = ct * 32 + li;
-        if (c >= HD) continue;
+        const int off = c < HD ? ((tile * 32 + 4 * lh) * o.ld + c) * 4 : 0x7FFFFFF0;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int r = tile * 32 + acc_row(v, lh);
-            if (r < L) *reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + ((unsigned)r * (unsigned)ld + (unsigned)c) * 4u) = t[ct][v] * scale;
-        }
+        for (int v = 0; v < 16; ++v)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t[ct][v] * scale), view_rsrc(o, col0 + acc_row0(v) * o.ld), off, 0, 0);
     }
 }
 
@@ -160,9 +172,25 @@ __global__ __launch_bounds__(1024) void mhsa_long_segments_kernel(const int* __r
         }                                                                                                         \
     }
 
+// keep bits of a lane's 16 (query, key) pairs of key tile jt: two Philox calls, one 16-bit field per decision.  Forward and backward
+// call it with the same (row, head, tile, lane half), so the backward pass redraws the forward's mask
+__device__ __forceinline__ uint32_t keep_bits(const Dropout& drop, uint32_t thr16, uint32_t ctr, int jt, int lh) {
+    uint32_t keep = 0u;
+#pragma unroll
+    for (int call = 0; call < 2; ++call) {
+        const Philox4 r = philox4x32_10(ctr, (uint32_t)((jt * 2 + lh) * 2 + call), drop.site, 0x6d687361u, drop.seed_lo, drop.seed_hi);
+        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int f = 0; f < 8; ++f)
+            keep |= (((w[f >> 1] >> (16 * (f & 1))) & 0xFFFFu) >= thr16 ? 1u : 0u) << (call * 8 + f);
+    }
+    return keep;
+}
+
 template <int HD, int JT>
 __device__ __forceinline__ void mhsa_fwd_pair(const float* __restrict__ qkv, int ldq, int D, int heads, float* __restrict__ out, int ldo,
-                                              float* __restrict__ probs, int Lmax, const Dropout& drop, int h, int beg, int L, int t0, int t1) {
+                                              float* __restrict__ lse, float* __restrict__ probs, int Lmax, const Dropout& drop, int h,
+                                              int beg, int L, int t0, int t1) {
     constexpr int CT = (HD + 31) / 32, HH = HD / 2;
     const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
     const bool dropping = drop.p > 0.f;
@@ -170,20 +198,22 @@ __device__ __forceinline__ void mhsa_fwd_pair(const float* __restrict__ qkv, int
     const uint32_t thr16 = (uint32_t)(drop.p * 65536.0f);
     const float qscale = rsqrtf((float)HD);
     {
-        const float* qb = qkv + (size_t)beg * ldq + h * HD;
-        float* ptile = probs + ((size_t)beg * heads + (size_t)h * L) * Lmax;
+        const View qv = make_view(qkv + (size_t)beg * ldq + h * HD, ldq, L, 3 * D - h * HD);
+        const View ov = make_view(out + (size_t)beg * ldo + h * HD, ldo, L, D - h * HD);
+        const bool save_p = probs != nullptr;                    // the (segment, head) tile [key j][query i], L x L floats
+        const View pv = make_view(save_p ? probs + ((size_t)beg * heads + (size_t)h * L) * Lmax : qkv, L, save_p ? L : 0, save_p ? L : 0);
         float kr[JT][HH], vc[JT][CT][16];
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
-            load_row<HD>(qb + D, ldq, jt * 32 + li, L, lh, kr[jt]);
-            load_cols<HD>(qb + 2 * D, ldq, jt, L, li, lh, vc[jt]);
+            load_row<HD>(qv, D, jt * 32 + li, lh, kr[jt]);
+            load_cols<HD>(qv, 2 * D, jt, li, lh, vc[jt]);
         }
 #pragma unroll 1
         for (int it = t0; it < t1; ++it) {
             if (it * 32 >= L) break;
             const int i = it * 32 + li;
             float qr[HH];
-            load_row<HD>(qb, ldq, i, L, lh, qr);
+            load_row<HD>(qv, 0, i, lh, qr);
             __builtin_amdgcn_sched_barrier(0);      // all operand loads in flight before the first MFMA
 #pragma unroll
             for (int s = 0; s < HH; ++s) qr[s] *= qscale;
@@ -207,36 +237,25 @@ __device__ __forceinline__ void mhsa_fwd_pair(const float* __restrict__ qkv, int
                 for (int v = 0; v < 16; ++v) { acc[jt][v] = __expf(acc[jt][v] - mx); se += acc[jt][v]; }
             se += __shfl_xor(se, 32, 64);
             const float inv = 1.f / se;
+            if (lse != nullptr && lh == 0 && i < L) lse[(size_t)(beg + i) * heads + h] = mx + __logf(se);   // all a recomputing backward needs
             f32x16 o[CT];
             zero<CT>(o);
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) {
-                // keep bits of this lane's 16 (query, key) pairs: two Philox calls, one 16-bit field per decision
                 uint32_t keep = 0xFFFFu;
-                if (dropping) {
-                    keep = 0u;
-                    const uint32_t ctr = (uint32_t)((beg + min(i, L - 1)) * heads + h);
-#pragma unroll
-                    for (int call = 0; call < 2; ++call) {
-                        const Philox4 r = philox4x32_10(ctr, (uint32_t)((jt * 2 + lh) * 2 + call), drop.site, 0x6d687361u, drop.seed_lo, drop.seed_hi);
-                        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-                        for (int f = 0; f < 8; ++f)
-                            keep |= (((w[f >> 1] >> (16 * (f & 1))) & 0xFFFFu) >= thr16 ? 1u : 0u) << (call * 8 + f);
-                    }
-                }
+                if (dropping) keep = keep_bits(drop, thr16, (uint32_t)((beg + min(i, L - 1)) * heads + h), jt, lh);
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const float p = acc[jt][v] * inv;
                     const bool kept = (keep >> v) & 1u;
-                    const int j = jt * 32 + acc_row(v, lh);
-                    if (i < L && j < L)      // sign bit = dropped
-                        *reinterpret_cast<float*>(reinterpret_cast<char*>(ptile) + ((unsigned)j * (unsigned)L + (unsigned)i) * 4u) = kept ? p : -p;
+                    if (save_p)                                  // sign bit = dropped; keys / queries past the segment are out of range
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, kept ? p : -p), view_rsrc(pv, (jt * 32 + acc_row0(v)) * L),
+                                                              i < L ? (4 * lh * L + i) * 4 : 0x7FFFFFF0, 0, 0);
                     acc[jt][v] = kept ? p * dinv : 0.f;
                 }
                 regs_mfma<HD>(acc[jt], vc[jt], o);
             }
-            store_cols<HD>(o, 1.f, out + (size_t)beg * ldo + h * HD, ldo, it, L, li, lh);
+            store_cols<HD>(o, 1.f, ov, 0, it, li, lh);
         }
     }
 }
@@ -244,55 +263,87 @@ __device__ __forceinline__ void mhsa_fwd_pair(const float* __restrict__ qkv, int
 template <int HD, int JT>
 __global__ __launch_bounds__(64 * JT) __attribute__((amdgpu_waves_per_eu(JT == 1 && HD <= 32 ? 4 : 2))) void mhsa_fwd_kernel(
     const float* __restrict__ qkv, int ldq, const int* __restrict__ seg_off, int n_cap, const int* __restrict__ n_dyn, int D,
-    int heads, float* __restrict__ out, int ldo, float* __restrict__ probs, int Lmax, Dropout drop,
+    int heads, float* __restrict__ out, int ldo, float* __restrict__ lse, float* __restrict__ probs, int Lmax, Dropout drop,
     const int* __restrict__ long_list, const int* __restrict__ long_count, int min_len) {
     const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
     const int t0 = JT == 1 ? 0 : (int)(threadIdx.x >> 6);           // JT == 2: wave t owns query tile t
-    LEGO_MHSA_WALK(mhsa_fwd_pair<HD, JT>(qkv, ldq, D, heads, out, ldo, probs, Lmax, drop, h, beg, L, t0, t0 + 1))
+    LEGO_MHSA_WALK(mhsa_fwd_pair<HD, JT>(qkv, ldq, D, heads, out, ldo, lse, probs, Lmax, drop, h, beg, L, t0, t0 + 1))
 }
 
-template <int HD, int JT>
+// RC (recompute): the probabilities come from S^T = K Q^T and the saved log-sum-exp rows, the keep bits from the forward's Philox
+// counters (no [rows, heads, L] tensor exists).  !RC: the forward pass saved the signed probabilities (`probs`), read here through a
+// descriptor of the (segment, head) tile.  Same-box measurement (tools/mhsa_bulk_probe.py): see DESIGN.md section 4.
+template <int HD, int JT, bool RC>
 __device__ __forceinline__ void mhsa_bwd_pair(const float* __restrict__ qkv, int ldq, int D, int heads, const float* __restrict__ gout, int ldgo,
-                                              const float* __restrict__ probs, int Lmax, float keep_scale, float* __restrict__ gqkv, int ldgq,
+                                              const float* __restrict__ lse, const float* __restrict__ probs, int Lmax, const Dropout& drop,
+                                              float keep_scale, float* __restrict__ gqkv, int ldgq,
                                               float* colsum, float* __restrict__ Pd, float* __restrict__ Ds, int h, int beg, int L, int t0, int t1) {
     constexpr int CT = (HD + 31) / 32, HH = HD / 2, LT = 32 * JT, PLD = LT + 1;
     const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
     const float scale = rsqrtf((float)HD);
-    const float* qb = qkv + (size_t)beg * ldq + h * HD;
-    const float* gb = gout + (size_t)beg * ldgo + h * HD;
-    const float* ptile = probs + ((size_t)beg * heads + (size_t)h * L) * Lmax;
-    float* gq = gqkv + (size_t)beg * ldgq + h * HD;
+    const bool dropping = drop.p > 0.f;
+    const uint32_t thr16 = (uint32_t)(drop.p * 65536.0f);
+    const View qv = make_view(qkv + (size_t)beg * ldq + h * HD, ldq, L, 3 * D - h * HD);
+    const View gv = make_view(gout + (size_t)beg * ldgo + h * HD, ldgo, L, D - h * HD);
+    const View dv_ = make_view(gqkv + (size_t)beg * ldgq + h * HD, ldgq, L, 3 * D - h * HD);
     __syncthreads();                                         // the previous pair's readers of Pd / Ds are done
     // ---- orientation 1, lane = query i: dP^T tiles -> row dots -> dS^T (kept for orientation 2 in LDS) -> dQ
     {
-        float vr[JT][HH], kc[JT][CT][16];
+        float kr[RC ? JT : 1][HH], vr[JT][HH], kc[JT][CT][16];
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
-            load_row<HD>(qb + 2 * D, ldq, jt * 32 + li, L, lh, vr[jt]);
-            load_cols<HD>(qb + D, ldq, jt, L, li, lh, kc[jt]);
+            if constexpr (RC) load_row<HD>(qv, D, jt * 32 + li, lh, kr[jt]);
+            load_row<HD>(qv, 2 * D, jt * 32 + li, lh, vr[jt]);
+            load_cols<HD>(qv, D, jt, li, lh, kc[jt]);
         }
 #pragma unroll 1
         for (int it = t0; it < t1; ++it) {
             if (it * 32 >= L) break;
             const int i = it * 32 + li;
-            float gr[HH];
-            load_row<HD>(gb, ldgo, i, L, lh, gr);
-            const float in_i = i < L ? 1.f : 0.f;
+            float qr[RC ? HH : 1], gr[HH];
             f32x16 dp[JT], ps[JT];
-            float dot = 0.f;
+            float lse_i = 0.f;
+            if constexpr (RC) {
+                load_row<HD>(qv, 0, i, lh, qr);
+                lse_i = lse[(size_t)(beg + min(i, L - 1)) * heads + h];
+            } else {
+                // the saved tile [key j][query i] (L x L floats) as a view of L rows of L columns: keys past the segment are out of
+                // range, and so is every lane whose query is (offset past the tile)
+                const View pv = make_view(probs + ((size_t)beg * heads + (size_t)h * L) * Lmax, L, L, L);
+                const int off = i < L ? (4 * lh * L + i) * 4 : 0x7FFFFFF0;
 #pragma unroll
-            for (int jt = 0; jt < JT; ++jt)
+                for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int j = jt * 32 + acc_row(v, lh);
-                    // signed: sign bit = dropped.  Entries outside the L x L tile are zeroed by a MULTIPLY (the clamped address reads
-                    // a real probability): a select here makes the compiler sink each load into its own branch, 16 round trips
-                    ps[jt][v] = ld_f(ptile, ((unsigned)min(j, L - 1) * (unsigned)L + (unsigned)min(i, L - 1)) * 4u) * (j < L ? in_i : 0.f);
-                    dp[jt][v] = 0.f;
-                }
+                    for (int v = 0; v < 16; ++v)
+                        ps[jt][v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(view_rsrc(pv, (jt * 32 + acc_row0(v)) * L), off, 0, 0));
+            }
+            load_row<HD>(gv, 0, i, lh, gr);
             __builtin_amdgcn_sched_barrier(0);      // every load of this phase is in flight before the first MFMA (see orientation 2)
+            float dot = 0.f;
+            if constexpr (RC) {
+                // the forward's probabilities again: S^T = K Q^T with the forward's operand values and order (bit-identical scores),
+                // p = exp(s - lse); signed as the forward's debug output is: p > 0 kept, p < 0 dropped, 0 outside the L x L tile
+#pragma unroll
+                for (int s_ = 0; s_ < HH; ++s_) qr[s_] *= scale;
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) ps[jt][v] = 0.f;
+                    rows_mfma<HD>(kr[jt], qr, ps[jt]);
+                    uint32_t keep = 0xFFFFu;
+                    if (dropping) keep = keep_bits(drop, thr16, (uint32_t)((beg + min(i, L - 1)) * heads + h), jt, lh);
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int j = jt * 32 + acc_row(v, lh);
+                        const float p = (i < L && j < L) ? __expf(ps[jt][v] - lse_i) : 0.f;
+                        ps[jt][v] = ((keep >> v) & 1u) ? p : -p;
+                    }
+                }
+            }
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) dp[jt][v] = 0.f;
                 rows_mfma<HD>(vr[jt], gr, dp[jt]);                         // dP^T[j][i] = V_j . dOut_i
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
@@ -315,7 +366,7 @@ __device__ __forceinline__ void mhsa_bwd_pair(const float* __restrict__ qkv, int
                 }
                 regs_mfma<HD>(dp[jt], kc[jt], dq);
             }
-            store_cols<HD>(dq, scale, gq, ldgq, it, L, li, lh);
+            store_cols<HD>(dq, scale, dv_, 0, it, li, lh);
             if (colsum != nullptr) col_add<HD>(dq, scale, colsum + h * HD, li, lh);             // in_proj_bias gradient, Q third
         }
     }
@@ -332,8 +383,8 @@ __device__ __forceinline__ void mhsa_bwd_pair(const float* __restrict__ qkv, int
         for (int it = 0; it < JT; ++it) {
             if (it * 32 >= L) break;
             float qc[CT][16], gc[CT][16];
-            load_cols<HD>(qb, ldq, it, L, li, lh, qc);
-            load_cols<HD>(gb, ldgo, it, L, li, lh, gc);
+            load_cols<HD>(qv, 0, it, li, lh, qc);
+            load_cols<HD>(gv, 0, it, li, lh, gc);
             // without this fence the scheduler of the 2-tile instantiation pairs every load with the MFMA that consumes it -- 48
             // dependent round trips, 69 us per launch for 4 % of the pairs
             __builtin_amdgcn_sched_barrier(0);
@@ -347,8 +398,8 @@ __device__ __forceinline__ void mhsa_bwd_pair(const float* __restrict__ qkv, int
             regs_mfma<HD>(ds, qc, dk);                                     // dK[j][c] += dS[i][j] Q[i][c]
             regs_mfma<HD>(pd, gc, dv);                                     // dV[j][c] += Pd[i][j] dOut[i][c]
         }
-        store_cols<HD>(dk, scale, gq + D, ldgq, jt, L, li, lh);
-        store_cols<HD>(dv, 1.f, gq + 2 * D, ldgq, jt, L, li, lh);
+        store_cols<HD>(dk, scale, dv_, D, jt, li, lh);
+        store_cols<HD>(dv, 1.f, dv_, 2 * D, jt, li, lh);
         if (colsum != nullptr) {                                               // ... K and V thirds
             col_add<HD>(dk, scale, colsum + D + h * HD, li, lh);
             col_add<HD>(dv, 1.f, colsum + 2 * D + h * HD, li, lh);
@@ -356,17 +407,18 @@ __device__ __forceinline__ void mhsa_bwd_pair(const float* __restrict__ qkv, int
     }
 }
 
-template <int HD, int JT>
-__global__ __launch_bounds__(64 * JT) __attribute__((amdgpu_waves_per_eu(JT == 1 ? (HD == 32 ? 3 : 2) : 1))) void mhsa_bwd_kernel(
+template <int HD, int JT, int OCC, bool RC>
+__global__ __launch_bounds__(64 * JT) __attribute__((amdgpu_waves_per_eu(OCC))) void mhsa_bwd_kernel(
     const float* __restrict__ qkv, int ldq, const int* __restrict__ seg_off, int n_cap, const int* __restrict__ n_dyn, int D,
-    int heads, const float* __restrict__ gout, int ldgo, const float* __restrict__ probs, int Lmax, float keep_scale,
+    int heads, const float* __restrict__ gout, int ldgo, const float* __restrict__ lse, const float* __restrict__ probs, int Lmax,
+    Dropout drop, float keep_scale,
     float* __restrict__ gqkv, int ldgq, float* colsum, const int* __restrict__ long_list, const int* __restrict__ long_count, int min_len) {
     constexpr int LT = 32 * JT;
     __shared__ float Pd[LT * (LT + 1)];                       // dropped-and-rescaled probabilities [key j][query i]
     __shared__ float Ds[LT * (LT + 1)];                       // dS^T [key j][query i]
     const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
     const int t0 = JT == 1 ? 0 : (int)(threadIdx.x >> 6);           // JT == 2: wave t owns query tile t, then key tile t
-    LEGO_MHSA_WALK(mhsa_bwd_pair<HD, JT>(qkv, ldq, D, heads, gout, ldgo, probs, Lmax, keep_scale, gqkv, ldgq, colsum, Pd, Ds, h, beg, L, t0, t0 + 1))
+    LEGO_MHSA_WALK(mhsa_bwd_pair<HD, JT, RC>(qkv, ldq, D, heads, gout, ldgo, lse, probs, Lmax, drop, keep_scale, gqkv, ldgq, colsum, Pd, Ds, h, beg, L, t0, t0 + 1))
 }
 #undef LEGO_MHSA_WALK
 
@@ -400,9 +452,10 @@ extern "C" int lego_mhsa_long_segments(const int32_t* seg_off, int n_cap, const 
 }
 
 extern "C" int lego_mhsa_core_fwd(const float* qkv, int ldq, const int32_t* seg_off, int n_cap, const int32_t* n_dyn,
-                                  int D, int heads, float* out, int ldo, float* probs, int Lmax,
+                                  int D, int heads, float* out, int ldo, float* lse, float* probs, int Lmax,
                                   const lego_dropout* drop, int rows_cap, int part, const int32_t* long_list,
                                   const int32_t* long_count, void* stream) {
+    LEGO_REQUIRE(lse != nullptr || probs != nullptr, "lego_mhsa_core_fwd: lse (recomputing backward) or probs (saved probabilities) is required");
     LEGO_REQUIRE(heads > 0 && D % heads == 0, "lego_mhsa_core_fwd: D=%d not divisible by heads=%d", D, heads);
     LEGO_REQUIRE(Lmax <= kMaxL, "lego_mhsa_core_fwd: Lmax=%d exceeds %d", Lmax, kMaxL);
     LEGO_REQUIRE((ldq & 3) == 0 && (D & 3) == 0, "lego_mhsa_core_fwd: ldq=%d and D=%d must be multiples of 4", ldq, D);
@@ -415,9 +468,9 @@ extern "C" int lego_mhsa_core_fwd(const float* qkv, int ldq, const int32_t* seg_
     const bool all_long = part == LEGO_MHSA_ALL_LONG && Lmax > 32;   // every segment through the two-wave instantiation: ONE launch
 #define LAUNCH(HD) do { \
         if (part != LEGO_MHSA_LONG && !all_long) \
-            hipLaunchKernelGGL((mhsa_fwd_kernel<HD, 1>), dim3(short_grid(n_cap, heads)), dim3(64), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, out, ldo, probs, Lmax, dr, nullptr, nullptr, 32); \
+            hipLaunchKernelGGL((mhsa_fwd_kernel<HD, 1>), dim3(short_grid(n_cap, heads)), dim3(64), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, out, ldo, lse, probs, Lmax, dr, nullptr, nullptr, 32); \
         if (Lmax > 32 && part != LEGO_MHSA_SHORT) \
-            hipLaunchKernelGGL((mhsa_fwd_kernel<HD, 2>), dim3(long_grid(n_cap, heads)), dim3(128), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, out, ldo, probs, Lmax, dr, all_long ? nullptr : long_list, all_long ? nullptr : long_count, all_long ? 0 : 32); \
+            hipLaunchKernelGGL((mhsa_fwd_kernel<HD, 2>), dim3(long_grid(n_cap, heads)), dim3(128), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, out, ldo, lse, probs, Lmax, dr, all_long ? nullptr : long_list, all_long ? nullptr : long_count, all_long ? 0 : 32); \
     } while (0)
     switch (hd) {
         case 8: LAUNCH(8); break;
@@ -431,7 +484,7 @@ extern "C" int lego_mhsa_core_fwd(const float* qkv, int ldq, const int32_t* seg_
 }
 
 extern "C" int lego_mhsa_core_bwd(const float* qkv, int ldq, const int32_t* seg_off, int n_cap, const int32_t* n_dyn,
-                                  int D, int heads, const float* gout, int ldgo, const float* probs, int Lmax,
+                                  int D, int heads, const float* gout, int ldgo, const float* lse, const float* probs, int Lmax,
                                   const lego_dropout* drop, int rows_cap, float* gqkv, int ldgq, float* colsum, int part,
                                   const int32_t* long_list, const int32_t* long_count, void* stream) {
     LEGO_REQUIRE(heads > 0 && D % heads == 0, "lego_mhsa_core_bwd: D=%d not divisible by heads=%d", D, heads);
@@ -440,23 +493,31 @@ extern "C" int lego_mhsa_core_bwd(const float* qkv, int ldq, const int32_t* seg_
     if (n_cap <= 0) return 0;
     const int hd = D / heads;
     const Dropout dr = to_drop(drop);
-    const float ks = dr.p > 0.f ? 1.f / (1.f - dr.p) : 1.f;     // the keep / drop decision itself is the sign of the saved probability
+    const float ks = dr.p > 0.f ? 1.f / (1.f - dr.p) : 1.f;     // the keep / drop decisions are redrawn in the kernel (same Philox counters)
     (void)rows_cap;
     hipStream_t st = (hipStream_t)stream;
     const bool all_long = part == LEGO_MHSA_ALL_LONG && Lmax > 32;
-#define LAUNCH(HD) do { \
-        if (part != LEGO_MHSA_LONG && !all_long) \
-            hipLaunchKernelGGL((mhsa_bwd_kernel<HD, 1>), dim3(short_grid(n_cap, heads)), dim3(64), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, gout, ldgo, probs, Lmax, ks, gqkv, ldgq, colsum, nullptr, nullptr, 32); \
-        if (Lmax > 32 && part != LEGO_MHSA_SHORT) \
-            hipLaunchKernelGGL((mhsa_bwd_kernel<HD, 2>), dim3(long_grid(n_cap, heads)), dim3(128), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, gout, ldgo, probs, Lmax, ks, gqkv, ldgq, colsum, all_long ? nullptr : long_list, all_long ? nullptr : long_count, all_long ? 0 : 32); \
+    LEGO_REQUIRE(lse != nullptr || probs != nullptr, "lego_mhsa_core_bwd: needs the forward's lse rows (recompute) or its saved probabilities");
+    const bool shrt = part != LEGO_MHSA_LONG && !all_long, lng = Lmax > 32 && part != LEGO_MHSA_SHORT;
+    const int* ll = all_long ? nullptr : long_list;
+    const int* lc = all_long ? nullptr : long_count;
+    const int ml = all_long ? 0 : 32;
+    const bool rc = probs == nullptr;                      // saved probabilities win when both are given
+    const dim3 gs(short_grid(n_cap, heads)), gl(long_grid(n_cap, heads));
+#define BWD(HD, JT, OCC, RC, GRID, ...) \
+    hipLaunchKernelGGL((mhsa_bwd_kernel<HD, JT, OCC, RC>), GRID, dim3(64 * JT), 0, st, qkv, ldq, seg_off, n_cap, n_dyn, D, heads, gout, ldgo, lse, probs, Lmax, dr, ks, gqkv, ldgq, colsum, __VA_ARGS__)
+#define BOTH(HD, OS_RC, OS_SV, OL_RC, OL_SV) do { \
+        if (shrt) { if (rc) BWD(HD, 1, OS_RC, true, gs, nullptr, nullptr, 32); else BWD(HD, 1, OS_SV, false, gs, nullptr, nullptr, 32); } \
+        if (lng) { if (rc) BWD(HD, 2, OL_RC, true, gl, ll, lc, ml); else BWD(HD, 2, OL_SV, false, gl, ll, lc, ml); } \
     } while (0)
-    switch (hd) {
-        case 8: LAUNCH(8); break;
-        case 16: LAUNCH(16); break;
-        case 32: LAUNCH(32); break;
-        case 64: LAUNCH(64); break;
+    switch (hd) {                                          // waves per SIMD: what the register counts allow (tools/regs.sh)
+        case 8: BOTH(8, 3, 4, 1, 2); break;
+        case 16: BOTH(16, 3, 4, 1, 2); break;
+        case 32: BOTH(32, 3, 4, 1, 2); break;
+        case 64: BOTH(64, 2, 2, 1, 1); break;
         default: return set_error("lego_mhsa_core_bwd: head dim %d not in {8,16,32,64}", hd);
     }
-#undef LAUNCH
+#undef BOTH
+#undef BWD
     return check_launch("lego_mhsa_core_bwd");
 }

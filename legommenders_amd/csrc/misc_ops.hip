@@ -753,6 +753,13 @@ __global__ void gather_i32_kernel(const int* __restrict__ table, const int* __re
     if (i < n) out[i] = table[idx[i]];
 }
 
+// rowinfo[i] = RI_LIVE iff segment i has rows (the live-mask epilogue of lego_linear_fwd then zeroes the output rows of empty segments)
+__global__ void segment_live_kernel(const int* __restrict__ seg_off, int n_cap, const int* __restrict__ n_dyn, int* __restrict__ out) {
+    const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = seg_off[i + 1] > seg_off[i] ? RI_LIVE : 0;
+}
+
 // out[c] += sum over rows; block = 64 columns x 4 row lanes, 256 rows per block
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ldx, int M_cap,
                                                      const int* __restrict__ M_dyn, const int* __restrict__ off_dyn,
@@ -1812,6 +1819,12 @@ extern "C" int lego_gather_i32(const int32_t* table, const int32_t* idx, int n_c
     if (n_cap <= 0) return 0;
     hipLaunchKernelGGL(gather_i32_kernel, dim3((n_cap + 255) / 256), dim3(256), 0, ST, table, idx, n_cap, n_dyn, out);
     return check_launch("lego_gather_i32");
+}
+
+extern "C" int lego_segment_live(const int32_t* seg_off, int n_cap, const int32_t* n_dyn, int32_t* rowinfo, void* stream) {
+    if (n_cap <= 0) return 0;
+    hipLaunchKernelGGL(segment_live_kernel, dim3((n_cap + 255) / 256), dim3(256), 0, ST, seg_off, n_cap, n_dyn, rowinfo);
+    return check_launch("lego_segment_live");
 }
 
 extern "C" int lego_colsum(const float* x, int ldx, int M_cap, const int32_t* M_dyn, const int32_t* row_off_dyn,

@@ -207,6 +207,23 @@ class _Base:
         self._forward_users(False)
         return self.user[:n].clone()
 
+    # ---- the de-duplication scratch (stamp / rank tables over the vocabulary, sort keys and temporaries) exists ONCE per engine,
+    # while plans are made on the prefetch stream (plan_on) and un-planned calls (item_vectors, forward(planned=False), bench's
+    # stand-alone gather) use it on the current stream: a use on another stream than the previous one waits for that one's
+    # event.  The steady training loop only ever uses the prefetch stream, so it never waits.
+    _uq_last = None
+
+    def _uq_begin(self, stream):
+        last = self._uq_last
+        if last is not None and last[0] != stream.cuda_stream:
+            stream.wait_event(last[1])
+
+    def _uq_end(self, stream):
+        last = self._uq_last
+        ev = last[1] if last is not None else torch.cuda.Event()
+        ev.record(stream)
+        self._uq_last = (stream.cuda_stream, ev)
+
     fused_grads = None      # set by bind_grads(): enables the fused user tower (forward writes its gradient partials)
     touched_rows = None     # uint8 [V] flags of the trainable token table's rows that have received a gradient (TrainStep)
     grad_hooks = None       # (dense_ready(), bucket_ready(lo_row, hi_row), rows_per_bucket): data-parallel TrainStep, trainable table
@@ -350,6 +367,7 @@ class NamlEngine(_Base):
         if self.dedup:
             # distinct tokens of the planned rows (uniq / inv / perm, U -> counters[6]), then ONE table row per distinct token
             self._uq_epoch = self._uq_epoch % 0x7FFFFFF0 + 1
+            self._uq_begin(s)
             self.kk(s, None, "lego_unique_tokens", _ptr(b["row_tok"]), self.Rc, _ptr(b["counters"], 0), self.V, _ptr(self.uq_stamp),
                     self._uq_epoch, _ptr(self.uq_rank), _ptr(self.uq_bsum), _ptr(b["uniq"]), _ptr(b["inv"]), _ptr(self.uq_cnt),
                     _ptr(self.uq_start), None, _ptr(self.uq_keys) if self.dedup_bwd else None, _ptr(b["counters"], 6))
@@ -359,6 +377,7 @@ class NamlEngine(_Base):
                 # Behind the table gather: the sort's ~10 small launches would push the gather into the backward's HBM-heavy phase
                 self.kk(s, None, "lego_sort_rows", _ptr(self.uq_keys), self.Rc, _ptr(b["keys_sorted"]), _ptr(b["perm"]),
                         _ptr(self.uq_temp), self.uq_temp.numel())
+            self._uq_end(s)
             if not self.dedup_bwd:                   # the weight gradient still runs over the token rows: X[r] = Xu[inv[r]]
                 self.kk(s, "expand_rows_in_step" if stream is not None else None, "lego_expand_rows", _ptr(b["Xu"]), self.E0, _ptr(b["inv"]),
                         self.Rc, _ptr(b["counters"], 0), self.E0, None, None, None, 0, None, None, 0, None, _ptr(b["X"]), self.E0)
@@ -735,6 +754,7 @@ class NrmsEngine(_Base):
             # read dE -- the separate mask pass over dE (20 us) is gone
             self.mask_proj = torch.zeros((((self.Rc + 3) // 4) * D if glove else 0) + 4, dtype=torch.uint8, device=self.dev)
         self._slot_mask_step, self._mask_step = {}, -1
+        self._slot_clean = {}
         self.X = (self._f(1, self.E0) if self.dedup else self._f(self.Rc, self.E0)) if glove else None
         self.E = self._f(self.Rc, D)
         self.dE = self._f(self.Rc, D)
@@ -771,9 +791,19 @@ class NrmsEngine(_Base):
     def use_slot(self, s):
         super().use_slot(s)
         self._mask_step = self._slot_mask_step.get(s, -1)
-        self._dhu_zeroed = self.dedup                # cleared by plan_on (_decode_gather)
+        # the slot's per-token sums dHu are zero rows only between its plan (plan_on -> _decode_gather clears them) and the first
+        # backward that adds into them: a slot used again WITHOUT a new plan (a replayed batch) must clear them in the sums' launch
+        self._cur_slot = s
+        self._dhu_zeroed = bool(self.dedup and self._slot_clean.get(s, False))
 
     _dhu_zeroed = False
+    _cur_slot = None
+
+    def _dhu_consumed(self):
+        """backward has added into dHu: the current slot's rows are not clean any more"""
+        self._dhu_zeroed = False
+        if self._cur_slot is not None:
+            self._slot_clean[self._cur_slot] = False
 
     def drop(self, p, site, training):
         if not training or p <= 0.0:
@@ -787,7 +817,8 @@ class NrmsEngine(_Base):
         super().plan_on(stream, slot, cand, hist, hist_len, nb)
         self._long_lists(self._slots[slot], ctypes.c_void_p(stream.cuda_stream), nb)
         if self.Rc > 0:
-            self._decode_gather(self._slots[slot], ctypes.c_void_p(stream.cuda_stream))
+            self._decode_gather(self._slots[slot], stream)
+            self._slot_clean[slot] = bool(self.dedup)
 
     def _long_lists(self, b, st, nb=None):
         if self.L > 32 and self.Rc > 0:
@@ -795,12 +826,14 @@ class NrmsEngine(_Base):
         if self.S > 32:
             call("lego_mhsa_long_segments", _ptr(b["hist_off"]), (nb or self.B) if b is not self.__dict__ else self.nb, None, _ptr(b["long_users"]), _ptr(b["long_cnt"], 1), st)
 
-    def _decode_gather(self, b, st):
+    def _decode_gather(self, b, stream):
+        st = ctypes.c_void_p(stream.cuda_stream)
         call("lego_nrms_decode_rows", _ptr(b["row_tok"]), self.Rc, _ptr(b["counters"], 0), _ptr(b["idx_tok"]), _ptr(b["idx_spec"]),
              _ptr(b["idx_cat"]), _ptr(b["tokinfo"]), st)
         if self.dedup:
             E0 = self.E0
             self._uq_epoch = self._uq_epoch % 0x7FFFFFF0 + 1
+            self._uq_begin(stream)
             call("lego_unique_tokens", _ptr(b["row_tok"]), self.Rc, _ptr(b["counters"], 0), self.V, _ptr(self.uq_stamp), self._uq_epoch,
                  _ptr(self.uq_rank), _ptr(self.uq_bsum), _ptr(b["uniq"]), _ptr(b["inv"]), _ptr(self.uq_cnt), _ptr(self.uq_start), None,
                  _ptr(self.uq_keys), _ptr(b["counters"], 6), st)
@@ -809,6 +842,7 @@ class NrmsEngine(_Base):
                      self.Uc, _ptr(b["counters"], 6), _ptr(b["Xu"]), E0, 0, st)
             call("lego_sort_rows", _ptr(self.uq_keys), self.Rc, _ptr(b["keys_sorted"]), _ptr(b["perm"]), _ptr(self.uq_temp),
                  self.uq_temp.numel(), st)
+            self._uq_end(stream)
             if b is not self.__dict__:               # a plan slot: its per-token sums start from rows cleared here, off the main stream
                 call("lego_zero_rows", _ptr(b["dHu"]), self.D, self.D, self.Uc, _ptr(b["counters"], 6), st)
         elif self.glove:
@@ -816,11 +850,18 @@ class NrmsEngine(_Base):
             call("lego_gather_rows", _ptr(self.P["embedding_vocab_table.glove.embedding.weight"]), E0, E0, _ptr(b["idx_tok"]),
                  self.Rc, _ptr(b["counters"], 0), _ptr(b["X"]), E0, 0, st)
 
+    # how the attention core's backward gets the softmax: recomputed from Q, K and one log-sum-exp per (row, head) (no [rows, heads, L]
+    # tensor: 64 MB less HBM traffic per step at the bench shape) or read back from probabilities the forward pass saved.  Same-box
+    # A/B in DESIGN.md section 4; LEGO_MHSA_RECOMPUTE picks
+    mhsa_recompute = os.environ.get("LEGO_MHSA_RECOMPUTE", "0") == "1"
+
     def _att_ws(self, rows, Lmax, n_seg):
         D, A, H = self.D, self.A, self.heads
         return dict(rows=rows, Lmax=Lmax, qkv=self._f(rows, 3 * D), o=self._f(rows, D), att=self._f(rows, D),
-                    lin=self._f(rows, D), t=self._f(rows, A), wrow=self._f(rows), probs=self._f(rows, H, Lmax),
+                    lin=self._f(rows, D), t=self._f(rows, A), wrow=self._f(rows),
+                    lse=self._f(rows, H) if self.mhsa_recompute else None, probs=None if self.mhsa_recompute else self._f(rows, H, Lmax),
                     d_lin=self._f(rows, D), d_att=self._f(rows, D), d_o=self._f(rows, D), d_qkv=self._f(rows, 3 * D),
+                    seg_live=torch.zeros(max(n_seg, 1), dtype=torch.int32, device=self.dev),
                     Wc=self._f(D, D), bc=self._f(D), T=self._f(D, D), U=self._f(D, D), s=self._f(D),
                     W2=self._f(A, D), b2=self._f(A), Tp=self._f(A, D), U2=self._f(A, D), sp=self._f(A),
                     pooled=self._f(n_seg, D), d_pooled=self._f(n_seg, D))
@@ -839,7 +880,7 @@ class NrmsEngine(_Base):
                 _ptr(P[pre + "multi_head_attention.in_proj_bias"]), _ptr(ws["qkv"]), 3 * D, rows, rows_dyn, 3 * D, D, 0,
                 None, None, None, None)
         core = ("lego_mhsa_core_fwd", _ptr(ws["qkv"]), 3 * D, _ptr(seg_off), n_cap, n_dyn, D, self.heads,
-                _ptr(ws["o"]), D, _ptr(ws["probs"]), ws["Lmax"], self.drop(self.p_att, site, training), rows)
+                _ptr(ws["o"]), D, _ptr(ws["lse"]), _ptr(ws["probs"]), ws["Lmax"], self.drop(self.p_att, site, training), rows)
         self.kk(m, "mhsa_core_fwd_" + tg, *core, *self._part(pre, ws))
         if self.fold and self._fold_ev is not None:          # the folded weights come from the side stream (_prepare_folds)
             m.wait_event(self._fold_ev)
@@ -853,10 +894,16 @@ class NrmsEngine(_Base):
                 # the user vector, the dot predictor, the loss and their backward down to d(pooled) in ONE launch (training steps)
                 call("lego_nrms_user_head_train", _ptr(ws["pooled"]), D, _ptr(ws["Wc"]), _ptr(ws["bc"]), _ptr(self.items), D,
                      self.nb, self.C, D, 1.0 / self.nb, _ptr(out), D, _ptr(self.scores), _ptr(self.loss), _ptr(self.d_user), D,
-                     _ptr(self.d_items), D, _ptr(ws["d_pooled"]), D, st)
+                     _ptr(self.d_items), D, _ptr(ws["d_pooled"]), D, _ptr(seg_off), st)
                 return
+            # an EMPTY segment (a user without clicked items) gets the zero vector the un-folded operator pools for it, not the
+            # folded bias bc: the product's live-mask epilogue reads one live bit per segment (item segments always have rows)
+            live = None
+            if pre == "user_op.":
+                call("lego_segment_live", _ptr(seg_off), n_cap, n_dyn, _ptr(ws["seg_live"]), st)
+                live = _ptr(ws["seg_live"])
             call("lego_linear_fwd", _ptr(ws["pooled"]), D, _ptr(ws["Wc"]), D, _ptr(ws["bc"]), _ptr(out), D, n_cap, n_dyn, D, D, 0,
-                 None, None, None, None, st)
+                 live, None, None, None, st)
             return
         if self.fold:
             self.kk(m, "outlin_fwd_" + tg, "lego_linear_fwd", _ptr(ws["o"]), D, _ptr(ws["Wc"]), D, _ptr(ws["bc"]), _ptr(ws["lin"]), D,
@@ -944,7 +991,7 @@ class NrmsEngine(_Base):
         else:
             self._att_bwd_head(pre, ws, G, rows_dyn, seg_off, n_cap, n_dyn, gout, st, ev, m, sw, sp)
         core = ("lego_mhsa_core_bwd", _ptr(ws["qkv"]), 3 * D, _ptr(seg_off),
-                n_cap, n_dyn, D, self.heads, _ptr(ws["d_o"]), D, _ptr(ws["probs"]), ws["Lmax"],
+                n_cap, n_dyn, D, self.heads, _ptr(ws["d_o"]), D, _ptr(ws["lse"]), _ptr(ws["probs"]), ws["Lmax"],
                 self.drop(self.p_att, site, training), rows, _ptr(ws["d_qkv"]), 3 * D,
                 _ptr(G[pre + "multi_head_attention.in_proj_bias"]))      # bias gradient = column sums of d_qkv, fused
         self.kk(m, "mhsa_core_bwd_" + pre[:4], *core, *self._part(pre, ws))
@@ -991,6 +1038,9 @@ class NrmsEngine(_Base):
         W1 = P[pre + "additive_attention.encoder.0.weight"]
         gw2, gW1, gb1 = (G[pre + "additive_attention.encoder." + k] for k in ("2.weight", "0.weight", "0.bias"))
         if not (pre == "user_op." and self._have_d_pooled):
+            if pre == "user_op.":                    # the zero vector of an empty segment is a constant: no gradient through it
+                call("lego_segment_live", _ptr(seg_off), n_cap, n_dyn, _ptr(ws["seg_live"]), st)
+                call("lego_mask_dropout_rows", _ptr(gout), D, n_cap, n_dyn, D, _ptr(ws["seg_live"]), None, None, st)
             call("lego_linear_bwd_data", _ptr(gout), D, _ptr(ws["Wc"]), D, _ptr(ws["d_pooled"]), D, n_cap, n_dyn, D, D, 0,
                  None, 0, 1.0, None, None, None, None, None, st)
         call("lego_additive_pool_bwd", _ptr(ws["t"]), A, _ptr(ws["o"]), D, _ptr(P[pre + "additive_attention.encoder.2.weight"]),
@@ -1100,6 +1150,7 @@ class NrmsEngine(_Base):
              _ptr(self.rowinfo), _ptr(self.row_tok), _stream())
         self._mask_step = -1                         # no keep bits were drawn for an un-planned batch
         self._dhu_zeroed = False
+        self._cur_slot = None
         self._long_lists(self.__dict__, _stream())
 
     _folds_fresh = False
@@ -1115,7 +1166,7 @@ class NrmsEngine(_Base):
         self._prepare_folds()
         self._folds_fresh = True
         if not (planned and getattr(self, "_slots", None) is not None):      # else: done with the plan (plan_on)
-            self._decode_gather(self.__dict__, st)
+            self._decode_gather(self.__dict__, torch.cuda.current_stream())
         if self.glove and self.dedup:
             E0 = self.E0
             call("lego_linear_fwd", _ptr(self.Xu), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
@@ -1232,7 +1283,7 @@ class NrmsEngine(_Base):
                 call("lego_segment_sum_rows", _ptr(self.dE), D, D, _ptr(self.perm), _ptr(self.inv), self.Rc, _ptr(self.keys_sorted),
                      self.cnt(0), _ptr(self.dHu), D, self.Uc, self.cnt(6), 0 if self._dhu_zeroed else 1, dp if in_sums else None,
                      _ptr(self.tokinfo) if in_sums else None, st)
-                self._dhu_zeroed = False
+                self._dhu_consumed()
                 if not fused:                        # the bias gradient = column sums of the masked dE = column sums of the per-token sums
                     call("lego_colsum", _ptr(self.dHu), D, self.Uc, self.cnt(6), None, D, gb, st)
                 call("lego_linear_bwd_weight", _ptr(self.dHu), D, _ptr(self.Xu), E0,
@@ -1247,7 +1298,7 @@ class NrmsEngine(_Base):
             if self.dedup:                           # per-token sums of dE (the [SEP] / category positions masked out) ...
                 call("lego_segment_sum_rows", _ptr(self.dE), D, D, _ptr(self.perm), _ptr(self.inv), self.Rc, _ptr(self.keys_sorted),
                      self.cnt(0), _ptr(self.dHu), D, self.Uc, self.cnt(6), 0 if self._dhu_zeroed else 1, None, _ptr(self.tokinfo), st)
-                self._dhu_zeroed = False
+                self._dhu_consumed()
             if self.grad_hooks is None:
                 if self.dedup:                       # ... added to the DISTINCT table rows: no two rows of this launch share a destination
                     call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.glove.weight"]), D, D, V, _ptr(self.uniq),

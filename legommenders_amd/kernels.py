@@ -233,24 +233,30 @@ def scatter_add_rows(grad_table, idx, g):
     return grad_table
 
 
-def mhsa_fwd(x, mask, in_w, in_b, out_w, out_b, heads, drop=None):
+def mhsa_fwd(x, mask, in_w, in_b, out_w, out_b, heads, drop=None, padded=False):
     """nn.MultiheadAttention(q=k=v=x, key_padding_mask=(1-mask)) on dense [n,L,D]; rows whose mask is 0
-    are neither keys nor queries (their output rows are returned as zeros)."""
+    are neither keys nor queries (their output rows are returned as zeros).
+    `padded`: the saved activations (compact x rows, qkv, head outputs, log-sum-exp) are allocated at n*L rows with the R live
+    rows first and zeros behind -- static shapes for the dispatcher route, written in place (no copy into a padded tensor)."""
     x = _f32(x)
     n, L, D = x.shape
     idx, seg_off = _compact(mask)
     R = idx.numel()
-    xc = gather_rows(x.view(n * L, D), idx)
-    qkv = linear_fwd(xc, in_w, in_b)
-    o = torch.empty(R, D, dtype=torch.float32, device=x.device)
-    probs = torch.zeros(R, heads, L, dtype=torch.float32, device=x.device)   # slots past a segment's length are never written
-    call("lego_mhsa_core_fwd", _ptr(qkv), 3 * D, _ptr(seg_off), n, None, D, heads, _ptr(o), D, _ptr(probs), L,
+    cap = n * L if padded else R
+    alloc = torch.zeros if padded else torch.empty
+    f = dict(dtype=torch.float32, device=x.device)
+    xc_, qkv_, o_, lse_ = alloc(cap, D, **f), alloc(cap, 3 * D, **f), alloc(cap, D, **f), alloc(cap, heads, **f)
+    xc = gather_rows(x.view(n * L, D), idx, out=xc_[:R])
+    qkv = linear_fwd(xc, in_w, in_b, out=qkv_[:R])
+    o, lse = o_[:R], lse_[:R]
+    call("lego_mhsa_core_fwd", _ptr(qkv), 3 * D, _ptr(seg_off), n, None, D, heads, _ptr(o), D, _ptr(lse), None, L,
          _drop(drop), R, 0, None, None, _stream())
     yc = linear_fwd(o, out_w, out_b)
     y = torch.zeros(n * L, D, dtype=torch.float32, device=x.device)
     y.index_copy_(0, idx.long(), yc)
     ctx = _MhsaCtx()
-    ctx.xc, ctx.qkv, ctx.o, ctx.probs, ctx.idx, ctx.seg_off = xc, qkv, o, probs, idx, seg_off
+    ctx.xc, ctx.qkv, ctx.o, ctx.lse, ctx.idx, ctx.seg_off = xc, qkv, o, lse, idx, seg_off
+    ctx.saved = (xc_, qkv_, o_, lse_)
     ctx.in_w, ctx.out_w, ctx.heads, ctx.shape, ctx.drop = _f32(in_w), _f32(out_w), heads, (n, L, D), drop
     return y.view(n, L, D), ctx
 
@@ -266,7 +272,7 @@ def mhsa_bwd(ctx, gy):
     colsum(gyc, gout_b)
     go = linear_bwd_data(gyc, ctx.out_w)
     gqkv = torch.empty(R, 3 * D, dtype=torch.float32, device=dev)
-    call("lego_mhsa_core_bwd", _ptr(ctx.qkv), 3 * D, _ptr(ctx.seg_off), n, None, D, ctx.heads, _ptr(go), D, _ptr(ctx.probs), L,
+    call("lego_mhsa_core_bwd", _ptr(ctx.qkv), 3 * D, _ptr(ctx.seg_off), n, None, D, ctx.heads, _ptr(go), D, _ptr(ctx.lse), None, L,
          _drop(ctx.drop), R, _ptr(gqkv), 3 * D, None, 0, None, None, _stream())
     gin_w = torch.zeros(3 * D, D, dtype=torch.float32, device=dev)
     gin_b = torch.zeros(3 * D, dtype=torch.float32, device=dev)

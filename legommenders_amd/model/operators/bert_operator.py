@@ -204,7 +204,10 @@ class BertOperator(LMOperator, abc.ABC):
 
     @staticmethod
     def _trim(states, mask):
-        live = int(mask.sum(1).max().item()) if mask.numel() else 0
+        # cut behind the LAST live position of any row (not the live count: a mask that is not a prefix -- another inputer, left
+        # padding -- must not lose live tokens)
+        pos = torch.arange(1, mask.shape[1] + 1, device=mask.device)
+        live = int(((mask != 0) * pos).max().item()) if mask.numel() else 0
         live = max(1, min(int(mask.shape[1]), live))
         return states[:, :live], mask[:, :live]
 

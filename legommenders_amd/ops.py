@@ -288,16 +288,11 @@ register_autograd(f"{NS}::additive_pool", _add_bwd, setup_context=_add_setup)
 def mhsa(x: torch.Tensor, mask: torch.Tensor, in_w: torch.Tensor, in_b: torch.Tensor, out_w: torch.Tensor,
          out_b: torch.Tensor, heads: int, p: float, seed: int, site: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """nn.MultiheadAttention(q=k=v=x, key_padding_mask=1-mask) (model/operators/attention_operator.py:46-50): MFMA in/out
-    projections + the LDS-staged attention core.  Returns (y [n,L,D], compact x rows, qkv, head outputs, probabilities);
-    the saved activations hold the R live rows first and are padded to n*L rows, so every output shape is static."""
-    y, c = K.mhsa_fwd(x, mask, in_w, in_b, out_w, out_b, heads, drop=_drop(p, seed, site))
-    rows = x.shape[0] * x.shape[1]
-
-    def pad(t):
-        out = torch.zeros(rows, *t.shape[1:], dtype=t.dtype, device=t.device)
-        out[: t.shape[0]] = t
-        return out
-    return y, pad(c.xc), pad(c.qkv), pad(c.o), pad(c.probs)
+    projections + the attention core.  Returns (y [n,L,D], compact x rows, qkv, head outputs, log-sum-exp of the score rows);
+    the saved activations hold the R live rows first inside n*L-row buffers the kernels wrote in place, so every output shape
+    is static and nothing is copied (the probabilities are not saved: the backward pass recomputes them)."""
+    y, c = K.mhsa_fwd(x, mask, in_w, in_b, out_w, out_b, heads, drop=_drop(p, seed, site), padded=True)
+    return (y,) + c.saved
 
 
 @register_fake(f"{NS}::mhsa")
@@ -306,24 +301,24 @@ def _(x, mask, in_w, in_b, out_w, out_b, heads, p, seed, site):
     R = n * L
     f = dict(dtype=torch.float32)
     return (x.new_empty(n, L, D, **f), x.new_empty(R, D, **f), x.new_empty(R, 3 * D, **f), x.new_empty(R, D, **f),
-            x.new_empty(R, heads, L, **f))
+            x.new_empty(R, heads, **f))
 
 
 @_cuda("mhsa_bwd")
 def mhsa_bwd(gy: torch.Tensor, mask: torch.Tensor, in_w: torch.Tensor, out_w: torch.Tensor, xc: torch.Tensor,
-             qkv: torch.Tensor, o: torch.Tensor, probs: torch.Tensor, heads: int, p: float, seed: int,
+             qkv: torch.Tensor, o: torch.Tensor, lse: torch.Tensor, heads: int, p: float, seed: int,
              site: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     n, L, D = gy.shape
     c = K._MhsaCtx()
     c.idx, c.seg_off = K._compact(mask)
     R = c.idx.numel()
-    c.xc, c.qkv, c.o, c.probs = xc[:R], qkv[:R], o[:R], probs[:R]
+    c.xc, c.qkv, c.o, c.lse = xc[:R], qkv[:R], o[:R], lse[:R]
     c.in_w, c.out_w, c.heads, c.shape, c.drop = _f(in_w), _f(out_w), heads, (n, L, D), _drop(p, seed, site)
     return K.mhsa_bwd(c, _f(gy))
 
 
 @register_fake(f"{NS}::mhsa_bwd")
-def _(gy, mask, in_w, out_w, xc, qkv, o, probs, heads, p, seed, site):
+def _(gy, mask, in_w, out_w, xc, qkv, o, lse, heads, p, seed, site):
     f = dict(dtype=torch.float32)
     D = gy.shape[2]
     return (torch.empty_like(gy, **f), torch.empty_like(in_w, **f), in_w.new_empty(3 * D, **f), torch.empty_like(out_w, **f),
@@ -337,8 +332,8 @@ def _mhsa_setup(ctx, inputs, output):
 
 
 def _mhsa_bwd(ctx, gy, *unused):
-    mask, in_w, out_w, xc, qkv, o, probs = ctx.saved_tensors
-    gx, gin_w, gin_b, gout_w, gout_b = torch.ops.lego_hip.mhsa_bwd(gy.contiguous(), mask, in_w, out_w, xc, qkv, o, probs, *ctx.args)
+    mask, in_w, out_w, xc, qkv, o, lse = ctx.saved_tensors
+    gx, gin_w, gin_b, gout_w, gout_b = torch.ops.lego_hip.mhsa_bwd(gy.contiguous(), mask, in_w, out_w, xc, qkv, o, lse, *ctx.args)
     return gx, None, gin_w, gin_b, gout_w, gout_b, None, None, None, None
 
 

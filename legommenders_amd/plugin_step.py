@@ -20,6 +20,9 @@ class PluginStep:
                  tail: str = "keep"):
         from legommenders_amd.loader.env import Env
         from legommenders_amd import functional
+        if data.balance not in (None, int(B)):                               # see TrainStep.__init__: the dealing is built for one B
+            raise ValueError(f"DeviceData(balance={data.balance}) deals global batches of {data.balance} rows per rank; "
+                             f"the step was built with B={B}")
         functional.seed_streams(rank_seed(seed, data.rank))                 # dropout streams differ per rank
         self.schedule = BatchSchedule(data.n_rows, B, tail)
         self.steps_per_epoch = self.schedule.steps_per_epoch

@@ -212,6 +212,11 @@ class TrainStep:
                  glove: bool = True, process_group=None, world_size: int = 1, dropout: bool = True,
                  force_allreduce: bool = False, accumulate: int = 1, tail: str = "keep", rank: Optional[int] = None):
         dev = data.tables.title_tok.device
+        if data.balance not in (None, int(B)):
+            # the dealing and the sampler's position table are built for global batches of world * data.balance rows: with another
+            # B the local batches would no longer line up with one global batch (rows sharing sampler streams) -- and nothing would say so
+            raise ValueError(f"DeviceData(balance={data.balance}) deals global batches of {data.balance} rows per rank; "
+                             f"the step was built with B={B}")
         self.data, self.B, self.C, self.K = data, B, K + 1, K
         self.rank = data.rank if rank is None else int(rank)
         frozen = ("embedding_vocab_table.glove.embedding.weight",) if "embedding_vocab_table.glove.embedding.weight" in params else ()

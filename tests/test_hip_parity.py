@@ -977,7 +977,8 @@ def test_trainable_token_table_full_vocabulary():
 @pytest.mark.parametrize("hd,heads,p", [(32, 8, 0.0), (32, 8, 0.2), (16, 4, 0.1), (8, 2, 0.0), (64, 2, 0.3)])
 def test_mhsa_core_ragged_segments_with_dropout(hd, heads, p, listed):
     """lego_mhsa_core_fwd / _bwd against float64 autograd on ragged segments of 1..64 rows (both tile instantiations, empty segments,
-    the 32/33-row boundary).  With dropout on, the keep decisions are read back from the sign bits of the saved probabilities:
+    the 32/33-row boundary).  With dropout on, the keep decisions are read back from the sign bits of the forward's DEBUG probability output
+    (the backward pass gets only the log-sum-exp rows and must redraw the same mask):
     the forward output and all three gradients must be those of softmax(QK^T/sqrt(hd)) * keep / (1-p) @ V with exactly that mask,
     and the keep rate must be 1-p.  The fused in_proj_bias gradient (`colsum`) is the column sum of d(qkv)."""
     from legommenders_amd._lib import call
@@ -1001,13 +1002,32 @@ def test_mhsa_core_ragged_segments_with_dropout(hd, heads, p, listed):
         torch.cuda.synchronize()
         want_long = [i for i, L in enumerate(lens) if L > 32]
         assert int(lc) == len(want_long) and sorted(ll[:int(lc)].cpu().tolist()) == want_long
-    call("lego_mhsa_core_fwd", _ptr(qkv), 3 * D, _ptr(seg), n, None, D, heads, _ptr(out), D, _ptr(probs), Lmax, _drop(drop), R, part,
+    lse = torch.full((R, heads), float("nan"), device=dev)
+    call("lego_mhsa_core_fwd", _ptr(qkv), 3 * D, _ptr(seg), n, None, D, heads, _ptr(out), D, _ptr(lse), _ptr(probs), Lmax, _drop(drop), R, part,
          _ptr(ll), _ptr(lc), _stream())
+    out2, lse2 = torch.full((R, D), float("nan"), device=dev), torch.full((R, heads), float("nan"), device=dev)
+    call("lego_mhsa_core_fwd", _ptr(qkv), 3 * D, _ptr(seg), n, None, D, heads, _ptr(out2), D, _ptr(lse2), None, Lmax, _drop(drop), R, part,
+         _ptr(ll), _ptr(lc), _stream())                                # the product's call: no probability output
     gqkv = torch.full((R, 3 * D), float("nan"), device=dev)
     colsum = torch.zeros(3 * D, device=dev)
-    call("lego_mhsa_core_bwd", _ptr(qkv), 3 * D, _ptr(seg), n, None, D, heads, _ptr(go), D, _ptr(probs), Lmax, _drop(drop), R,
+    probs_fwd = probs.clone()
+    probs.fill_(float("nan"))                        # the backward pass must not need them: it recomputes p from Q, K and lse
+    call("lego_mhsa_core_bwd", _ptr(qkv), 3 * D, _ptr(seg), n, None, D, heads, _ptr(go), D, _ptr(lse), None, Lmax, _drop(drop), R,
          _ptr(gqkv), 3 * D, _ptr(colsum), part, _ptr(ll), _ptr(lc), _stream())
+    # ... and the other mode: the saved probabilities, no lse, no random numbers (drop only carries p for the rescale)
+    gqkv_sv, colsum_sv = torch.full((R, 3 * D), float("nan"), device=dev), torch.zeros(3 * D, device=dev)
+    call("lego_mhsa_core_bwd", _ptr(qkv), 3 * D, _ptr(seg), n, None, D, heads, _ptr(go), D, None, _ptr(probs_fwd), Lmax,
+         _drop((p, 1, 1)) if p > 0 else None, R, _ptr(gqkv_sv), 3 * D, _ptr(colsum_sv), part, _ptr(ll), _ptr(lc), _stream())
     torch.cuda.synchronize()
+    probs = probs_fwd
+    assert torch.equal(out, out2) and torch.equal(lse, lse2)
+    # lse = log sum_j exp(q_i . k_j / sqrt(hd)) per (row, head)
+    q3 = qkv.cpu().double().view(R, 3, heads, hd)
+    for s_, L_ in enumerate(lens):
+        if L_:
+            b_ = int(seg[s_])
+            sc = torch.einsum("ihd,jhd->hij", q3[b_:b_ + L_, 0], q3[b_:b_ + L_, 1]) / hd ** 0.5
+            np.testing.assert_allclose(lse[b_:b_ + L_].cpu().double().numpy(), torch.logsumexp(sc, 2).t().numpy(), rtol=2e-5, atol=2e-5)
     pr, q64, g64 = probs.cpu().double().reshape(-1), qkv.cpu().double(), go.cpu().double()
     kept = total = 0
     exp_out, exp_g = torch.zeros(R, D, dtype=torch.float64), torch.zeros(R, 3 * D, dtype=torch.float64)
@@ -1031,6 +1051,8 @@ def test_mhsa_core_ragged_segments_with_dropout(hd, heads, p, listed):
     _close(out.cpu(), exp_out, rtol=2e-5, what="core out")
     _close(gqkv.cpu(), exp_g, rtol=5e-5, what="core d(qkv)")
     _close(colsum.cpu(), exp_g.sum(0), rtol=5e-5, what="fused in_proj_bias gradient")
+    _close(gqkv_sv.cpu(), exp_g, rtol=5e-5, what="core d(qkv), saved probabilities")
+    _close(colsum_sv.cpu(), exp_g.sum(0), rtol=5e-5, what="fused in_proj_bias gradient, saved probabilities")
     if p > 0:
         assert abs(kept / total - (1 - p)) < 0.01, kept / total
 

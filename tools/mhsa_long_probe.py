@@ -11,7 +11,7 @@ for k in (1, 8, 60, 480, 1500):
     seg = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device=dev)
     R = int(lens.sum())
     qkv, go = torch.randn(R, 3 * D, device=dev), torch.randn(R, D, device=dev)
-    out, gq, probs = torch.empty(R, D, device=dev), torch.empty(R, 3 * D, device=dev), torch.zeros(R, heads, Lmax, device=dev)
+    out, gq, lse = torch.empty(R, D, device=dev), torch.empty(R, 3 * D, device=dev), torch.zeros(R, heads, device=dev)
     ll, lc = torch.zeros(n, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
     call("lego_mhsa_long_segments", _ptr(seg), n, None, _ptr(ll), _ptr(lc), _stream())
     dr = _drop((0.1, 5, 3))
@@ -26,6 +26,6 @@ for k in (1, 8, 60, 480, 1500):
     for part, name in ((2, "long"), (1, "short")):
         for lst in ((None, None), (_ptr(ll), _ptr(lc))):
             if part == 1 and lst[0] is not None: continue
-            f = t(lambda: call("lego_mhsa_core_fwd", _ptr(qkv), 3 * D, _ptr(seg), n, None, D, heads, _ptr(out), D, _ptr(probs), Lmax, dr, R, part, *lst, _stream()))
-            b = t(lambda: call("lego_mhsa_core_bwd", _ptr(qkv), 3 * D, _ptr(seg), n, None, D, heads, _ptr(go), D, _ptr(probs), Lmax, dr, R, _ptr(gq), 3 * D, None, part, *lst, _stream()))
+            f = t(lambda: call("lego_mhsa_core_fwd", _ptr(qkv), 3 * D, _ptr(seg), n, None, D, heads, _ptr(out), D, _ptr(lse), None, Lmax, dr, R, part, *lst, _stream()))
+            b = t(lambda: call("lego_mhsa_core_bwd", _ptr(qkv), 3 * D, _ptr(seg), n, None, D, heads, _ptr(go), D, _ptr(lse), None, Lmax, dr, R, _ptr(gq), 3 * D, None, part, *lst, _stream()))
             print(f"k={k:5d} {name:5s} {'listed' if lst[0] is not None else 'ballot':6s} fwd {f:7.1f} us  bwd {b:7.1f} us")
