@@ -26,6 +26,7 @@ steps / ms so the driver's wall clock still bounds them):
                      50, every title 30 tokens) and a world with MIND-like length statistics are NOT the metric; they are printed so that the number's dependence
                      on the model and on raggedness is on record
   allreduce_ms       (N > 1 or --force-dist) one RCCL all-reduce of the flat gradient buffer, timed alone
+  dist_path_check    (N = 1) the same on a one-rank RCCL communicator created after the timed region: all-reduce alone + 100 steps with it
   cpu_baseline       the oracle's port of the reference CPU training step on the host cores
 """
 from __future__ import annotations
@@ -64,7 +65,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the long run and the secondary configurations")
     ap.add_argument("--no-bert", action="store_true", help="skip the BERT-base secondary line (config 5)")
-    ap.add_argument("--cpu-steps", type=int, default=12)
+    ap.add_argument("--cpu-steps", type=int, default=20, help="timed CPU-baseline steps (after 3 warm-up steps; BASELINE.md section 3)")
+    ap.add_argument("--no-dist-check", action="store_true", help="N = 1: skip the one-rank RCCL path check after the timed region")
     ap.add_argument("--time-every", type=int, default=4, help="bracket the roofline kernel and the in-step gather with HIP events every N-th timed step")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even at world size 1 (path check)")
     ap.add_argument("--no-balance", action="store_true", help="N > 1: deal rows r::W instead of by live-row cost (A/B)")
@@ -105,7 +107,7 @@ def pmc_traffic():
     return {k: v.get("hbm_bytes_per_launch") for k, v in d["kernels"].items()}, src
 
 
-def cpu_baseline(world, B, D, steps):
+def cpu_baseline(world, B, D, steps, with_config1=True):
     """Oracle port of the reference's `--cuda -1` NAML training step, timed on this host's cores."""
     import numpy as np
     from oracle import lego_oracle as O
@@ -130,16 +132,41 @@ def cpu_baseline(world, B, D, steps):
         cand = np.concatenate([world["row_item"][rows][:, None], rs.randint(0, world["n_items"], size=(B, 4))], 1)
         return (torch.from_numpy(cand.astype("int64")), torch.from_numpy(world["user_hist"][u].astype("int64")),
                 torch.from_numpy(world["user_hist_len"][u].astype("int64")))
-    O.naml_train_step_cpu(P, opt, tt, ct, *batch())            # warm-up (thread pools, mkldnn primitives)
+    warm = 3
+    for _ in range(warm):                                      # warm-up (thread pools, mkldnn primitives)
+        O.naml_train_step_cpu(P, opt, tt, ct, *batch())
     t0 = time.perf_counter()
     for _ in range(steps):
         O.naml_train_step_cpu(P, opt, tt, ct, *batch())
     dt = time.perf_counter() - t0
-    return {"value": round(B * steps / dt, 2), "unit": "impressions/s", "cores": cores, "host_cores": host, "kind": "port",
-            "sample": f"{steps} training steps (fwd+bwd+Adam, dropout on) of B={B} NAML hidden={D}, DENSE reference layout "
-                      f"(all 50 history slots x 30 title positions, as the reference computes), on the same synthetic "
-                      f"MIND-small-shaped world after 1 warm-up step; torch {torch.__version__} CPU, {cores} of {host} "
-                      f"host threads (the GPU path skips pad rows; it is timed on the ragged layout)"}
+    out = {"value": round(B * steps / dt, 2), "unit": "impressions/s", "cores": cores, "host_cores": host, "kind": "port",
+           "sample": f"{steps} training steps (fwd+bwd+Adam, dropout on) of B={B} NAML hidden={D}, DENSE reference layout "
+                     f"(all 50 history slots x 30 title positions, as the reference computes), on the same synthetic "
+                     f"MIND-small-shaped world after {warm} warm-up steps; torch {torch.__version__} CPU, {cores} of {host} "
+                     f"host threads (the GPU path skips pad rows; it is timed on the ragged layout)"}
+    if with_config1:
+        # BASELINE config 1 (the reference's own CPU-runnable case): NAML hidden=64 bs=32, same world, same port
+        B1, D1 = 32, 64
+        P1 = init_naml_params(D=D1, V=world["V"], n_cat=world["n_cat"], glove=P["embedding_vocab_table.glove.embedding.weight"])
+        tr1 = []
+        for k, v in P1.items():
+            if not k.endswith("glove.embedding.weight"):
+                v.requires_grad_(True)
+                tr1.append(v)
+        opt1 = torch.optim.Adam(tr1, lr=1e-3)
+
+        def batch1():
+            c, h, hl = batch()
+            return c[:B1], h[:B1], hl[:B1]
+        for _ in range(warm):
+            O.naml_train_step_cpu(P1, opt1, tt, ct, *batch1())
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            O.naml_train_step_cpu(P1, opt1, tt, ct, *batch1())
+        d1 = time.perf_counter() - t0
+        out["config1"] = {"value": round(B1 * steps / d1, 2), "unit": "impressions/s", "cores": cores,
+                          "sample": f"{steps} training steps of B={B1} NAML hidden={D1} (BASELINE config 1), after {warm} warm-up steps"}
+    return out
 
 
 def dense_world(world):
@@ -210,6 +237,7 @@ def tagged_steps(ts, steps, barrier):
     ts.engine.timers = None
     cs = ts.counter_sum.tolist()
     tagged_steps.uniq = cs[6] / steps
+    tagged_steps.hist = cs[3] / steps                       # clicked-item instances (the user side's rows)
     return timers, cs[0] / steps, cs[1] / steps
 
 
@@ -290,7 +318,7 @@ def main():
     glove = glove_like(cfg["V"], 300, seed=2024, device=dev)
     B, D, E0 = args.batch, args.hidden, 300
 
-    def make_ts(kind, d, force=False, embed="glove"):
+    def make_ts(kind, d, force=False, embed="glove", pg=pg):
         init = init_naml_params if kind == "naml" else init_nrms_params
         use_glove = not (kind == "nrms" and embed == "null")
         params = init(D=D, V=cfg["V"], n_cat=cfg["n_cat"], glove=glove if use_glove else None)
@@ -370,6 +398,9 @@ def main():
     else:
         solo, wino = ("qkv_fwd_item", "out_proj_fwd_item", "linear_fwd_item", "outlin_fwd_item", "additive_fwd_item"), ()
     price(kern, flops_for(rows_tab, inst_tab, uniq_tab if dedup else None), wino)
+    if args.model == "naml":
+        price(kern, naml_small_flops(tagged_steps.hist, D), ())
+        price_hbm(kern, naml_stream_bytes(rows_tab, inst_tab, uniq_tab if dedup else rows_tab, D))
     flops = flops_for(rows_per_launch, inst_per_launch, uniq_per_launch if dedup else None)
     price(kern_in, flops, wino)
     if args.model == "nrms":
@@ -389,10 +420,14 @@ def main():
     if gather_ms:
         gbytes = gather_rows * E0 * 4 * 2 + gather_rows * 4     # row read + row write + index
         gbs = gbytes / (gather_ms * 1e-3) / 1e9
-        roofline_gather = {"kernel": "gather_rows", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
-                           "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic.get("gather_rows"),
-                           "avg_launch_ms": round(gather_ms, 5), "timed": "20 back-to-back launches of one plan after the timed "
-                           "region: cache-assisted (the PMC pass shows a third of the row reads reaching HBM)",
+        # `frac` / `achieved` are the IN-STEP figures (set below from the HIP events on the prefetch stream inside the timed region):
+        # the launch as the training step really runs it.  The back-to-back repeat of one plan is cache-assisted (the PMC pass shows a
+        # third of its row reads reaching HBM) and is kept beside it as `*_back_to_back` -- it is not an HBM fraction
+        roofline_gather = {"kernel": "gather_rows", "bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS,
+                           "unit": "GB/s", "frac": None, "traffic": traffic.get("gather_rows"),
+                           "achieved_back_to_back": round(gbs, 1), "frac_back_to_back": round(gbs / PEAK_HBM_GBS, 4),
+                           "avg_launch_ms_back_to_back": round(gather_ms, 5), "timed_back_to_back": "20 back-to-back launches of one plan "
+                           "after the timed region: cache-assisted (the PMC pass shows a third of the row reads reaching HBM)",
                            "algorithmic_bytes_per_launch": gbytes, "rows_gathered_per_launch": gather_rows,
                            "dense_reference_bytes_per_launch": B * 55 * 30 * 1200}
         ins = kern.get("gather_rows_in_step")
@@ -400,7 +435,11 @@ def main():
             b_in = uniq_per_launch * (E0 * 4 * 2 + 4)
             g_in = b_in / (ins["avg_ms"] * 1e-3) / 1e9
             g_rd = uniq_per_launch * E0 * 4 / (ins["avg_ms"] * 1e-3) / 1e9        # the row READS only
-            roofline_gather.update({"achieved_in_step": round(g_in, 1), "frac_in_step": round(g_in / PEAK_HBM_GBS, 4),
+            roofline_gather.update({"achieved": round(g_in, 1), "frac": round(g_in / PEAK_HBM_GBS, 4), "avg_launch_ms": round(ins["avg_ms"], 5),
+                                    "algorithmic_bytes_per_launch": int(b_in),
+                                    "note": "an 11 MB, ~14 us launch after the token de-duplication (4.5 k distinct rows of 1200 B): latency-bound, "
+                                            "far below the HBM roof by construction; the dense reference would move 127 MB here",
+                                    "achieved_in_step": round(g_in, 1), "frac_in_step": round(g_in / PEAK_HBM_GBS, 4),
                                     "achieved_reads_only_in_step": round(g_rd, 1),
                                     "frac_reads_only_in_step": round(g_rd / PEAK_HBM_GBS, 4),
                                     "avg_launch_ms_in_step": round(ins["avg_ms"], 5), "launches_in_step": ins["launches"],
@@ -464,6 +503,30 @@ def main():
             "kernels": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in k2.items()}}
         del t2
         torch.cuda.empty_cache()
+        # config 3, the OTHER embedding variant (config/embed/null.yaml): trainable [V, D] token table -- its row gather (three summed
+        # look-ups in one pass, 1 KB rows) sits on the step's critical path and is the HBM-bound launch of this variant
+        if other == "nrms":
+            tn = make_ts("nrms", data, embed="null")
+            dn, _, _ = timed_steps(tn, 60, 10, barrier)
+            cn = tn.counter_sum.tolist()
+            tmn, rn, _ = tagged_steps(tn, 8, barrier)
+            kn = kernel_table(tmn)
+            price(kn, nrms_flops(rn, D, E0), ())
+            price_hbm(kn, nrms_core_bytes(rn, D))
+            gb = rn * (D * 4.0 * 2 + 16.0)                     # table row read + E row written + three index words and the token info
+            price_hbm(kn, {"embed_gather_item": gb})
+            g = kn.get("embed_gather_item", {})
+            sec[f"nrms_null_hidden{D}_bs{B}"] = {
+                "workload": f"MIND-small-shaped NRMS hidden={D} bs={B}, trainable 400k x {D} token table (embed/null), full train step",
+                "steps": 60, "warmup": 10, "ms_per_step": round(dn / 60 * 1e3, 4), "value": round(B * 60 / dn, 1), "unit": "impressions/s",
+                "live_token_rows_per_step": round(cn[0] / 60, 1),
+                "roofline_gather": {"kernel": "embed_gather_item (lego_expand_rows: token + [SEP] + category look-ups summed in one pass)",
+                                    "bound": "hbm", "achieved": round(g.get("gb_per_s", 0.0), 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                    "frac": round(g.get("frac_of_hbm_peak", 0.0), 4), "avg_launch_ms": round(g.get("avg_ms", 0.0), 5),
+                                    "algorithmic_bytes_per_launch": int(gb), "timed": "HIP events on the main stream, 8 steps after the timed ones"},
+                "kernels": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kn.items()}}
+            del tn
+            torch.cuda.empty_cache()
         # worst case for the ragged plan: nothing to skip
         dd = DeviceData(dense_world(world), dev, seed=2023)
         t3 = make_ts("naml", dd)
@@ -514,6 +577,8 @@ def main():
                                          f"5 000-item world, full plug-in train step (device sampler ids, fwd, bwd, torch Adam), fp32")
         extra["secondary"] = sec
 
+    if world_size == 1 and not dist_on and not args.no_dist_check and not args.small:
+        extra["dist_path_check"] = dist_path_check(make_ts, args, data, dev, barrier, B)
     if rank != 0:
         if dist_on:
             torch.distributed.destroy_process_group()
@@ -552,6 +617,50 @@ def main():
         torch.distributed.destroy_process_group()
 
 
+def dist_path_check(make_ts, args, data, dev, barrier, B):
+    """N = 1, after everything that is timed: the data-parallel step's own code path on a ONE-rank RCCL communicator -- communicator
+    creation, the flat gradient buffer's all-reduce (timed alone, 20 launches) and 100 training steps with the all-reduce in them
+    (`TrainStep(force_allreduce=True)`).  A path check, not a scaling number: one rank moves no bytes over xGMI.  A failure is recorded
+    as text and does not take the metric line with it."""
+    out = {"backend": "nccl (RCCL)", "world": 1}
+    try:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        pg = torch.distributed.group.WORLD
+        ts = make_ts(args.model, data, force=True, embed=args.embed, pg=pg)
+        for _ in range(10):
+            ts.step()
+        barrier()
+        t0 = time.perf_counter()
+        n = 100
+        for _ in range(n):
+            ts.step()
+        barrier()
+        dt = time.perf_counter() - t0
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ts.sync_gradients()
+        barrier()
+        a.record()
+        for _ in range(20):
+            ts.sync_gradients()
+        b.record()
+        torch.cuda.synchronize()
+        out.update({"allreduce_ms": round(a.elapsed_time(b) / 20, 4), "allreduce_bytes": ts.fp.numel * 4,
+                    "steps_with_allreduce": n, "ms_per_step_with_allreduce": round(dt / n * 1e3, 4),
+                    "value_with_allreduce": round(B * n / dt, 1), "ok": True})
+        del ts
+        torch.distributed.destroy_process_group()
+    except Exception as exc:                       # noqa: BLE001 -- recorded, the metric line stands
+        out.update({"ok": False, "error": f"{type(exc).__name__}: {exc}"[:300]})
+        try:
+            if torch.distributed.is_initialized():
+                torch.distributed.destroy_process_group()
+        except Exception:
+            pass
+    return out
+
+
 def step_roofline(model, flops, step_s, rows, D, E0, wino):
     """the whole step against the fp32 matrix peak: ALGORITHMIC flops of its products (every token row projected, the
     direct conv's 2*3*D*D per row) over the measured step time, and beside it the flops the kernels ISSUE (projection once per
@@ -575,6 +684,19 @@ def nrms_flops(rows, D, E0):
             "outlin_fwd_item": 2.0 * rows * D * D,       # out-projection and Linear folded into one product (engine.py, fold_linear)
             "additive_fwd_item": 2.0 * rows * D * 256,      # fold level 2: the only product over the rows between the core and the pool
             }
+
+
+def naml_small_flops(hist_rows, D, A=256):
+    """the user-side additive products (rows = clicked-item instances of the batch, ~1.3 k): latency-bound launches, priced all the same"""
+    return {"additive_fwd_user": 2.0 * hist_rows * D * A, "additive_bwd_weight_user": 2.0 * hist_rows * D * A}
+
+
+def naml_stream_bytes(rows, inst, uniq, D):
+    """algorithmic HBM bytes of the streaming kernels of the de-duplicated projection: the expansion H[r] = drop(Hu[inv[r]]) reads the
+    distinct rows (L2-resident), an index and a keep byte per 4 rows and writes one D-row per token row; the per-token sums read
+    every dH row once (through the sort permutation) and write one row per distinct token"""
+    return {"proj_expand": uniq * D * 4.0 + rows * (D * 4.0 + 4.0 + D / 4.0),
+            "proj_bwd_segsum": rows * (D * 4.0 + 8.0) + uniq * D * 4.0}
 
 
 def nrms_core_bytes(rows, D, heads=8, Lbar=21):

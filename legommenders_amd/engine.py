@@ -1188,9 +1188,11 @@ class NrmsEngine(_Base):
             # trainable table (embed/null): the three look-ups ConcatInputer sums (concat_inputer.py:96-114) in ONE pass over the sequence
             # rows -- token row where the position holds a token (tokinfo's live bit; idx_tok is -1 elsewhere and not read), plus the
             # special-id and category rows where those indices are >= 0
-            call("lego_expand_rows", _ptr(P["embedding_vocab_table.glove.weight"]), D, _ptr(self.idx_tok), self.Rc, self.cnt(0), D, None,
-                 _ptr(self.tokinfo), _ptr(P["embedding_vocab_table.__cat_inputer_special_ids.weight"]), D, _ptr(self.idx_spec),
-                 _ptr(P["embedding_vocab_table.category.weight"]), D, _ptr(self.idx_cat), _ptr(self.E), D, st)
+            # (tagged: bench.py prices this launch -- the trainable table's row gather, on the step's critical path -- against the HBM roof)
+            self.kk(torch.cuda.current_stream(), "embed_gather_item", "lego_expand_rows", _ptr(P["embedding_vocab_table.glove.weight"]), D,
+                    _ptr(self.idx_tok), self.Rc, self.cnt(0), D, None,
+                    _ptr(self.tokinfo), _ptr(P["embedding_vocab_table.__cat_inputer_special_ids.weight"]), D, _ptr(self.idx_spec),
+                    _ptr(P["embedding_vocab_table.category.weight"]), D, _ptr(self.idx_cat), _ptr(self.E), D)
             self._att_fwd("item_op.", self.item_ws, _ptr(self.E), self.cnt(0), self.seg_off, self.NIc, self.cnt(1),
                           self.items, SITE_ITEM_ATT, training, st)
             return

@@ -49,7 +49,7 @@ METRICS = ["GAUC", "NDCG@10", "MRR"]
 CACHE = os.environ.get("LEGO_BAND_CACHE", "/tmp/lego_band_cache")     # one json per (band, seed): the generator is resumable
 
 
-def build(kind, w, seed):
+def build(kind, w, seed, pretrained=True):
     """Manager.__init__ order (loader/manager.py:139-153,294-326) on duck-typed tables of the learnable world"""
     from loader.env import Env
     Env.device = torch.device("cpu")
@@ -101,9 +101,11 @@ def build(kind, w, seed):
     lc.set_column_map(ColumnMap(item_col="item_id", user_col="user_id", history_col="history", neg_col="neg",
                                 label_col="click", group_col="user_id"))
     eh = EmbeddingHub(embedding_dim=D, transformation="auto", transformation_dropout=p)
-    path = "/tmp/_band_glove_%d_%d_%d.npy" % (HYPER["glove_seed"], w["V"], os.getpid())
-    np.save(path, glove_table_np(HYPER["glove_seed"], w["V"]))
-    eh.load_pretrained_embedding(path, vocab_name="glove", frozen=True)
+    if pretrained:                                # else (config/embed/null.yaml): a trainable nn.Embedding(V, D) token table
+        path = "/tmp/_band_glove_%d_%d_%d.npy" % (HYPER["glove_seed"], w["V"], os.getpid())
+        np.save(path, glove_table_np(HYPER["glove_seed"], w["V"]))
+        eh.load_pretrained_embedding(path, vocab_name="glove", frozen=True)
+        os.remove(path)
     eh.register_ut(item_ut, ["title@glove", "category"])
     lc.set_embedding_hub(eh)
     lc.build_components()
