@@ -200,8 +200,9 @@ int lego_additive_pool_bwd_fold(float* scratch, int A, float* gw2, float* gb1, v
 int lego_dot_ce_fwd(const float* user /*[B,D]*/, int ldu, const float* items /*[B*C,D]*/, int ldi,
                     int B, int C, int D, float* scores /*[B,C]*/, float* loss /*[1], +=mean*/, void* stream);
 int lego_dot_ce_bwd(const float* user, int ldu, const float* items, int ldi, const float* scores,
-                    int B, int C, int D, float gscale /*dloss * 1/B*/, float* guser, int ldgu,
-                    float* gitems, int ldgi, void* stream);
+                    int B, int C, int D, float gscale /*dloss * 1/B*/,
+                    const float* gscale_dev /*nullable [1]: multiplied into gscale ON THE DEVICE -- autograd's upstream gradient of the loss
+                    without a host read*/, float* guser, int ldgu, float* gitems, int ldgi, void* stream);
 
 /* ---- a7 + a9 + a10 fused for TRAINING: AdaOperator pool over each user's clicked-item vectors (rows
  * items[B*C + hist_off[b] ..]), dot scores against the user's C candidates (rows items[b*C ..]), CE(label 0), the

@@ -68,7 +68,7 @@ SIGNATURES = {
     "lego_additive_pool_bwd_fold": [P, I, P, P, P],
     "lego_additive_pool_bwd": [P, I, P, I, P, P, P, I, P, I, I, P, I, P, P, I, P, P, P, P],
     "lego_dot_ce_fwd": [P, I, P, I, I, I, I, P, P, P],
-    "lego_dot_ce_bwd": [P, I, P, I, P, I, I, I, F, P, I, P, I, P],
+    "lego_dot_ce_bwd": [P, I, P, I, P, I, I, I, F, P, P, I, P, I, P],
     "lego_mhsa_long_segments": [P, I, P, P, P, P],
     "lego_mhsa_core_fwd": [P, I, P, I, P, I, I, P, I, P, P, I, P, I, I, P, P, P],
     "lego_mhsa_core_bwd": [P, I, P, I, P, I, I, P, I, P, P, I, P, I, P, I, P, I, P, P, P],

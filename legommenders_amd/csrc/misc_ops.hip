@@ -1169,10 +1169,12 @@ __global__ __launch_bounds__(256) void dot_ce_fwd_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void dot_ce_bwd_kernel(const float* __restrict__ user, int ldu,
                                                          const float* __restrict__ items, int ldi,
                                                          const float* __restrict__ scores, int B, int C, int D, float gscale,
+                                                         const float* __restrict__ gscale_dev,
                                                          float* __restrict__ guser, int ldgu, float* __restrict__ gitems, int ldgi) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
+    if (gscale_dev != nullptr) gscale *= *gscale_dev;          // the upstream gradient of the loss, read on the device (no host sync)
     const float mine = lane < C ? scores[b * C + lane] : -INFINITY;
     float mx = mine;
 #pragma unroll
@@ -1904,10 +1906,11 @@ extern "C" int lego_dot_ce_fwd(const float* user, int ldu, const float* items, i
     return check_launch("lego_dot_ce_fwd");
 }
 extern "C" int lego_dot_ce_bwd(const float* user, int ldu, const float* items, int ldi, const float* scores,
-                               int B, int C, int D, float gscale, float* guser, int ldgu, float* gitems, int ldgi, void* stream) {
+                               int B, int C, int D, float gscale, const float* gscale_dev, float* guser, int ldgu, float* gitems, int ldgi,
+                               void* stream) {
     LEGO_REQUIRE(C <= kMaxCand && (D & 3) == 0 && D <= 256 * kMaxChunks, "lego_dot_ce_bwd: C=%d D=%d unsupported", C, D);
     if (B <= 0) return 0;
-    hipLaunchKernelGGL(dot_ce_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, user, ldu, items, ldi, scores, B, C, D, gscale,
+    hipLaunchKernelGGL(dot_ce_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, user, ldu, items, ldi, scores, B, C, D, gscale, gscale_dev,
                        guser, ldgu, gitems, ldgi);
     return check_launch("lego_dot_ce_bwd");
 }

@@ -556,8 +556,10 @@ class NamlEngine(_Base):
                 _ptr(seg_off), None, extra, n_cap, n_dyn, D, A, _ptr(out), D, _ptr(wrow))
 
     # ------------------------------------------------------------------ backward
-    def backward(self, G: Dict[str, torch.Tensor], gloss: float = 1.0):
-        """Accumulates d(loss)/d(param) into G (reference key names); call after forward(training...)."""
+    def backward(self, G: Dict[str, torch.Tensor], gloss: float = 1.0, gloss_dev: Optional[torch.Tensor] = None):
+        """Accumulates d(loss)/d(param) into G (reference key names); call after forward(training...).
+        `gloss_dev`: a one-element device tensor multiplied into the loss gradient ON THE DEVICE (autograd's upstream gradient:
+        `Legommender`'s engine route passes it instead of reading it on the host, which would be a device sync per backward)."""
         P, B, C, S, D, A, E0 = self.P, self.nb, self.C, self.S, self.D, self.A, self.E0
         m, sb, sc = self._lanes()
         ev = self._evs
@@ -568,11 +570,11 @@ class NamlEngine(_Base):
         hist_items = _ptr(self.items, self.BC * D)
         d_hist_items = _ptr(self.d_items, self.BC * D)
         if getattr(self, "_fused", False):
-            if G is not self.fused_grads or abs(float(gloss) - self._fused_gloss) > 0:
+            if G is not self.fused_grads or abs(float(gloss) - self._fused_gloss) > 0 or gloss_dev is not None:
                 raise _lib.LegoHipError("fused user tower: backward() must use the bound gradient buffers and the forward's gloss")
         else:
             self.kk(m, None, "lego_dot_ce_bwd", _ptr(self.user), D, _ptr(self.items), D, _ptr(self.scores), B, C, D,
-                    float(gloss) / B, _ptr(self.d_user), D, _ptr(self.d_items), D)
+                    float(gloss) / B, _ptr(gloss_dev), _ptr(self.d_user), D, _ptr(self.d_items), D)
             self._pool_bwd(m, "user_op.", G, hist_items, d_hist_items, self.Tu, self.Au, self.hist_off, None, B, None,
                            self.d_user, self.wu)
             self._pool_fold(m, "user_op.", G, self.Au)
@@ -1214,18 +1216,19 @@ class NrmsEngine(_Base):
         self._att_fwd("user_op.", self.user_ws, _ptr(self.items, self.BC * self.D), self.cnt(3), self.hist_off, self.nb, None,
                       self.user, SITE_USER_ATT, training, _stream(), head=head)
 
-    def backward(self, G, gloss: float = 1.0):
+    def backward(self, G, gloss: float = 1.0, gloss_dev: Optional[torch.Tensor] = None):
         P, B, C, S, D = self.P, self.nb, self.C, self.S, self.D
         st = _stream()
         training = self._training
         step_save = self.step
         if training:
             self.step -= 1
-        head = self._head_done and float(gloss) == 1.0     # forward's fused head already holds d_user, d_items (candidates), d_pooled
+        # forward's fused head already holds d_user, d_items (candidates), d_pooled -- for a unit loss gradient known on the host
+        head = self._head_done and float(gloss) == 1.0 and gloss_dev is None
         self._head_done = False
         if not head:
             call("lego_dot_ce_bwd", _ptr(self.user), D, _ptr(self.items), D, _ptr(self.scores), B, C, D,
-                 float(gloss) / B, _ptr(self.d_user), D, _ptr(self.d_items), D, st)
+                 float(gloss) / B, _ptr(gloss_dev), _ptr(self.d_user), D, _ptr(self.d_items), D, st)
         self._have_d_pooled = head
         m, sw = self._side()
         sev = self._sev if sw is not m else [None] * 6

@@ -190,7 +190,7 @@ def dot_ce_bwd(user, items, scores, gloss=1.0):
     it = items.reshape(B * C, D)
     gu = torch.empty_like(user)
     gi = torch.empty_like(it)
-    call("lego_dot_ce_bwd", _ptr(user), D, _ptr(it), D, _ptr(scores), B, C, D, float(gloss) / B, _ptr(gu), D, _ptr(gi), D, _stream())
+    call("lego_dot_ce_bwd", _ptr(user), D, _ptr(it), D, _ptr(scores), B, C, D, float(gloss) / B, None, _ptr(gu), D, _ptr(gi), D, _stream())
     return gu, gi.view(B, C, D)
 
 

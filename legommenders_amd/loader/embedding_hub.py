@@ -34,8 +34,8 @@ class Transformation(nn.Module):
         self.dropout = nn.Dropout(transformation_dropout)
 
     def forward(self, indexes):
-        if self.embedding.weight.requires_grad:
-            raise NotImplementedError("un-frozen pre-trained tables are outside the MI355X hot path (SURVEY.md 8a4)")
+        # frozen=False (embedding_hub.py:171,262): the table's weight requires grad and the op's autograd formula adds the dense
+        # table gradient (glove_project_bwd_table); such a model trains through the plug-in route (trainer.build_model)
         return F_hip.glove_project(indexes, self.embedding.weight, self.linear.weight, self.linear.bias,
                                    p=self.dropout.p, training=self.training)
 

@@ -52,7 +52,8 @@ class _EngineStep(torch.autograd.Function):
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
                 G[name] = p.grad
-        model.engine.backward(G, gloss=float(g))
+        # the upstream gradient of the loss stays on the device (float(g) would be a host sync in every backward)
+        model.engine.backward(G, gloss=1.0, gloss_dev=g.detach().reshape(-1)[:1].to(torch.float32).contiguous())
         return torch.zeros_like(model._anchor), None, None, None, None, None, None
 
 

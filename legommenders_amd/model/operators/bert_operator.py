@@ -17,7 +17,13 @@ a CPU tensor and copies the batch's rows to the device every step; here it lives
 MIND-small at BERT-base width, of 288 GB) and the per-batch look-up is a device gather.  The on-disk layout
 `cache/<data>/<operator>/layer_k.npy` + `mask.npy` is read when present and written after a build
 (`LEGO_LAYER_CACHE_SAVE=0` skips the write), so caches made by the reference's splitter.py are usable.
-LoRA (needs `peft`) is not built and says so."""
+LoRA (`use_lora: true`, once_operator.py:27-38,137-151 through `peft.get_peft_model(self.transformer.encoder, LoraConfig(r, lora_alpha,
+lora_dropout))`, bert_operator.py:26-28): `peft` is not in this image, so its published algorithm is restated natively
+(`LoraLinear`, `_LoraEncoder`): peft's default targets for model_type "bert" are the `query` and `value` projections of every kept
+block; each becomes y = base(x) + (alpha / r) * B(A(dropout(x))) with A ~ kaiming_uniform(a = sqrt(5)), B = 0, every other encoder
+parameter frozen; the module tree (and so the state_dict keys) is peft's: `encoder.base_model.model.layer.N.attention.self.query.
+{base_layer.weight, base_layer.bias, lora_A.default.weight, lora_B.default.weight}`.  Parity for this piece is held against the
+oracle's restatement only (no peft to generate a fixture from: stated in DESIGN.md)."""
 import abc
 import os
 
@@ -45,6 +51,60 @@ class OnceOperatorConfig(AdaOperatorConfig):
         self.lora_r = lora_r
         self.lora_dropout = lora_dropout
         self.transformer_config = transformer_config
+
+
+class LoraLinear(nn.Module):
+    """peft.tuners.lora.Linear restated: the frozen base layer plus a rank-r update, scaled by alpha / r."""
+
+    def __init__(self, base: nn.Linear, r: int, alpha: int, dropout: float):
+        super().__init__()
+        import math
+        self.base_layer = base
+        self.r, self.scaling = int(r), float(alpha) / float(r)
+        self.lora_dropout = nn.ModuleDict({"default": nn.Dropout(dropout) if dropout > 0.0 else nn.Identity()})
+        self.lora_A = nn.ModuleDict({"default": nn.Linear(base.in_features, self.r, bias=False)})
+        self.lora_B = nn.ModuleDict({"default": nn.Linear(self.r, base.out_features, bias=False)})
+        nn.init.kaiming_uniform_(self.lora_A["default"].weight, a=math.sqrt(5))
+        nn.init.zeros_(self.lora_B["default"].weight)
+        for p in base.parameters():
+            p.requires_grad = False
+
+    def forward(self, x):
+        # the two rank-r products on the path's own MFMA kernels (torch.ops.lego_hip.linear, autograd registered)
+        a = F_hip.linear(self.lora_dropout["default"](x).float().contiguous(), self.lora_A["default"].weight)
+        return self.base_layer(x) + F_hip.linear(a, self.lora_B["default"].weight) * self.scaling
+
+
+class _LoraModel(nn.Module):
+    def __init__(self, model):
+        super().__init__()
+        self.model = model
+
+
+class _LoraEncoder(nn.Module):
+    """what `get_peft_model(encoder, LoraConfig(...))` returns, as far as the operator uses it: `.base_model.model` is the encoder
+    (so parameters are named `base_model.model.layer...`), calls are forwarded to it."""
+
+    def __init__(self, encoder, r, alpha, dropout, targets=("query", "value")):
+        super().__init__()
+        for p in encoder.parameters():
+            p.requires_grad = False
+        for block in encoder.layer:
+            att = block.attention.self
+            for t in targets:
+                setattr(att, t, LoraLinear(getattr(att, t), r, alpha, dropout))
+        self.base_model = _LoraModel(encoder)
+
+    @property
+    def layer(self):
+        return self.base_model.model.layer
+
+    def forward(self, *args, **kwargs):
+        return self.base_model.model(*args, **kwargs)
+
+    def trainable_parameters(self):
+        t = sum(p.numel() for p in self.parameters() if p.requires_grad)
+        return t, sum(p.numel() for p in self.parameters())
 
 
 class LMOperator(BaseOperator):
@@ -113,9 +173,21 @@ class BertOperator(LMOperator, abc.ABC):
             if not self.config.tune_from:
                 self._slice_transformer_layers()                      # also for tune_from == 0: see the module docstring
             # tune_from > 0: the cache needs every block and the item table -- `build_layer_cache` slices afterwards
-        if (self.config.tune_from is None or self.config.tune_from < self.num_hidden_layers - 1) and self.config.use_lora:
-            raise NotImplementedError("use_lora needs `peft`, which this build does not ship; set item_config.use_lora: false "
-                                      "(the bert-naml.yaml default)")
+        if not self.config.tune_from:
+            self._lora_encoder()                 # tune_from > 0: after build_layer_cache has sliced the blocks
+
+    def _lora_encoder(self):
+        """once_operator.py:137-151 + bert_operator.py:26-28 (peft restated natively, see the module docstring)"""
+        c = self.config
+        if not ((c.tune_from is None or c.tune_from < self.num_hidden_layers - 1) and c.use_lora):
+            return
+        if not isinstance(c.lora_r, int):
+            raise ValueError("lora_r should be an integer")
+        if not isinstance(c.lora_alpha, int):
+            raise ValueError("lora_alpha should be an integer")
+        if not isinstance(c.lora_dropout, float):
+            raise ValueError("lora_dropout should be a float")
+        self.transformer.encoder = _LoraEncoder(self.transformer.encoder, c.lora_r, c.lora_alpha, c.lora_dropout)
 
     def get_pretrained_parameter_names(self):
         return ["transformer"]
@@ -188,6 +260,8 @@ class BertOperator(LMOperator, abc.ABC):
             mask[bad] = template
         self.hidden_weights, self.attention_mask = hidden, mask
         self._slice_transformer_layers()
+        self._lora_encoder()                                          # once_operator.py:128-151: slice first, then the adapters
+        self.transformer.to(dev)
 
     def _loop_forward(self, hidden_states, attention_mask):
         """bert_operator.py:30-45: the kept blocks on cached states"""

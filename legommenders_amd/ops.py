@@ -160,16 +160,41 @@ def _(gH, X, ids, W, p, seed, site):
     return torch.empty_like(W, dtype=torch.float32), W.new_empty(W.shape[0], dtype=torch.float32)
 
 
+@_cuda("glove_project_bwd_table")
+def glove_project_bwd_table(gH: torch.Tensor, ids: torch.Tensor, W: torch.Tensor, rows: int, p: float, seed: int, site: int) -> torch.Tensor:
+    """gradient of an UN-FROZEN pre-trained table under Transformation (`load_pretrained_embedding(..., frozen=False)`,
+    loader/embedding_hub.py:171,262: nn.Embedding.from_pretrained with requires_grad switched on): the mask + Dropout backward of
+    gH (the same Philox bits as the forward), dX = g W, rows added to the DENSE [rows, E0] gradient the reference's autograd
+    produces (pad ids -1 contribute nothing: the reference's masked positions look up row 0 and are zeroed after the projection)"""
+    D = W.shape[0]
+    flat = ids.to(torch.int32).contiguous()
+    rowinfo = torch.where(flat >= 0, torch.full_like(flat, 4), torch.zeros_like(flat))
+    g = _f(gH).clone()
+    call("lego_mask_dropout_rows", K._ptr(g), D, g.shape[0], None, D, K._ptr(rowinfo), K._drop(_drop(p, seed, site)), None, K._stream())
+    gX = K.linear_bwd_data(g, _f(W))
+    gT = torch.zeros(rows, W.shape[1], dtype=torch.float32, device=W.device)
+    return K.scatter_add_rows(gT, flat, gX)
+
+
+@register_fake(f"{NS}::glove_project_bwd_table")
+def _(gH, ids, W, rows, p, seed, site):
+    return W.new_empty(rows, W.shape[1], dtype=torch.float32)
+
+
 def _gp_setup(ctx, inputs, output):
     ids, table, W, b, p, seed, site = inputs
     ctx.save_for_backward(output[1], ids, W)
     ctx.rng = (p, seed, site)
+    ctx.table_rows = table.shape[0]
 
 
 def _gp_bwd(ctx, gH, gX):
     X, ids, W = ctx.saved_tensors
     gW, gb = torch.ops.lego_hip.glove_project_bwd(gH.contiguous(), X, ids, W, *ctx.rng)
-    return None, None, gW, gb, None, None, None
+    gT = None
+    if ctx.needs_input_grad[1]:                  # un-frozen pre-trained table
+        gT = torch.ops.lego_hip.glove_project_bwd_table(gH.contiguous(), ids, W, ctx.table_rows, *ctx.rng)
+    return None, gT, gW, gb, None, None, None
 
 
 register_autograd(f"{NS}::glove_project", _gp_bwd, setup_context=_gp_setup)
@@ -453,6 +478,6 @@ def _(row_user, user_hist, user_hist_len):
     return row_user.new_empty(row_user.numel(), user_hist.shape[1], dtype=torch.int32), row_user.new_empty(row_user.numel(), dtype=torch.int32)
 
 
-OPS = ("gather_rows", "scatter_add_rows", "linear", "linear_bwd", "glove_project", "glove_project_bwd", "conv3_relu_mask",
+OPS = ("gather_rows", "scatter_add_rows", "linear", "linear_bwd", "glove_project", "glove_project_bwd", "glove_project_bwd_table", "conv3_relu_mask",
        "conv3_relu_mask_bwd", "additive_pool", "additive_pool_bwd", "mhsa", "mhsa_bwd", "rowdot", "rowdot_bwd", "dot_ce",
        "dot_ce_bwd", "adam_step", "sample_negatives", "gather_history")

@@ -144,6 +144,9 @@ def build_model(config: Obj, world: dict, device):
     if kind is None or type(lc.user_operator).__name__ not in ("AdaOperator", "AttentionOperator") \
             or (kind == "naml") != (type(lc.user_operator).__name__ == "AdaOperator"):
         kind = "plugin"          # e.g. BertBase + Ada: trained operator by operator (plugin_step.py), not by a fused engine
+    if any(not info.get("frozen", True) for info in (embed.embeddings() or [])):
+        kind = "plugin"          # an un-frozen pre-trained table: the fused engines keep the pre-trained table frozen
+    if kind == "plugin":
         from legommenders_amd.engine import ItemTables
         legommender.attach_item_table(ItemTables(world["title_tok"], world["title_len"], world["cat"], device))
     return legommender, kind

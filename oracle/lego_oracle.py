@@ -240,6 +240,12 @@ def _bert_layer(h, ext, P, lp, heads, eps):
 
     def heads_of(name):
         y = F.linear(h, P[lp + f"attention.self.{name}.weight"], P[lp + f"attention.self.{name}.bias"])
+        a_key = lp + f"attention.self.{name}.lora_A.default.weight"
+        if a_key in P:
+            # LoRA (peft is a third-party dependency of the reference, requirements.txt `peft`, absent here -- published algorithm,
+            # Hu et al. 2021 / peft.tuners.lora.Linear.forward: result = base(x) + lora_B(lora_A(dropout(x))) * (lora_alpha / r);
+            # call site once_operator.py:137-151, bert_operator.py:26-28).  Dropout 0 in this restatement.
+            y = y + F.linear(F.linear(h, P[a_key]), P[lp + f"attention.self.{name}.lora_B.default.weight"]) * float(P["__lora_scaling__"])
         return y.view(n, L, heads, dh).permute(0, 2, 1, 3)
     q, k, v = heads_of("query"), heads_of("key"), heads_of("value")
     probs = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(dh) + ext, dim=-1)
@@ -357,12 +363,17 @@ def eval_scores(kind, P, title_tok, title_len, cat, user_hist, user_hist_len, ro
 
 
 def loss_and_grads(kind, P_np, tables, cand, hist, hist_len, heads=8, glove=True, frozen=(), bert_layers=0, bert_eps=1e-12,
-                   layer_cache=None):
-    """Logits, loss and d(loss)/d(param) for every trainable tensor (dropout 0).  numpy in/out."""
+                   layer_cache=None, train_table=False):
+    """Logits, loss and d(loss)/d(param) for every trainable tensor (dropout 0).  numpy in/out.
+    `train_table`: the pre-trained token table is un-frozen (`load_pretrained_embedding(..., frozen=False)`,
+    loader/embedding_hub.py:171,262 -- its weight gets requires_grad and the dense gradient of the look-up)."""
     P = {}
     for k, v in P_np.items():
+        if k.startswith("__"):                                  # non-tensor settings riding along (e.g. __lora_scaling__)
+            P[k] = v
+            continue
         t = _t(v).clone()
-        if k not in frozen and t.dtype == torch.float32 and not k.endswith("glove.embedding.weight"):
+        if k not in frozen and t.dtype == torch.float32 and (train_table or not k.endswith("glove.embedding.weight")):
             t.requires_grad_(True)
         P[k] = t
     tt, tl, ct = _t(tables["title_tok"]), _t(tables["title_len"]), _t(tables["cat"])
@@ -376,7 +387,7 @@ def loss_and_grads(kind, P_np, tables, cand, hist, hist_len, heads=8, glove=True
     else:
         logits = nrms_forward(P, tt, tl, ct, c, h, hl, heads=heads, glove=glove)
     loss = ce_label0(logits)
-    names = [k for k, v in P.items() if v.requires_grad]
+    names = [k for k, v in P.items() if isinstance(v, torch.Tensor) and v.requires_grad]
     grads = torch.autograd.grad(loss, [P[k] for k in names], allow_unused=True)
     g = {k: (gv.numpy() if gv is not None else np.zeros_like(P_np[k])) for k, gv in zip(names, grads)}
     return logits.detach().numpy(), float(loss.detach()), g

@@ -58,8 +58,10 @@ def test_construction_rules_follow_the_reference():
     with pytest.raises(ValueError, match="does not match input_dim"):          # bert_operator.py:19-21
         bad = dict(meta["bert"], hidden_size=32, num_attention_heads=4)
         _lego_config(meta, tables, P, ops, preds, {"transformer_config": bad}).build_components()
-    with pytest.raises(NotImplementedError, match="peft"):
-        _lego_config(meta, tables, P, ops, preds, {"use_lora": True, "lora_r": 8, "lora_alpha": 16}).build_components()
+    with pytest.raises(ValueError, match="lora_dropout should be a float"):     # once_operator.py:143-144
+        _lego_config(meta, tables, P, ops, preds, {"use_lora": True, "lora_r": 8, "lora_alpha": 16, "lora_dropout": 0}).build_components()
+    with pytest.raises(ValueError, match="lora_r should be an integer"):        # once_operator.py:139-140
+        _lego_config(meta, tables, P, ops, preds, {"use_lora": True, "lora_r": None, "lora_alpha": 16}).build_components()
     with pytest.raises(ValueError, match="tune_from should be less than"):      # once_operator.py:103-104
         _lego_config(meta, tables, P, ops, preds, {"tune_from": 7}).build_components()
     with pytest.raises(ValueError, match="no local checkpoint"):                # no network: the checkpoint must be local
@@ -103,6 +105,87 @@ def test_bert_naml_matches_reference_logits_loss_grads():
         scores = model(batch=dict(ids))
     assert float(np.abs(scores.cpu().numpy() - logits).max()) < 1e-3               # the north-star bar on fp32 logits
     assert float(np.abs(scores.cpu().numpy() - logits).max()) < 1e-4
+
+
+@pytest.mark.gpu
+def test_bert_lora_adapters_match_oracle():
+    """`use_lora: true` (once_operator.py:27-38,137-151; bert_operator.py:26-28): LoRA on the query / value projections of the kept
+    blocks, everything else of the encoder frozen.  peft is not in the image, so the pin is the oracle's restatement of peft's
+    published forward (result = base(x) + B(A(x)) * alpha / r): loss, logits, the adapter gradients, and the freeze set."""
+    from legommenders_amd.engine import ItemTables
+    from legommenders_amd.loader.class_hub import ClassHub
+    from legommenders_amd.loader.env import Env
+    from legommenders_amd.model.legommender import Legommender
+    from oracle import lego_oracle as O
+    dev = torch.device("cuda:0")
+    Env.set_device(dev)
+    meta, P, G, tables, batch, logits, loss = load_model_fixture("bert_naml_small")
+    r, alpha = 4, 16
+    lc = _lego_config(meta, tables, P, ClassHub.operators(), ClassHub.predictors(),
+                      {"use_lora": True, "lora_r": r, "lora_alpha": alpha, "lora_dropout": 0.0})
+    lc.build_components()
+    lc.register_inputer_vocabs()
+    torch.manual_seed(3)
+    model = Legommender(lc).to(dev)
+    sd = model.state_dict()
+    pre = "item_op.transformer.encoder."
+    # peft's names; the fixture's checkpoint goes into the base layers, B (zero at construction) gets values so that the update counts
+    load = {}
+    for k, v in P.items():
+        k2 = k
+        if k.startswith(pre):
+            k2 = pre + "base_model.model." + k[len(pre):]
+            for t in ("query", "value"):
+                k2 = k2.replace(f"attention.self.{t}.", f"attention.self.{t}.base_layer.")
+        load[k2] = torch.tensor(v)
+    g = torch.Generator().manual_seed(5)
+    for k in sd:
+        if "lora_B" in k:
+            load[k] = torch.randn(sd[k].shape, generator=g) * 0.05
+        elif "lora_A" in k:
+            load[k] = sd[k].cpu()
+    missing, unexpected = model.load_state_dict(load, strict=False)
+    assert not unexpected and all(m.startswith("_") for m in missing), (missing, unexpected)
+    lora_keys = [k for k in sd if "lora_" in k]
+    assert len(lora_keys) == 2 * 2 * meta["layers_kept"]                            # A and B, query and value, per kept block
+    named = dict(model.named_parameters())
+    enc_trainable = [k for k, p in named.items() if k.startswith(pre) and p.requires_grad]
+    assert sorted(enc_trainable) == sorted(lora_keys)                               # the rest of the encoder is frozen
+    tb = ItemTables(tables["title_tok"], tables["title_len"], tables["cat"], dev)
+    model.attach_item_table(tb)
+    ids = {"item_id": torch.tensor(batch["cand"]), "history": torch.tensor(batch["hist"]),
+           "__clicks_mask__": (torch.arange(50)[None] < torch.tensor(batch["hist_len"])[:, None]).long()}
+    Env.train()
+    model.train()
+    out = model(batch=dict(ids))
+    out.backward()
+    # oracle: the same parameters under the reference's un-wrapped names + the adapter matrices
+    Po = {}
+    for k, v in model.state_dict().items():
+        Po[k.replace("base_model.model.", "").replace(".base_layer.", ".")] = v.detach().cpu().numpy()
+    Po["__lora_scaling__"] = alpha / r
+    frozen = [k for k in Po if k.startswith(pre) and "lora_" not in k]
+    ref_logits, ref_loss, ref_g = O.loss_and_grads("bert_naml", Po, {k: tables[k].astype("int64") for k in ("title_tok", "title_len", "cat")},
+                                                   batch["cand"].astype("int64"), batch["hist"].astype("int64"), batch["hist_len"].astype("int64"),
+                                                   heads=meta["bert"]["num_attention_heads"], frozen=frozen, bert_layers=meta["layers_kept"],
+                                                   bert_eps=meta["bert"].get("layer_norm_eps", 1e-12))
+    assert abs(float(out) - ref_loss) < 2e-5 and abs(ref_loss - loss) > 1e-4        # the adapters changed the function
+    gscale = max(float(np.abs(v).max()) for v in ref_g.values())
+    for k, p in named.items():
+        ko = k.replace("base_model.model.", "").replace(".base_layer.", ".")
+        if not p.requires_grad:
+            continue
+        if p.grad is None:                          # e.g. BertModel's pooler: in the module, not in the function
+            assert float(np.abs(ref_g[ko]).max()) == 0.0, k
+            continue
+        d = p.grad.detach().cpu().numpy().astype(np.float64) - ref_g[ko]
+        assert float(np.abs(d).max()) <= 2e-3 * float(np.abs(ref_g[ko]).max()) + 2e-6 * gscale, (k, float(np.abs(d).max()))
+    assert all(float(np.abs(ref_g[k.replace("base_model.model.", "")]).max()) > 0 for k in lora_keys)
+    Env.test()
+    model.eval()
+    with torch.no_grad():
+        scores = model(batch=dict(ids))
+    assert float(np.abs(scores.cpu().numpy() - ref_logits).max()) < 1e-4
 
 
 @pytest.mark.gpu

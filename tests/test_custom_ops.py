@@ -71,6 +71,7 @@ def _samples():
         "linear_bwd": (_r(10, 8), _r(10, 12, seed=1), _r(8, 12, seed=2), True),
         "glove_project": (ids, _r(9, 12), _r(32, 12, seed=1, grad=True), _r(32, seed=2, grad=True), 0.1, 7, 3),
         "glove_project_bwd": (_r(8, 32), _r(8, 12, seed=1), ids, _r(32, 12, seed=2), 0.1, 7, 3),
+        "glove_project_bwd_table": (_r(8, 32), ids, _r(32, 12, seed=2), 9, 0.1, 7, 3),
         "conv3_relu_mask": (_r(n, Ls, D, grad=True), _mask(n, Ls), _r(D, D, 3, seed=1, grad=True, scale=0.1), _r(D, seed=2, grad=True), 0.0, 0, 0),
         "additive_pool": (_r(n, Ls, D, grad=True), _mask(n, Ls), _r(A, D, seed=1, grad=True, scale=0.2), _r(A, seed=2, grad=True),
                           _r(1, A, seed=3, grad=True)),
@@ -88,7 +89,7 @@ def _samples():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["gather_rows", "scatter_add_rows", "linear", "linear_bwd", "glove_project", "glove_project_bwd",
+@pytest.mark.parametrize("name", ["gather_rows", "scatter_add_rows", "linear", "linear_bwd", "glove_project", "glove_project_bwd", "glove_project_bwd_table",
                                   "conv3_relu_mask", "additive_pool", "mhsa", "rowdot", "rowdot_bwd", "dot_ce", "sample_negatives",
                                   "gather_history"])
 def test_opcheck(name):

@@ -385,12 +385,21 @@ def test_eight_ranks_emulated_global_512(kind):
     # travelled.)  Bars: whole parameter vector <= 2e-4 of its norm; per tensor <= 1 % of the distance it travelled.
     a, b = ranks[0].fp.flat, one.fp.flat
     rel = float((a - b).norm() / b.norm())
-    worst = {}
+    worst, noise = {}, []
+    lr = 1e-3
     for k in one.fp.names:
         o, n = one.fp.offsets[k], one.fp.P[k].numel()
         moved = float((b[o:o + n] - P[k].reshape(-1).to(dev)).norm())
+        # a tensor whose gradient is SIGNAL moves by ~lr per element and step under Adam; tensors that moved far less (NRMS at this
+        # initialisation: the key bias, the user tower's additive hidden layer) carry only rounding noise, which no two summation
+        # orders share -- they are bounded by the movement itself, not compared (tests/test_dp_device.py, two-process table test)
+        if moved < 0.2 * lr * steps * n ** 0.5:
+            noise.append(k)
+            assert float((a[o:o + n] - b[o:o + n]).abs().max()) <= 2.0 * lr * steps, k
+            continue
         worst[k] = float((a[o:o + n] - b[o:o + n]).norm()) / max(moved, 1e-30)
+    assert len(worst) >= 6 and len(noise) <= 4, (sorted(worst), noise)
     print(kind, "first-step gradient rel", g_rel, "parameters rel", rel, "worst tensor / travelled",
-          max(worst.items(), key=lambda kv: kv[1]))
+          max(worst.items(), key=lambda kv: kv[1]), "noise-only tensors", noise)
     assert rel <= 2e-4, rel
     assert max(worst.values()) <= 1e-2, worst

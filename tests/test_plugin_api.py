@@ -10,7 +10,7 @@ import torch
 from tests.golden_util import load_model_fixture
 
 
-def _build(name, dev):
+def _build(name, dev, frozen=True):
     from legommenders_amd.engine import ItemTables
     from legommenders_amd.loader.class_hub import ClassHub
     from legommenders_amd.loader.column_map import ColumnMap
@@ -50,7 +50,7 @@ def _build(name, dev):
                                 label_col="click", group_col="user_id"))
     eh = EmbeddingHub(embedding_dim=D, transformation="auto", transformation_dropout=0.0)
     if meta["embed"] == "glove":
-        eh.load_pretrained_embedding(None, vocab_name="glove", frozen=True,
+        eh.load_pretrained_embedding(None, vocab_name="glove", frozen=frozen,
                                      array=P["embedding_vocab_table.glove.embedding.weight"])
     eh.register_ut(item_ut, ["title@glove", "category"])
     lc.set_embedding_hub(eh)
@@ -96,6 +96,33 @@ def test_legommender_routes_match_reference(name, route):
     with torch.no_grad():
         scores = model(batch=dict(ids))
     assert float(np.abs(scores.cpu().numpy() - logits).max()) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["naml_glove_d64", "nrms_glove_d64"])
+def test_unfrozen_pretrained_table_matches_oracle(name):
+    """`load_pretrained_embedding(..., frozen=False)` (loader/embedding_hub.py:171,262: the GloVe table fine-tunes): the plug-in
+    route's loss and EVERY gradient, the dense [V, 300] table gradient included, against the oracle with the table trainable"""
+    from legommenders_amd.loader.env import Env
+    from oracle import lego_oracle as O
+    dev = torch.device("cuda:0")
+    model, ids, tb, G, logits, loss = _build(name, dev, frozen=False)
+    meta, P, _, tables, batch, _, _ = load_model_fixture(name)
+    tk = "embedding_vocab_table.glove.embedding.weight"
+    assert dict(model.named_parameters())[tk].requires_grad
+    Env.train()
+    model.train()
+    out = model(batch=dict(ids))
+    out.backward()
+    ref_logits, ref_loss, ref_g = O.loss_and_grads(meta["kind"], P, {k: tables[k].astype("int64") for k in ("title_tok", "title_len", "cat")},
+                                                   batch["cand"].astype("int64"), batch["hist"].astype("int64"),
+                                                   batch["hist_len"].astype("int64"), heads=meta.get("heads", 8), glove=True, train_table=True)
+    assert abs(float(out) - ref_loss) < 2e-5 and abs(ref_loss - loss) < 2e-5
+    assert tk in ref_g and float(np.abs(ref_g[tk]).max()) > 0
+    _check_grads(model, ref_g, name + " (table un-frozen)")
+    # rows no token of the batch touches keep an exactly zero gradient (dense gradient, as the reference's autograd gives)
+    gt = dict(model.named_parameters())[tk].grad.cpu().numpy()
+    assert np.array_equal(np.abs(gt).sum(1) == 0, np.abs(ref_g[tk]).sum(1) == 0)
 
 
 def test_class_hub_discovers_reference_names():
