@@ -555,8 +555,8 @@ def main():
         del t4, dm
         torch.cuda.empty_cache()
         # config 5: BERT-base news encoder through the plug-in route (random-init BertConfig() defaults = bert-base-uncased
-        # shapes; the blocks run in PyTorch-ROCm as SURVEY.md 8f-2 prescribes, gather / Linear / pools / dot + CE on the
-        # path's kernels).  Both modes the reference has: tune_from = 0 (11 blocks train) and cached-layer (tune_from = 9:
+        # shapes; round 4: the transformer blocks run on the path's own kernels over ragged rows -- legommenders_amd/bert_native.py --
+        # as do gather / Linear / pools / dot + CE).  Both modes the reference has: tune_from = 0 (11 blocks train) and cached-layer (tune_from = 9:
         # layer-9 states of every item resident in HBM, 2 blocks train).  Few steps: a step is 0.1-0.6 s.
         if not args.no_bert:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -568,12 +568,13 @@ def main():
                 bsec[name] = {"steps": st, "warmup": 1, "ms_per_step": round(r["s_per_step"] * 1e3, 2), "value": r["impressions_per_s"],
                               "unit": "impressions/s", "bert_blocks_run": r["bert_layers_run"], "trainable_params": r["trainable_params"],
                               "layer_cache_s": r["layer_cache_s"], "layer_cache_GB": r["layer_cache_GB"], "final_loss": round(r["loss"], 4),
-                              "item_page_size_yaml": r["item_page_size"], "item_page_effective": r["effective_item_page"]}
+                              "item_page_size_yaml": r["item_page_size"], "item_page_effective": r["effective_item_page"],
+                              "blocks_on": r["blocks_on"], "kernels": r["kernels"]}
                 torch.cuda.empty_cache()
             Env.set_lm_cache(False)
             sec["bert_naml_base"] = dict(bsec, workload=f"MIND-small-shaped BERT-NAML (BASELINE config 5): BertConfig() defaults "
-                                         f"(768 x 12 blocks x 12 heads, random init), item_page_size 64 in the yaml (raised to the engine's floor of 256 items per "
-                                         f"call: same values, fuller launches; only the LIVE history slots are encoded), hidden={D} bs={B}, "
+                                         f"(768 x 12 blocks x 12 heads, random init), item_page_size 64 in the yaml (raised to one call per batch side: same values, "
+                                         f"fuller launches; only the LIVE history slots are encoded), hidden={D} bs={B}, "
                                          f"5 000-item world, full plug-in train step (device sampler ids, fwd, bwd, torch Adam), fp32")
         extra["secondary"] = sec
 

@@ -354,6 +354,23 @@ int lego_mask_dropout_rows(float* x, int ld, int R_cap, const int32_t* R_dyn, in
 int lego_grouped_metrics(const float* scores, const int32_t* labels, const int32_t* group_off, int n_groups,
                          const int32_t* ks /*host*/, int n_k, float* out, void* stream);
 
+/* ---- 8f-2 (config 5): the row-wise pieces of a BERT block around the path's products and attention core -- the `transformers`
+ * BertSelfOutput / BertOutput tail `LayerNorm(Dropout(dense(x)) + residual)`, BertEmbeddings' `Dropout(LayerNorm(sum of embeddings))`
+ * and BertIntermediate's exact GELU (reference call sites: model/operators/once_operator.py:156-193, bert_operator.py:10-52).
+ *   out = drop_post(LayerNorm(drop_pre(y) + resid) * gamma + beta);   mean / rstd [rows] are saved for the backward pass, which
+ *   forms v = drop_pre(y) + resid again from y, resid and the redrawn keep bits.  resid, drop_pre, drop_post nullable.
+ *   backward: dy (nullable) = d(loss)/dy, dresid (nullable) = d(loss)/dresid, dgamma / dbeta (nullable) += their gradients. */
+int lego_dropout_add_layernorm_fwd(const float* y, int ldy, const float* resid, int ldr, const float* gamma, const float* beta, float eps,
+                                   const lego_dropout* drop_pre, const lego_dropout* drop_post, float* out, int ldo,
+                                   float* mean /*[rows]*/, float* rstd /*[rows]*/, int rows, int width, void* stream);
+int lego_dropout_add_layernorm_bwd(const float* dout, int lddo, const float* y, int ldy, const float* resid, int ldr, const float* gamma,
+                                   const float* mean, const float* rstd, const lego_dropout* drop_pre, const lego_dropout* drop_post,
+                                   float* dy, int lddy, float* dresid, int lddr, float* dgamma, float* dbeta, int rows, int width,
+                                   void* stream);
+/* g = z Phi(z) (erf form) over n contiguous floats; dz = dg (Phi(z) + z phi(z)), dz may alias dg */
+int lego_gelu_fwd(const float* z, float* g, int64_t n, void* stream);
+int lego_gelu_bwd(const float* dg, const float* z, float* dz, int64_t n, void* stream);
+
 /* small utilities used by the host side */
 int lego_gather_i32(const int32_t* table, const int32_t* idx, int n_cap, const int32_t* n_dyn, int32_t* out, void* stream);
 /* rowinfo[i] = live bit (4) iff segment i of seg_off has rows: with it the live-mask epilogue of lego_linear_fwd zeroes the output

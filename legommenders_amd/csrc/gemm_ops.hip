@@ -440,7 +440,14 @@ constexpr int TN_LONG = 8192;
 
 static int pick_split_small(int rows_cap, int M, int N) {
     const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
-    int s = 1024 / tiles;
+    // ~1024 workgroups (four per CU).  Outputs of several hundred tiles (BERT's 768 x 3072 FFN weights: 576) take ~2 300 workgroups --
+    // 1024 / 576 floors to 1 and leaves 44 % of the workgroup slots empty; more, shorter workgroups also hide each other's load
+    // latency (LEGO_TN_SPLIT overrides: tuning)
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("LEGO_TN_SPLIT"); forced = e != nullptr ? atoi(e) : 0; }
+    // measured on [3072 x 768] over 29.6 k rows (tools/bert_shapes_bench.py): split 1 / 2 / 3 / 4 / 8 = 82 / 98 / 104 / 107 / 105 TFLOP/s
+    int s = tiles > 256 ? (2304 + tiles - 1) / tiles : 1024 / tiles;
+    if (forced > 0) s = forced;
     const int max_s = (rows_cap + 127) / 128;       // at least 128 reduction rows per block
     if (s > max_s) s = max_s;
     if (s >= 16) s &= ~7;                           // a multiple of 8: the k splits can then be dealt to the 8 XCDs (gemm_tn.hpp)

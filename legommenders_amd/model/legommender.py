@@ -231,7 +231,8 @@ class Legommender(nn.Module):
 
     def _item_page(self, n: int) -> int:
         page = int(self.config.item_page_size or 0)
-        return max(page, self.item_page_floor) if page else n
+        floor = max(self.item_page_floor, int(getattr(self.item_op, "page_floor", 0) or 0)) if self.item_page_floor else 0
+        return max(page, floor) if page else n
 
     def _encode_live_history(self, hist: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
         ids = hist.to(Env.device)

@@ -263,8 +263,31 @@ class BertOperator(LMOperator, abc.ABC):
         self._lora_encoder()                                          # once_operator.py:128-151: slice first, then the adapters
         self.transformer.to(dev)
 
+    # The transformer blocks run on the path's own kernels over RAGGED rows (legommenders_amd/bert_native.py: MFMA products, the
+    # head-dim-64 attention core, fused Dropout + residual + LayerNorm, GELU) unless the configuration is outside what they cover
+    # (LoRA-wrapped projections, sequences wider than 64, a non-GELU activation): then -- and with LEGO_BERT_NATIVE=0 -- through the
+    # `transformers` modules on PyTorch-ROCm, as SURVEY.md section 8f-2 first prescribed.
+    native = os.environ.get("LEGO_BERT_NATIVE", "1") != "0"
+    native_page_floor = int(os.environ.get("LEGO_BERT_PAGE_FLOOR", "4096"))
+
+    def _native_ok(self, L):
+        if not self.native:
+            return False
+        from legommenders_amd import bert_native
+        return bert_native.supported(self.transformer, int(L)) is None
+
+    @property
+    def page_floor(self):
+        """items per operator call the paging of Legommender.get_item_content is raised to: one call for the whole batch keeps the
+        block products at tens of thousands of rows (a 256-item page is 4.7 k rows: each CU would stage a whole weight panel for 18
+        of them); the saved activations of 1 600 items x 11 blocks are ~15 GB of 288"""
+        return self.native_page_floor if self._native_ok(32) else 0
+
     def _loop_forward(self, hidden_states, attention_mask):
         """bert_operator.py:30-45: the kept blocks on cached states"""
+        if self._native_ok(hidden_states.shape[1]):
+            from legommenders_amd import bert_native
+            return bert_native.encoder_forward(self.transformer, hidden_states, attention_mask, embed=False)
         ext = (1.0 - attention_mask[:, None, None, :].to(hidden_states.dtype)) * torch.finfo(hidden_states.dtype).min
         return self.transformer.encoder(hidden_states=hidden_states, attention_mask=ext, return_dict=True).last_hidden_state
 
@@ -301,8 +324,12 @@ class BertOperator(LMOperator, abc.ABC):
             mask = mask.to(Env.device)
             if self.trim_pads and isinstance(embeddings, torch.Tensor):
                 embeddings, mask = self._trim(embeddings, mask)
-            outputs = self.transformer(inputs_embeds=embeddings.float(), attention_mask=mask.float(),
-                                       return_dict=True).last_hidden_state
+            if isinstance(embeddings, torch.Tensor) and self._native_ok(embeddings.shape[1]):
+                from legommenders_amd import bert_native
+                outputs = bert_native.encoder_forward(self.transformer, embeddings, mask, embed=True)
+            else:
+                outputs = self.transformer(inputs_embeds=embeddings.float(), attention_mask=mask.float(),
+                                           return_dict=True).last_hidden_state
         outputs = F_hip.linear(outputs.float().contiguous(), self.linear.weight, self.linear.bias)
         return self.additive_attention(outputs, mask)
 

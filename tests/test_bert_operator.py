@@ -311,3 +311,113 @@ def test_bert_base_size_matches_oracle():
     assert float(np.abs(scores - ref.numpy()).max()) < 1e-3 * max(1.0, scale), (float(np.abs(scores - ref.numpy()).max()), scale)
     assert abs(loss - ref_loss) < 1e-4 * max(1.0, abs(ref_loss))
     Env.test()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,rows", [(768, 1003), (64, 37), (1024, 260), (200, 8)])
+def test_layernorm_tail_and_gelu_kernels_match_torch(W, rows):
+    """lego_dropout_add_layernorm_fwd / _bwd and lego_gelu_fwd / _bwd (csrc/bert_ops.hip) against torch fp64: without dropout
+    everything to rounding; with dropout the keep decisions are read back from the output (zeros), must be redrawn identically by
+    the backward pass, and the keep rate must be 1 - p."""
+    import ctypes
+    from legommenders_amd._lib import LegoDropout, call
+    from legommenders_amd.kernels import _ptr, _stream
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(W + rows)
+    y, res, do = (torch.randn(rows, W, generator=g).to(dev) for _ in range(3))
+    gam, bet = (torch.randn(W, generator=g) * 0.5 + 1.0).to(dev), torch.randn(W, generator=g).to(dev)
+    eps = 1e-12
+
+    def run(pre, post):
+        out, mean, rstd = torch.empty(rows, W, device=dev), torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+        call("lego_dropout_add_layernorm_fwd", _ptr(y), W, _ptr(res), W, _ptr(gam), _ptr(bet), eps, pre, post, _ptr(out), W, _ptr(mean),
+             _ptr(rstd), rows, W, _stream())
+        dy, dr = torch.empty(rows, W, device=dev), torch.empty(rows, W, device=dev)
+        dg, db = torch.zeros(W, device=dev), torch.zeros(W, device=dev)
+        call("lego_dropout_add_layernorm_bwd", _ptr(do), W, _ptr(y), W, _ptr(res), W, _ptr(gam), _ptr(mean), _ptr(rstd), pre, post,
+             _ptr(dy), W, _ptr(dr), W, _ptr(dg), _ptr(db), rows, W, _stream())
+        torch.cuda.synchronize()
+        return out, dy, dr, dg, db
+
+    def ref(mpre, mpost):
+        y64, r64 = y.double().requires_grad_(True), res.double().requires_grad_(True)
+        g64, b64 = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+        o = torch.nn.functional.layer_norm(y64 * mpre + r64, (W,), g64, b64, eps) * mpost
+        o.backward(do.double())
+        return o.detach(), y64.grad, r64.grad, g64.grad, b64.grad
+
+    one = torch.ones(rows, W, dtype=torch.float64, device=dev)
+    for got, want in zip(run(None, None), ref(one, one)):
+        assert float((got.double() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-6
+    # dropout in front of the residual add (BertSelfOutput / BertOutput) and behind the LayerNorm (BertEmbeddings)
+    p = 0.25
+    pre = ctypes.byref(LegoDropout(p, 11, 5))
+    out_pre = run(pre, None)
+    #   the pre-mask is not visible in `out`; recover it from dy / dresid (dy = dresid * keep / (1 - p))
+    keep_pre = (out_pre[1] != 0) | (out_pre[2] == 0)
+    assert abs(float(keep_pre.float().mean()) - (1 - p)) < 0.02
+    for got, want in zip(out_pre, ref(keep_pre.double() / (1 - p), one)):
+        assert float((got.double() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-6
+    post = ctypes.byref(LegoDropout(p, 12, 6))
+    out_post = run(None, post)
+    keep_post = out_post[0] != 0
+    assert abs(float(keep_post.float().mean()) - (1 - p)) < 0.02
+    for got, want in zip(out_post, ref(one, keep_post.double() / (1 - p))):
+        assert float((got.double() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-6
+    # GELU
+    n = rows * W // 4 * 4
+    z = (torch.randn(n, generator=g) * 2).to(dev)
+    go = torch.randn(n, generator=g).to(dev)
+    gl, dz = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    call("lego_gelu_fwd", _ptr(z), _ptr(gl), n, _stream())
+    call("lego_gelu_bwd", _ptr(go), _ptr(z), _ptr(dz), n, _stream())
+    z64 = z.double().requires_grad_(True)
+    r = torch.nn.functional.gelu(z64)
+    r.backward(go.double())
+    assert float((gl.double() - r.detach()).abs().max()) < 2e-6 and float((dz.double() - z64.grad).abs().max()) < 5e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tune", [0, 1])
+def test_native_blocks_equal_the_transformers_route(tune, tmp_path, monkeypatch):
+    """the same operator, the same parameters, the same batch: blocks on the path's kernels over ragged rows (bert_native) against
+    the `transformers` modules on PyTorch-ROCm (LEGO_BERT_NATIVE=0 route) -- loss, scores and every gradient (dropout off)"""
+    from legommenders_amd.engine import ItemTables
+    from legommenders_amd.loader.class_hub import ClassHub
+    from legommenders_amd.loader.env import Env
+    from legommenders_amd.model.legommender import Legommender
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("LEGO_LAYER_CACHE_SAVE", "0")
+    dev = torch.device("cuda:0")
+    Env.set_device(dev)
+    meta, P, G, tables, batch, logits, loss = load_model_fixture("bert_naml_small")
+    res = {}
+    for native in (True, False):
+        lc = _lego_config(meta, tables, P, ClassHub.operators(), ClassHub.predictors(), {"tune_from": tune})
+        lc.build_components()
+        lc.register_inputer_vocabs()
+        torch.manual_seed(1)
+        model = Legommender(lc).to(dev)
+        model.item_op.native = native
+        if tune == 0:
+            model.load_state_dict({k: torch.tensor(v) for k, v in P.items()}, strict=False)
+        model.attach_item_table(ItemTables(tables["title_tok"], tables["title_len"], tables["cat"], dev))
+        ids = {"item_id": torch.tensor(batch["cand"]), "history": torch.tensor(batch["hist"]),
+               "__clicks_mask__": (torch.arange(50)[None] < torch.tensor(batch["hist_len"])[:, None]).long()}
+        Env.train()
+        model.train()
+        out = model(batch=dict(ids))
+        out.backward()
+        grads = {k: p.grad.detach().cpu().double() for k, p in model.named_parameters() if p.grad is not None}
+        Env.test()
+        model.eval()
+        with torch.no_grad():
+            scores = model(batch=dict(ids)).cpu()
+        res[native] = (float(out), grads, scores)
+    assert abs(res[True][0] - res[False][0]) < 2e-5
+    assert float((res[True][2] - res[False][2]).abs().max()) < 1e-4
+    assert set(res[True][1]) == set(res[False][1])
+    gscale = max(float(g.abs().max()) for g in res[False][1].values())
+    for k, g in res[False][1].items():
+        d = float((res[True][1][k] - g).abs().max())
+        assert d <= 2e-3 * float(g.abs().max()) + 2e-6 * gscale, (k, d)

@@ -86,10 +86,30 @@ def run(batch=64, steps=5, warmup=2, layers=12, hidden=256, tune_from=0, n_items
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     n_par = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    # per-product table of the native blocks: two more steps with every product launch bracketed by HIP events (outside the timing above)
+    kernels = None
+    from legommenders_amd import bert_native
+    if getattr(model.item_op, "native", False) and model.item_op._native_ok(32):
+        bert_native.TIMERS = {}
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        tm, bert_native.TIMERS = bert_native.TIMERS, None
+        kernels = {}
+        for tag, evs in tm.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in evs)
+            fl = sum(f for _, _, f in evs)
+            tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            kernels[tag] = {"ms_per_step": round(ms / 2, 3), "launches_per_step": len(evs) // 2, "tflops": round(tf, 1),
+                            "frac_of_f32_mfma_peak": round(tf / 157.3, 4)}
+
     return ({"model": "BERT-NAML plug-in route", "batch": B, "bert_layers_run": len(model.item_op.transformer.encoder.layer),
            "trainable_params": n_par, "s_per_step": round(dt, 4), "impressions_per_s": round(B / dt, 1), "loss": float(loss.detach()),
            "item_page_size": item_page_size, "effective_item_page": model._item_page(10 ** 9), "tune_from": a.tune_from, "layer_cache_s": round(t_cache, 3) if a.tune_from else None,
-           "layer_cache_GB": round(model.item_op.hidden_weights.numel() * 4 / 1e9, 3) if a.tune_from else None})
+           "layer_cache_GB": round(model.item_op.hidden_weights.numel() * 4 / 1e9, 3) if a.tune_from else None,
+           "blocks_on": "the path's kernels over ragged rows (legommenders_amd/bert_native.py)" if kernels is not None
+                        else "transformers modules on PyTorch-ROCm (LEGO_BERT_NATIVE=0 or an uncovered configuration)",
+           "kernels": kernels})
 
 
 def main():
