@@ -409,7 +409,10 @@ static int launch_light(const GemmDims& d, const AL& a, const BL& b, const Epi& 
 template <bool B_MC, class EK, class AL, class BL>
 static int launch_rows(const GemmDims& d, const AL& a, const BL& b, const Epi& e, hipStream_t st, const char* what) {
     const int tm = (d.M + 127) / 128;
-    if (d.M >= 32 * num_cus() && d.N <= 4 * STRIP_BN) {
+    // LEGO_STRIP_MAXK (tuning): reductions at least this long skip the row-strip kernels and take the 128 x 128 tile kernel
+    static int strip_maxk = -1;
+    if (strip_maxk < 0) { const char* e = getenv("LEGO_STRIP_MAXK"); strip_maxk = e != nullptr ? atoi(e) : (1 << 30); }
+    if (d.M >= 32 * num_cus() && d.N <= 4 * STRIP_BN && d.K < strip_maxk) {
         if constexpr (std::is_same<AL, KcRows>::value && (std::is_same<BL, KcRows>::value || std::is_same<BL, McRows>::value))
             // the DMA staging moves 16-byte chunks clamped to K - 4 and zeroes tails at 4-element granularity: K % 4 == 0 and
             // 16-byte-aligned rows on both sides, else the register-staged strip kernel

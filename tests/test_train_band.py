@@ -1,7 +1,8 @@
 """Training quality with everything stochastic ON (north star: "AUC within +-0.002 of reference"; VERDICT r2 missing #2).
 
 `tests/golden/train_band_{naml,nrms}.json` hold what the REAL reference reaches on `synthetic.make_learnable_world` --
-8 seeds of its own training loop (torch dropout at its three sites, python-random negatives, DataLoader(shuffle=True), Adam +
+16 seeds (8 for the headline-width bands `*_d256`: D = 256, B = 64) of its own training loop (torch dropout at its three sites,
+python-random negatives, DataLoader(shuffle=True), Adam +
 linear schedule), dev rows scored by its own forward + MetricPool (generator: tests/golden/make_train_band.py).  Here the
 MI355X trainer path (`TrainStep`: device sampler, Philox dropout, per-epoch reshuffle, fused Adam; `Evaluator` + the metrics
 kernel) runs the same world / hyper-parameters from the SAME initial parameters, one run per seed.  The streams differ, so
@@ -11,6 +12,7 @@ the comparison is between means:
                                                                            reference's own max-min seed spread)
 
 and training must have moved the metric the way it moved the reference's (well above both 0.5 and the untrained model)."""
+import glob
 import json
 import os
 
@@ -44,11 +46,15 @@ def _run(kind, band, seed, dev, world, glove):
     return before, after, float(losses[-50:].mean())
 
 
-@pytest.mark.parametrize("kind", ["naml", "nrms"])
-def test_trained_gauc_matches_the_reference_band(kind):
+BANDS = sorted(os.path.basename(f)[len("train_band_"):-len(".json")] for f in glob.glob(os.path.join(HERE, "golden", "train_band_*.json")))
+
+
+@pytest.mark.parametrize("name", BANDS)
+def test_trained_gauc_matches_the_reference_band(name):
     from legommenders_amd.synthetic import glove_table_np, make_learnable_world
     dev = torch.device("cuda:0")
-    band = json.load(open(os.path.join(HERE, "golden", f"train_band_{kind}.json")))
+    band = json.load(open(os.path.join(HERE, "golden", f"train_band_{name}.json")))
+    kind = band["kind"]
     world = make_learnable_world(**band["world"])
     glove = torch.from_numpy(glove_table_np(band["hyper"]["glove_seed"], world["V"]))
     seeds = [r["seed"] for r in band["runs"]]
@@ -65,8 +71,12 @@ def test_trained_gauc_matches_the_reference_band(kind):
         se = float(np.sqrt(got.std(ddof=1) ** 2 / n + ref.std(ddof=1) ** 2 / n))
         tol = 0.002 + min(2.0 * se, band["spread"][m])
         report[m] = (round(float(got.mean()), 4), round(float(ref.mean()), 4), round(tol, 4))
-        assert abs(got.mean() - ref.mean()) <= tol, (kind, m, got.tolist(), ref.tolist(), tol)
-    print(kind, "mean (hip, reference, tolerance):", report)
+        assert abs(got.mean() - ref.mean()) <= tol, (name, m, got.tolist(), ref.tolist(), tol)
+        if m == "GAUC":
+            # the pin itself has to be tight: the north-star bar is +-0.002; with >= 16 seeds, a 4 000-user dev split and NRMS at its
+            # plateau the statistical slack on top of it stays below 0.002 (tol <= 0.004)
+            assert tol <= 0.004 or len(seeds) < 16, (name, tol)
+    print(name, "mean (hip, reference, tolerance):", report)
     # (2) training did what it did for the reference: clearly above chance and above the untrained model
     g_after = np.mean([a["GAUC"] for _, a, _ in runs])
     g_before = np.mean([b["GAUC"] for b, _, _ in runs])

@@ -1,9 +1,13 @@
+#!/bin/bash
+# round 4 profiles: NAML (tools/prof_round.sh), then NRMS with the same passes (kernel stats overlapped / serial, FETCH / WRITE / issue PMC)
+cd $GRAFT_REPO_ROOT
+bash tools/prof_round.sh gpurun_out/prof_r04 > gpurun_out/prof_r04.log 2>&1
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=${1:-gpurun_out/prof_r04}; rm -rf $O; mkdir -p $O
-B="python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-secondary"
+O=gpurun_out/prof_r04_nrms; rm -rf $O; mkdir -p $O
+B="python3 bench.py --model nrms --steps 100 --warmup 10 --no-cpu-baseline --no-secondary"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/bench_under_rocprof.json 2> $O/stats.err
 LEGO_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_serial -- $B > $O/bench_serial_under_rocprof.json 2> $O/stats_serial.err
-S="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary"
+S="python3 bench.py --model nrms --steps 20 --warmup 5 --no-cpu-baseline --no-secondary"
 LEGO_SERIAL=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $S > /dev/null 2> $O/pmc_fetch.err
 LEGO_SERIAL=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $S > /dev/null 2> $O/pmc_write.err
 LEGO_SERIAL=1 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_issue -- $S > /dev/null 2> $O/pmc_issue.err
@@ -13,5 +17,5 @@ cp $(ls $O/stats_serial/*/*kernel_stats.csv | head -1) $O/kernel_stats_serial.cs
 python3 tools/traffic_from_pmc.py $(ls $O/pmc_fetch/*/*counter_collection.csv | head -1) $(ls $O/pmc_write/*/*counter_collection.csv | head -1) $O/traffic.json > $O/traffic.log 2>&1
 python3 tools/pmc_summary.py $O/pmc_issue.json $(ls $O/pmc_issue/*/*counter_collection.csv | head -1) > $O/pmc_issue.log 2>&1
 rm -rf $O/stats $O/stats_serial $O/pmc_fetch $O/pmc_write $O/pmc_issue
-python3 bench.py --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.err
-ls -la $O
+python3 bench.py --model nrms --steps 100 --warmup 10 --no-cpu-baseline --no-secondary > $O/bench.json 2> $O/bench.err
+ls -la gpurun_out/prof_r04 $O; tail -3 gpurun_out/prof_r04.log

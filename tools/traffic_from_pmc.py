@@ -21,7 +21,7 @@ def tag_of(name):
         return "conv3_bwd_weight"
     if "conv3_wino_unpack_add_kernel" in n:
         return "conv3_bwd_weight_unpack"
-    m = re.match(r"(?:void )?(mhsa_(?:fwd|bwd)_kernel)<(\d+), (\d+)>", n)
+    m = re.match(r"(?:void )?(mhsa_(?:fwd|bwd)_kernel)<(\d+), (\d+)[,>]", n)      # (round 4: the backward has two more template arguments)
     if m:
         return f"{m.group(1)}<{m.group(2)},{m.group(3)}>"
     if "dma_strip_kernel" in n:
