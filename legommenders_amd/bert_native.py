@@ -13,8 +13,8 @@ item are rows, nothing is padded to the page's longest sequence -- built from:
 
 The HF module tree stays what it is (parameter names, state_dict keys, optimizer groups); this module only reads its parameter
 tensors.  Published algorithm of the third-party package (transformers modeling_bert.py: BertEmbeddings, BertSelfAttention,
-BertSelfOutput, BertIntermediate, BertOutput; pinned through the reference-generated fixtures tests/golden/bert_naml_*.npz and
-oracle/lego_oracle.py `_bert_layer`).  Measured against the HF route: DESIGN.md section 5 (config 5 table).
+BertSelfOutput, BertIntermediate, BertOutput; pinned through the reference-generated fixtures tests/golden/bert_naml_*.npz and the
+test suite's CPU restatement of a BERT block).  Measured against the HF route: DESIGN.md section 5 (config 5 table).
 
 Where PyTorch-ROCm's hipBLASLt is used instead of the path's kernel: nowhere by default.  `tools/bert_shapes_bench.py` has the
 per-shape comparison (forward / data-gradient products: hipBLASLt 0-15 % faster at the FFN shapes; weight gradients: the path's

@@ -1,6 +1,6 @@
 // Row-wise kernels of the native BERT block (config 5: the BERT news encoder of config/model/bert-naml.yaml, reference call sites
 // model/operators/once_operator.py:156-193, bert_operator.py:10-52; the arithmetic itself is the third-party `transformers`
-// package's BertEmbeddings / BertSelfOutput / BertIntermediate / BertOutput, restated in oracle/lego_oracle.py `_bert_layer`):
+// package's BertEmbeddings / BertSelfOutput / BertIntermediate / BertOutput; the test suite holds a CPU restatement):
 //
 //   lego_dropout_add_layernorm_fwd / _bwd   out = drop_post(LayerNorm(drop_pre(y) + resid) * gamma + beta)
 //       BertSelfOutput / BertOutput: dense output -> Dropout -> + residual -> LayerNorm   (drop_pre)
