@@ -686,8 +686,20 @@ extern "C" int lego_conv3_wino_bwd_data(const float* gy, int ldg, const float* u
     return launch_wino<true>(w, e, (hipStream_t)stream, "lego_conv3_wino_bwd_data");
 }
 
+// LEGO_CONVW_64=<split> (tuning): the conv weight gradient on 64 x 64 tiles, four workgroups per CU, <split> slabs -- the
+// configuration that took the plain-row weight gradients from 63 to 100 TFLOP/s (more, shorter workgroups hide each other's loads).
+// MEASURED SLOWER for the pair operands (round 4, same box, bench.py --steps 200): 126-138 us against 111-114 us for the 128 x 128
+// one-workgroup-per-CU kernel (step 0.649-0.655 vs 0.631 ms) -- every workgroup re-reads and re-combines its pair rows, and 64-wide
+// tiles double that traffic (~900 MB of L2 reads per launch).  Off by default; kept as the record.
+static int convw64_split() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("LEGO_CONVW_64"); v = e != nullptr ? atoi(e) : 0; }
+    return v;
+}
+
 extern "C" int lego_conv3_wino_du_slabs(int Dout, int Din, int P_cap) {
     if (P_cap < TN_LONG) return 1;                  // short reductions accumulate with atomics into ONE cleared buffer
+    if (convw64_split() > 1) return convw64_split();
     return tn_split(Dout, Din, P_cap, 4);
 }
 
@@ -700,6 +712,15 @@ extern "C" int lego_conv3_wino_bwd_weight(const float* gy, int ldg, const float*
     McPair b{h, ldh, Din, P_cap, pair_info, 0, 0};
     Epi e = make_epi(du, Din);
     e.tap_stride = (size_t)Dout * Din;
+    if (P_cap >= TN_LONG && convw64_split() > 1) {
+        const int split = convw64_split(), tm = (Dout + 63) / 64, tn = (Din + 63) / 64;
+        const int deal = split % 8 == 0;
+        TnDims d{Dout, Din, P_cap, P_dyn, split, 4, (size_t)4 * e.tap_stride, tm, tn, deal};
+        auto k = tn_kernel<McPair, McPair, true, 2, 2, 1>;
+        constexpr size_t lds = tn_lds_bytes(TN_BM_S, TN_BN_S, true);
+        hipLaunchKernelGGL(k, deal ? dim3(tm * tn * 4 * split) : dim3(tm, tn, 4 * split), dim3(TN_THREADS_S), lds, (hipStream_t)stream, d, a, b, e);
+        return check_launch("lego_conv3_wino_bwd_weight");
+    }
     if (lego_conv3_wino_du_slabs(Dout, Din, P_cap) > 1)      // long reduction: one slab per k split, plain stores
         return launch_tn_long<true>(Dout, Din, P_cap, P_dyn, a, b, e, 4, (hipStream_t)stream, "lego_conv3_wino_bwd_weight");
     return launch_tn(Dout, Din, P_cap, P_dyn, a, b, e, 4, (hipStream_t)stream, "lego_conv3_wino_bwd_weight");
