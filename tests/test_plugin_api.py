@@ -125,6 +125,34 @@ def test_unfrozen_pretrained_table_matches_oracle(name):
     assert np.array_equal(np.abs(gt).sum(1) == 0, np.abs(ref_g[tk]).sum(1) == 0)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["naml_glove_d64", "nrms_null_d64"])
+def test_one_item_operator_call_equals_two(name):
+    """id-only batch on the plug-in route: candidates and live history slots through ONE item-operator call
+    (`Legommender._encode_items_once`) against the reference's control flow (one call for the candidates, one for the history):
+    the same loss, gradients and scores"""
+    from legommenders_amd.loader.env import Env
+    dev = torch.device("cuda:0")
+    res = {}
+    for one in (True, False):
+        model, ids, tb, G, logits, loss = _build(name, dev)
+        model.one_item_call = one
+        assert model._one_call_ok(dict(ids)) == one
+        Env.train()
+        model.train()
+        out = model(batch=dict(ids))
+        out.backward()
+        _check_grads(model, G, f"{name} one_call={one}")
+        res[one] = float(out)
+        assert abs(res[one] - loss) < 2e-5
+        Env.test()
+        model.eval()
+        with torch.no_grad():
+            scores = model(batch=dict(ids))
+        assert float(np.abs(scores.cpu().numpy() - logits).max()) < 1e-4
+    assert abs(res[True] - res[False]) < 2e-6
+
+
 def test_class_hub_discovers_reference_names():
     from legommenders_amd.loader.class_hub import ClassHub
     ops, preds = ClassHub.operators(), ClassHub.predictors()
