@@ -39,7 +39,11 @@ def _grads_close(grads, G, name):
         ref = g.astype(np.float64)
         d = got - ref
         scale = float(np.abs(ref).max())
-        assert float(np.abs(d).max()) <= 2e-3 * scale + 2e-7 * gscale, \
+        # the loose max-norm bound is for tensors UPSTREAM of a ReLU only (the conv and what feeds it); every tensor behind it -- the
+        # additive attentions, the user tower -- cannot see a flipped pre-activation and is held 100x tighter
+        behind_relu = "additive_attention" in k or k.startswith("user_op.")
+        rel = 2e-5 if behind_relu else 2e-3
+        assert float(np.abs(d).max()) <= rel * scale + 2e-7 * gscale, \
             f"{name} grad {k}: max|diff|={np.abs(d).max():.3e} scale={scale:.3e}"
         assert float(np.linalg.norm(d)) <= 3e-4 * float(np.linalg.norm(ref)) + 2e-7 * gscale * np.sqrt(d.size), \
             f"{name} grad {k}: |diff|_F={np.linalg.norm(d):.3e} |ref|_F={np.linalg.norm(ref):.3e}"
