@@ -203,6 +203,43 @@ def test_train_step_two_processes_on_one_gpu_over_gloo(tmp_path):
     _same_trajectory({k: v.cpu() for k, v in fp1.P.items()}, r0, P, fp1.names, steps)
 
 
+def _gloo_rank8(rank, world, port, out_dir, steps):
+    import torch.distributed as dist
+    from legommenders_amd.synthetic import init_naml_params
+    from legommenders_amd.train_step import DeviceData, TrainStep
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                            timeout=__import__("datetime").timedelta(seconds=300))
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    w = _world(n_rows=200)
+    P = init_naml_params(D=64, A=64, V=3000, seed=5)
+    ts = TrainStep("naml", P, DeviceData(w, dev, rank=rank, world_size=world, seed=9, balance=8), 8, seed=9, world_size=world,
+                   process_group=dist.group.WORLD, dropout=False, total_steps=50)
+    for _ in range(steps):
+        ts.step()
+    torch.cuda.synchronize()
+    torch.save({k: v.cpu() for k, v in ts.fp.P.items()}, os.path.join(out_dir, f"r8_{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_train_step_eight_processes_on_one_gpu_over_gloo(tmp_path):
+    """EIGHT real processes (the rank count of BASELINE config 4) run `TrainStep.step()` -- cost-balanced dealing over 8 ranks,
+    device sampler keyed on global positions, the step's own all-reduce (gloo: RCCL refuses several ranks on one device), Adam with
+    1/8 -- sharing the GPU, two epochs incl. the short last batch, against one device with batch 64"""
+    from legommenders_amd.synthetic import init_naml_params
+    W, steps = 8, 8
+    spawn_ranks(_gloo_rank8, (W, _free_port(), str(tmp_path), steps), W, deadline=600.0)
+    rs = [torch.load(os.path.join(str(tmp_path), f"r8_{r}.pt")) for r in range(W)]
+    for r in rs[1:]:
+        for k in rs[0]:
+            assert torch.equal(rs[0][k], r[k]), k                    # replicas stay bit-identical
+    dev = _dev()
+    P = init_naml_params(D=64, A=64, V=3000, seed=5)
+    fp1, _ = _trajectory_single("naml", P, _world(n_rows=200), dev, 64, steps)
+    assert fp1 is not None
+    _same_trajectory({k: v.cpu() for k, v in fp1.P.items()}, rs[0], P, fp1.names, steps)
+
+
 def _gloo_rank_table(rank, world, port, out_dir, steps):
     """NRMS with the trainable token table: the step's exchange runs in its OVERLAPPED form (engine.grad_hooks: dense part at
     the join of the side streams, the table gradient as bucketed scatters, each bucket all-reduced behind its own scatter)"""
