@@ -365,8 +365,9 @@ int lego_dropout_add_layernorm_fwd(const float* y, int ldy, const float* resid, 
                                    float* mean /*[rows]*/, float* rstd /*[rows]*/, int rows, int width, void* stream);
 int lego_dropout_add_layernorm_bwd(const float* dout, int lddo, const float* y, int ldy, const float* resid, int ldr, const float* gamma,
                                    const float* mean, const float* rstd, const lego_dropout* drop_pre, const lego_dropout* drop_post,
-                                   float* dy, int lddy, float* dresid, int lddr, float* dgamma, float* dbeta, int rows, int width,
-                                   void* stream);
+                                   float* dy, int lddy, float* dresid, int lddr, float* dgamma, float* dbeta,
+                                   float* dybias /*nullable [width], += column sums of dy: the bias gradient of the layer that produced y*/,
+                                   int rows, int width, void* stream);
 /* g = z Phi(z) (erf form) over n contiguous floats; dz = dg (Phi(z) + z phi(z)), dz may alias dg */
 int lego_gelu_fwd(const float* z, float* g, int64_t n, void* stream);
 int lego_gelu_bwd(const float* dg, const float* z, float* dz, int64_t n, void* stream);

@@ -84,7 +84,7 @@ SIGNATURES = {
     "lego_gather_i32": [P, P, I, P, P, P],
     "lego_segment_live": [P, I, P, P, P],
     "lego_dropout_add_layernorm_fwd": [P, I, P, I, P, P, F, P, P, P, I, P, P, I, I, P],
-    "lego_dropout_add_layernorm_bwd": [P, I, P, I, P, I, P, P, P, P, P, P, I, P, I, P, P, I, I, P],
+    "lego_dropout_add_layernorm_bwd": [P, I, P, I, P, I, P, P, P, P, P, P, I, P, I, P, P, P, I, I, P],
     "lego_gelu_fwd": [P, P, I64, P],
     "lego_gelu_bwd": [P, P, P, I64, P],
     "lego_grouped_metrics": [P, P, P, I, P, I, P, P],

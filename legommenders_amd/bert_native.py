@@ -150,10 +150,10 @@ def _ln_fwd(y, resid, gamma, beta, eps, pre, post, out, mean, rstd):
          _ptr(mean), _ptr(rstd), R, W, _stream())
 
 
-def _ln_bwd(dout, y, resid, gamma, mean, rstd, pre, post, dy, dresid, dgamma, dbeta):
+def _ln_bwd(dout, y, resid, gamma, mean, rstd, pre, post, dy, dresid, dgamma, dbeta, dybias=None):
     R, W = y.shape
     call("lego_dropout_add_layernorm_bwd", _ptr(dout), W, _ptr(y), W, _ptr(resid), W, _ptr(gamma), _ptr(mean), _ptr(rstd), pre, post,
-         _ptr(dy), W, _ptr(dresid), W, _ptr(dgamma), _ptr(dbeta), R, W, _stream())
+         _ptr(dy), W, _ptr(dresid), W, _ptr(dgamma), _ptr(dbeta), _ptr(dybias), R, W, _stream())
 
 
 class _Blocks(torch.autograd.Function):
@@ -246,8 +246,17 @@ class _Blocks(torch.autograd.Function):
         def want(i):                                 # gradient of params[i] wanted?
             return need[n_fixed + i]
 
+        # every wanted gradient is a view of ONE zero-filled buffer (one fill launch per backward instead of one per tensor; the
+        # products and the LayerNorm column sums accumulate into it)
+        sizes = [(p.numel() + 3) // 4 * 4 if need[n_fixed + i] else 0 for i, p in enumerate(params)]
+        flat = torch.zeros(sum(sizes), **f)
+        offs, o = [], 0
+        for sz in sizes:
+            offs.append(o)
+            o += sz
+
         def gbuf(i):
-            grads[i] = torch.zeros_like(params[i], dtype=torch.float32)
+            grads[i] = flat[offs[i]:offs[i] + params[i].numel()].view(params[i].shape)
             return grads[i]
         dh = K.gather_rows(gout.detach().float().contiguous().view(n * L, H), ctx.idx)
         for l in reversed(range(n_layers)):
@@ -258,11 +267,10 @@ class _Blocks(torch.autograd.Function):
             # ---- BertOutput: hn = LN(drop(fo) + a)
             d_fo, d_a = torch.empty(R, H, **f), torch.empty(R, H, **f)
             _ln_bwd(dh, fo, a, g2, mean2, rstd2, _redrop(rng2), None, d_fo, d_a,
-                    gbuf(base + 14) if want(base + 14) else None, gbuf(base + 15) if want(base + 15) else None)
+                    gbuf(base + 14) if want(base + 14) else None, gbuf(base + 15) if want(base + 15) else None,
+                    gbuf(base + 13) if want(base + 13) else None)                         # ... and b2's gradient = colsum(d_fo), same pass
             if want(base + 12):
                 _lin_bwd_weight(d_fo, H, 0, g, gbuf(base + 12), tag="ffn2_bwd_weight")
-            if want(base + 13):
-                _colsum(d_fo, H, 0, H, gbuf(base + 13))
             dg = torch.empty(R, I, **f)
             _lin_bwd_data(d_fo, H, 0, W2, dg, False, tag="ffn2_bwd_data")
             call("lego_gelu_bwd", _ptr(dg), _ptr(z), _ptr(dg), R * I, _stream())          # dz in place
@@ -275,11 +283,10 @@ class _Blocks(torch.autograd.Function):
             # ---- BertSelfOutput: a = LN(drop(ao) + h)
             d_ao, d_h = torch.empty(R, H, **f), torch.empty(R, H, **f)
             _ln_bwd(d_a, ao, h, g1, mean1, rstd1, _redrop(rng1), None, d_ao, d_h,
-                    gbuf(base + 8) if want(base + 8) else None, gbuf(base + 9) if want(base + 9) else None)
+                    gbuf(base + 8) if want(base + 8) else None, gbuf(base + 9) if want(base + 9) else None,
+                    gbuf(base + 7) if want(base + 7) else None)                           # bo's gradient = colsum(d_ao)
             if want(base + 6):
                 _lin_bwd_weight(d_ao, H, 0, ctxv, gbuf(base + 6), tag="attn_out_bwd_weight")
-            if want(base + 7):
-                _colsum(d_ao, H, 0, H, gbuf(base + 7))
             d_ctx = d_a                                                                   # reuse: d_a is consumed
             _lin_bwd_data(d_ao, H, 0, Wo, d_ctx, False, tag="attn_out_bwd_data")
             # ---- attention core: d(qkv) and, fused, the three bias gradients (column sums of d(qkv))

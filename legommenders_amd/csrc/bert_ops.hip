@@ -94,25 +94,26 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ y
 
 // backward: v = drop_pre(y) + resid is formed again from the saved y / resid rows and the redrawn keep bits; with xh = (v - mu) rs,
 //   do = dout * post,  dxh = do * gamma,  dv = rs (dxh - mean(dxh) - xh mean(dxh xh)),  dresid = dv,  dy = dv * pre,
-//   dgamma += sum_rows do xh,  dbeta += sum_rows do   (per-wave register partials -> LDS fold over the workgroup's 4 waves -> one
+//   dgamma += sum_rows do xh,  dbeta += sum_rows do,  dybias += sum_rows dy   (per-wave register partials -> LDS fold over the workgroup's 4 waves -> one
 //   atomicAdd per column and workgroup)
 template <int NJ>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dout, int lddo, const float* __restrict__ y, int ldy,
                                                      const float* __restrict__ resid, int ldr, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd, Dropout dpre,
                                                      Dropout dpost, float* __restrict__ dy, int lddy, float* __restrict__ dresid, int lddr,
-                                                     float* dgamma, float* dbeta, int rows, int W) {
-    __shared__ float red[4][2][LN_MAX_NJ * 256];
+                                                     float* dgamma, float* dbeta, float* dybias, int rows, int W) {
+    __shared__ float red[4][3][LN_MAX_NJ * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int waves = gridDim.x * (blockDim.x >> 6);
     const float inv_pre = dpre.p > 0.f ? 1.f / (1.f - dpre.p) : 1.f, inv_post = dpost.p > 0.f ? 1.f / (1.f - dpost.p) : 1.f;
-    f32x4 gm[NJ], ag[NJ], ab[NJ];
+    f32x4 gm[NJ], ag[NJ], ab[NJ], ay[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int c = 4 * (lane + 64 * j);
         gm[j] = c < W ? *reinterpret_cast<const f32x4*>(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
         ag[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         ab[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ay[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const float invW = 1.f / (float)W;
     for (int g8 = blockIdx.x * (blockDim.x >> 6) + wave; g8 * 8 < rows; g8 += waves) {
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                     for (int i = 0; i < 4; ++i) {
                         dv[i] = rs * (dx[j][i] - m1 - xh[j][i] * m2);
                         dyv[i] = dv[i] * (((kpre[j][i] >> f) & 1u) ? inv_pre : 0.f);
+                        ay[j][i] += dyv[i];
                     }
                     if (dresid != nullptr) *reinterpret_cast<f32x4*>(dresid + (size_t)r * lddr + c) = dv;
                     if (dy != nullptr) *reinterpret_cast<f32x4*>(dy + (size_t)r * lddy + c) = dyv;
@@ -173,13 +175,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         for (int i = 0; i < 4; ++i) {
             red[wave][0][4 * (lane + 64 * j) + i] = ag[j][i];
             red[wave][1][4 * (lane + 64 * j) + i] = ab[j][i];
+            red[wave][2][4 * (lane + 64 * j) + i] = ay[j][i];
         }
     __syncthreads();
     for (int c = threadIdx.x; c < W; c += blockDim.x) {
         const float sg = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
         const float sb = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
+        const float sy = red[0][2][c] + red[1][2][c] + red[2][2][c] + red[3][2][c];
         if (dgamma != nullptr) atomicAdd(dgamma + c, sg);
         if (dbeta != nullptr) atomicAdd(dbeta + c, sb);
+        if (dybias != nullptr) atomicAdd(dybias + c, sy);       // column sums of dy: the bias gradient of the dense layer that produced y
     }
 }
 
@@ -237,7 +242,7 @@ extern "C" int lego_dropout_add_layernorm_fwd(const float* y, int ldy, const flo
 extern "C" int lego_dropout_add_layernorm_bwd(const float* dout, int lddo, const float* y, int ldy, const float* resid, int ldr,
                                               const float* gamma, const float* mean, const float* rstd, const lego_dropout* drop_pre,
                                               const lego_dropout* drop_post, float* dy, int lddy, float* dresid, int lddr, float* dgamma,
-                                              float* dbeta, int rows, int width, void* stream) {
+                                              float* dbeta, float* dybias, int rows, int width, void* stream) {
     LEGO_REQUIRE(width > 0 && (width & 3) == 0 && width <= 256 * LN_MAX_NJ && (ldy & 3) == 0 && (lddo & 3) == 0 && (resid == nullptr || (ldr & 3) == 0) &&
                  (dy == nullptr || (lddy & 3) == 0) && (dresid == nullptr || (lddr & 3) == 0),
                  "lego_dropout_add_layernorm_bwd: width=%d (multiple of 4, <= %d) and every leading dimension must be a multiple of 4", width,
@@ -246,7 +251,7 @@ extern "C" int lego_dropout_add_layernorm_bwd(const float* dout, int lddo, const
     const Dropout a = make_dropout(drop_pre), b = make_dropout(drop_post);
     const int nj = (width + 255) / 256;
     const int grid = ln_grid(rows) < 512 ? ln_grid(rows) : 512;          // fewer, longer-lived workgroups: fewer column atomics
-#define GO(NJ) hipLaunchKernelGGL((ln_bwd_kernel<NJ>), dim3(grid), dim3(256), 0, ST, dout, lddo, y, ldy, resid, ldr, gamma, mean, rstd, a, b, dy, lddy, dresid, lddr, dgamma, dbeta, rows, width)
+#define GO(NJ) hipLaunchKernelGGL((ln_bwd_kernel<NJ>), dim3(grid), dim3(256), 0, ST, dout, lddo, y, ldy, resid, ldr, gamma, mean, rstd, a, b, dy, lddy, dresid, lddr, dgamma, dbeta, dybias, rows, width)
     switch (nj) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; default: GO(4); break; }
 #undef GO
     return check_launch("lego_dropout_add_layernorm_bwd");

@@ -333,10 +333,11 @@ def test_layernorm_tail_and_gelu_kernels_match_torch(W, rows):
         call("lego_dropout_add_layernorm_fwd", _ptr(y), W, _ptr(res), W, _ptr(gam), _ptr(bet), eps, pre, post, _ptr(out), W, _ptr(mean),
              _ptr(rstd), rows, W, _stream())
         dy, dr = torch.empty(rows, W, device=dev), torch.empty(rows, W, device=dev)
-        dg, db = torch.zeros(W, device=dev), torch.zeros(W, device=dev)
+        dg, db, dyb = torch.zeros(W, device=dev), torch.zeros(W, device=dev), torch.zeros(W, device=dev)
         call("lego_dropout_add_layernorm_bwd", _ptr(do), W, _ptr(y), W, _ptr(res), W, _ptr(gam), _ptr(mean), _ptr(rstd), pre, post,
-             _ptr(dy), W, _ptr(dr), W, _ptr(dg), _ptr(db), rows, W, _stream())
+             _ptr(dy), W, _ptr(dr), W, _ptr(dg), _ptr(db), _ptr(dyb), rows, W, _stream())
         torch.cuda.synchronize()
+        assert float((dyb.double() - dy.double().sum(0)).abs().max()) <= 2e-5 * float(dy.double().sum(0).abs().max()) + 1e-5   # fused colsum(dy)
         return out, dy, dr, dg, db
 
     def ref(mpre, mpost):
