@@ -26,6 +26,7 @@ from . import _lib
 from ._lib import LegoDropout, call
 
 SITE_PROJ, SITE_CONV, SITE_ITEM_ATT, SITE_USER_ATT = 0, 1, 2, 3
+RI_LIVE_BIT = 4        # csrc/common.hpp RI_LIVE
 
 
 def _ptr(t: Optional[torch.Tensor], off: int = 0):
@@ -757,6 +758,31 @@ class NrmsEngine(_Base):
             self.mask_proj = torch.zeros((((self.Rc + 3) // 4) * D if glove else 0) + 4, dtype=torch.uint8, device=self.dev)
         self._slot_mask_step, self._mask_step = {}, -1
         self._slot_clean = {}
+        # Trainable table (embed/null), round 4: EVERY position of a sequence row is a pure function of an id -- the token id, the [SEP]
+        # id or the category id (ConcatInputer sums three look-ups of which exactly one is live per position, concat_inputer.py:96-114;
+        # no Dropout sits between the table and the attention's in-projection when the table is not pre-trained) -- so the in-projection
+        # q|k|v = E W_in^T + b is computed once per DISTINCT key of the batch (~4.5 k of 30.7 k rows) and expanded; its weight gradient and
+        # its data gradient (= the three tables' gradients) are formed from per-key sums of d(qkv).  Key space: tokens [0, V), [SEP] -> V,
+        # category c -> V + 1 + c.  Exact up to fp32 summation order.  LEGO_NRMS_QKV_DEDUP=0: row by row.
+        self.qkv_dedup = self.dedup and not glove and os.environ.get("LEGO_NRMS_QKV_DEDUP", "1") != "0"
+        if self.qkv_dedup:
+            n_cat = P["embedding_vocab_table.category.weight"].shape[0]
+            self.Vk = self.V + 1 + n_cat
+            self.Uc = min(self.Rc, self.Vk)
+            self.uq_stamp = torch.zeros(self.Vk, **i32)
+            self.uq_rank = torch.zeros(self.Vk, **i32)
+            self.uq_bsum = torch.zeros((self.Vk + 1023) // 1024 + 1, **i32)
+            self.uq_cnt = torch.zeros(self.Uc + 1, **i32)
+            self.uq_start = torch.zeros(self.Uc + 1, **i32)
+            self.uniq = torch.zeros(self.Uc, **i32)
+            self.dHu = self._f(self.Uc, D)                              # d(E) per distinct key
+            self.row_key = torch.zeros(self.Rc, **i32)
+            self.idx_tok_u, self.idx_spec_u = torch.zeros(self.Uc, **i32), torch.zeros(self.Uc, **i32)
+            self.idx_cat_u, self.tokinfo_u = torch.zeros(self.Uc, **i32), torch.zeros(self.Uc, **i32)
+            self.Eu = self._f(self.Uc, D)
+            self.QKVu = self._f(self.Uc, 3 * D)
+            self.dQKVu = self._f(self.Uc, 3 * D)
+            self._kconst = {k: torch.tensor(k, **i32) for k in (-1, 0, 2, RI_LIVE_BIT)}
         self.X = (self._f(1, self.E0) if self.dedup else self._f(self.Rc, self.E0)) if glove else None
         self.E = self._f(self.Rc, D)
         self.dE = self._f(self.Rc, D)
@@ -779,7 +805,8 @@ class NrmsEngine(_Base):
     def enable_plan_slots(self):
         if getattr(self, "_slots", None) is None and (self.glove or self.dedup):
             self._PLAN_FIELDS = NrmsEngine._PLAN_FIELDS + (
-                (("Xu", "mask_proj") if self.glove else ()) + ("uniq", "inv", "perm", "keys_sorted", "dHu") if self.dedup else ("X",))
+                (("Xu", "mask_proj") if self.glove else ()) + ("uniq", "inv", "perm", "keys_sorted", "dHu") if self.dedup else ("X",)) + (
+                ("idx_tok_u", "idx_spec_u", "idx_cat_u", "tokinfo_u") if self.qkv_dedup else ())
         return super().enable_plan_slots()
 
     def prefetch_masks(self, stream, slot):
@@ -836,7 +863,12 @@ class NrmsEngine(_Base):
             E0 = self.E0
             self._uq_epoch = self._uq_epoch % 0x7FFFFFF0 + 1
             self._uq_begin(stream)
-            call("lego_unique_tokens", _ptr(b["row_tok"]), self.Rc, _ptr(b["counters"], 0), self.V, _ptr(self.uq_stamp), self._uq_epoch,
+            keys, nkeys = b["row_tok"], self.V
+            if self.qkv_dedup:                       # every position gets a key >= 0: tokens as they are, [SEP] (-2) -> V, category -(3+c) -> V+1+c
+                with torch.cuda.stream(stream):
+                    torch.where(b["row_tok"] >= 0, b["row_tok"], (self.V - 2) - b["row_tok"], out=self.row_key)
+                keys, nkeys = self.row_key, self.Vk
+            call("lego_unique_tokens", _ptr(keys), self.Rc, _ptr(b["counters"], 0), nkeys, _ptr(self.uq_stamp), self._uq_epoch,
                  _ptr(self.uq_rank), _ptr(self.uq_bsum), _ptr(b["uniq"]), _ptr(b["inv"]), _ptr(self.uq_cnt), _ptr(self.uq_start), None,
                  _ptr(self.uq_keys), _ptr(b["counters"], 6), st)
             if self.glove:
@@ -845,7 +877,15 @@ class NrmsEngine(_Base):
             call("lego_sort_rows", _ptr(self.uq_keys), self.Rc, _ptr(b["keys_sorted"]), _ptr(b["perm"]), _ptr(self.uq_temp),
                  self.uq_temp.numel(), st)
             self._uq_end(stream)
-            if b is not self.__dict__:               # a plan slot: its per-token sums start from rows cleared here, off the main stream
+            if self.qkv_dedup:                       # the distinct keys back into per-table row indices (-1 = not this table's)
+                with torch.cuda.stream(stream):
+                    u, V = b["uniq"], self.V
+                    c = self._kconst
+                    torch.where(u < V, u, c[-1], out=b["idx_tok_u"])
+                    torch.where(u == V, c[2], c[-1], out=b["idx_spec_u"])             # [SEP] = id 2 of the special vocabulary
+                    torch.where(u > V, u - (V + 1), c[-1], out=b["idx_cat_u"])
+                    torch.where(u < V, c[RI_LIVE_BIT], c[0], out=b["tokinfo_u"])
+            elif b is not self.__dict__:             # a plan slot: its per-token sums start from rows cleared here, off the main stream
                 call("lego_zero_rows", _ptr(b["dHu"]), self.D, self.D, self.Uc, _ptr(b["counters"], 6), st)
         elif self.glove:
             E0 = self.E0
@@ -869,7 +909,7 @@ class NrmsEngine(_Base):
                     pooled=self._f(n_seg, D), d_pooled=self._f(n_seg, D))
 
     # AttentionOperator.forward over ragged segments
-    def _att_fwd(self, pre, ws, x_ptr, rows_dyn, seg_off, n_cap, n_dyn, out, site, training, st, head=False):
+    def _att_fwd(self, pre, ws, x_ptr, rows_dyn, seg_off, n_cap, n_dyn, out, site, training, st, head=False, per_key=False):
         P, D, A = self.P, self.D, self.A
         rows = ws["rows"]
         m = torch.cuda.current_stream()          # == st; tagged launches are HIP-event timed on it when bench.py asks
@@ -878,9 +918,16 @@ class NrmsEngine(_Base):
         Wo, bo = P[pre + "multi_head_attention.out_proj.weight"], P[pre + "multi_head_attention.out_proj.bias"]
         Wl, bl = P[pre + "linear.weight"], P[pre + "linear.bias"]
         w2 = P[pre + "additive_attention.encoder.2.weight"]
-        self.kk(m, "qkv_fwd_" + tg, "lego_linear_fwd", x_ptr, D, _ptr(P[pre + "multi_head_attention.in_proj_weight"]), D,
-                _ptr(P[pre + "multi_head_attention.in_proj_bias"]), _ptr(ws["qkv"]), 3 * D, rows, rows_dyn, 3 * D, D, 0,
-                None, None, None, None)
+        if per_key:                                  # x_ptr = Eu [U, D]: project the distinct keys, expand q|k|v to the sequence rows
+            self.kk(m, "qkv_fwd_" + tg, "lego_linear_fwd", x_ptr, D, _ptr(P[pre + "multi_head_attention.in_proj_weight"]), D,
+                    _ptr(P[pre + "multi_head_attention.in_proj_bias"]), _ptr(self.QKVu), 3 * D, self.Uc, self.cnt(6), 3 * D, D, 0,
+                    None, None, None, None)
+            self.kk(m, "qkv_expand_" + tg, "lego_expand_rows", _ptr(self.QKVu), 3 * D, _ptr(self.inv), rows, rows_dyn, 3 * D, None, None,
+                    None, 0, None, None, 0, None, _ptr(ws["qkv"]), 3 * D)
+        else:
+            self.kk(m, "qkv_fwd_" + tg, "lego_linear_fwd", x_ptr, D, _ptr(P[pre + "multi_head_attention.in_proj_weight"]), D,
+                    _ptr(P[pre + "multi_head_attention.in_proj_bias"]), _ptr(ws["qkv"]), 3 * D, rows, rows_dyn, 3 * D, D, 0,
+                    None, None, None, None)
         core = ("lego_mhsa_core_fwd", _ptr(ws["qkv"]), 3 * D, _ptr(seg_off), n_cap, n_dyn, D, self.heads,
                 _ptr(ws["o"]), D, _ptr(ws["lse"]), _ptr(ws["probs"]), ws["Lmax"], self.drop(self.p_att, site, training), rows)
         self.kk(m, "mhsa_core_fwd_" + tg, *core, *self._part(pre, ws))
@@ -980,7 +1027,7 @@ class NrmsEngine(_Base):
         m = torch.cuda.current_stream()
         return m, (m if os.environ.get("LEGO_SERIAL") == "1" else self._sw)
 
-    def _att_bwd(self, pre, ws, G, x_ptr, dx_ptr, rows_dyn, seg_off, n_cap, n_dyn, gout, site, training, st, ev, dx_epi=None):
+    def _att_bwd(self, pre, ws, G, x_ptr, dx_ptr, rows_dyn, seg_off, n_cap, n_dyn, gout, site, training, st, ev, dx_epi=None, per_key=False):
         """data-gradient chain on the current stream `st`; weight gradients in two groups on the side stream, each behind
         ONE event (`ev[0]`, `ev[1]`) recorded where its inputs are final (the workspace is not overwritten before the
         next forward, which the caller orders after the side stream)"""
@@ -997,6 +1044,27 @@ class NrmsEngine(_Base):
                 self.drop(self.p_att, site, training), rows, _ptr(ws["d_qkv"]), 3 * D,
                 _ptr(G[pre + "multi_head_attention.in_proj_bias"]))      # bias gradient = column sums of d_qkv, fused
         self.kk(m, "mhsa_core_bwd_" + pre[:4], *core, *self._part(pre, ws))
+        if per_key:
+            # d(qkv) summed per distinct key, then both products of the in-projection's backward over the ~4.5 k keys instead of the
+            # ~31 k sequence rows: dW_in = dQKVu^T Eu (side stream), dEu = dQKVu W_in (x_ptr = Eu, dx_ptr = dEu)
+            W_in = P[pre + "multi_head_attention.in_proj_weight"]
+            self.kk(m, "qkv_bwd_segsum", "lego_segment_sum_rows", _ptr(ws["d_qkv"]), 3 * D, 3 * D, _ptr(self.perm), _ptr(self.inv), rows,
+                    _ptr(self.keys_sorted), rows_dyn, _ptr(self.dQKVu), 3 * D, self.Uc, self.cnt(6), 1, None, None)
+            if sw is not m:
+                ev[1].record(m)
+
+            def side2k():
+                if sw is not m:
+                    sw.wait_event(ev[1])
+                call("lego_linear_bwd_weight", _ptr(self.dQKVu), 3 * D, x_ptr, D, _ptr(G[pre + "multi_head_attention.in_proj_weight"]), D,
+                     self.Uc, self.cnt(6), 3 * D, D, None, None, sp)
+            if self.fold == 2:
+                self._deferred.append(side2k)
+            else:
+                side2k()
+            call("lego_linear_bwd_data", _ptr(self.dQKVu), 3 * D, _ptr(W_in), D, dx_ptr, D, self.Uc, self.cnt(6), 3 * D, D, 0,
+                 None, 0, 1.0, None, None, None, None, None, st)
+            return
         if sw is not m:
             ev[1].record(m)
 
@@ -1121,6 +1189,31 @@ class NrmsEngine(_Base):
             call("lego_linear_bwd_data", _ptr(ws["d_att"]), D, _ptr(Wo), D,
                  _ptr(ws["d_o"]), D, rows, rows_dyn, D, D, 0, None, 0, 1.0, None, None, None, None, None, st)
 
+    def _key_table_grads(self, G, g_spec, g_cat, n_cat, st):
+        """per-key in-projection (qkv_dedup): dEu [U, D] is the gradient of the ONE live look-up of every distinct key -- added to the row
+        of the table that key belongs to (no two keys share a destination row)"""
+        D, V = self.D, self.V
+        call("lego_scatter_add_rows", _ptr(g_spec), D, D, 3, _ptr(self.idx_spec_u), self.Uc, self.cnt(6), _ptr(self.dHu), D, st)
+        call("lego_scatter_add_rows", _ptr(g_cat), D, D, n_cat, _ptr(self.idx_cat_u), self.Uc, self.cnt(6), _ptr(self.dHu), D, st)
+        if self.touched_rows is not None:
+            call("lego_mark_rows", _ptr(self.idx_tok_u), self.Uc, self.cnt(6), V, _ptr(self.touched_rows), st)
+        if self.grad_hooks is None:
+            call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.glove.weight"]), D, D, V, _ptr(self.idx_tok_u), self.Uc, self.cnt(6),
+                 _ptr(self.dHu), D, st)
+
+    def _key_table_buckets(self, G, st):
+        """data parallel: the table gradient one destination-row bucket at a time, each handed to the exchange behind its scatter"""
+        if self.grad_hooks is None:
+            return
+        D, V = self.D, self.V
+        dense_ready, bucket_ready, per = self.grad_hooks
+        dense_ready()
+        for lo in range(0, V, per):
+            hi = min(V, lo + per)
+            call("lego_scatter_add_rows_range", _ptr(G["embedding_vocab_table.glove.weight"]), D, D, _ptr(self.idx_tok_u), self.Uc,
+                 self.cnt(6), _ptr(self.dHu), D, lo, hi, st)
+            bucket_ready(lo, hi)
+
     def _plan_tables(self):
         return self.seq_tok, self.seq_len, self.L
 
@@ -1190,6 +1283,14 @@ class NrmsEngine(_Base):
             # trainable table (embed/null): the three look-ups ConcatInputer sums (concat_inputer.py:96-114) in ONE pass over the sequence
             # rows -- token row where the position holds a token (tokinfo's live bit; idx_tok is -1 elsewhere and not read), plus the
             # special-id and category rows where those indices are >= 0
+            if self.qkv_dedup:                       # Eu[u] = the one live look-up of distinct key u (token / [SEP] / category row)
+                self.kk(torch.cuda.current_stream(), "embed_gather_item", "lego_expand_rows", _ptr(P["embedding_vocab_table.glove.weight"]), D,
+                        _ptr(self.idx_tok_u), self.Uc, self.cnt(6), D, None, _ptr(self.tokinfo_u),
+                        _ptr(P["embedding_vocab_table.__cat_inputer_special_ids.weight"]), D, _ptr(self.idx_spec_u),
+                        _ptr(P["embedding_vocab_table.category.weight"]), D, _ptr(self.idx_cat_u), _ptr(self.Eu), D)
+                self._att_fwd("item_op.", self.item_ws, _ptr(self.Eu), self.cnt(0), self.seg_off, self.NIc, self.cnt(1),
+                              self.items, SITE_ITEM_ATT, training, st, per_key=True)
+                return
             # (tagged: bench.py prices this launch -- the trainable table's row gather, on the step's critical path -- against the HBM roof)
             self.kk(torch.cuda.current_stream(), "embed_gather_item", "lego_expand_rows", _ptr(P["embedding_vocab_table.glove.weight"]), D,
                     _ptr(self.idx_tok), self.Rc, self.cnt(0), D, None,
@@ -1246,6 +1347,19 @@ class NrmsEngine(_Base):
             # the data gradient of the in-projection lands in dE already masked + dropout-scaled, with the projection's bias gradient as
             # its column sums (one epilogue instead of two more passes over dE: 20 + 18-26 us of the main stream's tail)
             epi = (_ptr(self.tokinfo), self.drop(self.p_proj, SITE_PROJ, training), _ptr(G["embedding_vocab_table.glove.linear.bias"]))
+        if self.qkv_dedup:
+            self._att_bwd("item_op.", self.item_ws, G, _ptr(self.Eu), _ptr(self.dHu), self.cnt(0), self.seg_off, self.NIc,
+                          self.cnt(1), self.d_items, SITE_ITEM_ATT, training, st, sev[2:4], per_key=True)
+            self._key_table_grads(G, g_spec, g_cat, n_cat, st)
+            for side in self._deferred:
+                side()
+            self._deferred = ()
+            if sw is not m:
+                sev[4].record(sw)
+                m.wait_event(sev[4])
+            self._key_table_buckets(G, st)
+            self.step = step_save
+            return
         self._att_bwd("item_op.", self.item_ws, G, _ptr(self.E), _ptr(self.dE), self.cnt(0), self.seg_off, self.NIc,
                       self.cnt(1), self.d_items, SITE_ITEM_ATT, training, st, sev[2:4], dx_epi=epi)
         # embedding tables: the three summed look-ups of ConcatInputer.get_embeddings.  [SEP] (id 2 of the special table) and the
