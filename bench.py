@@ -390,7 +390,10 @@ def main():
                     "additive_fwd_item": 2.0 * yrows * D * 256,
                     "additive_bwd_data": 2.0 * rows * D * 256,
                     "additive_bwd_weight_item": 2.0 * yrows * D * 256}
-        return nrms_flops(rows, D, E0)
+        f = nrms_flops(rows, D, E0)
+        if getattr(eng, "qkv_dedup", False) and uniq is not None:
+            f["qkv_fwd_item"] = 2.0 * uniq * D * 3 * D       # per-key in-projection (trainable table): the product runs over the distinct keys
+        return f
 
     if args.model == "naml":
         solo = ("conv3_fwd", "proj_fwd", "additive_fwd_item")
@@ -511,15 +514,27 @@ def main():
             cn = tn.counter_sum.tolist()
             tmn, rn, _ = tagged_steps(tn, 8, barrier)
             kn = kernel_table(tmn)
-            price(kn, nrms_flops(rn, D, E0), ())
+            per_key = bool(getattr(tn.engine, "qkv_dedup", False))
+            un = tagged_steps.uniq
+            fn_ = nrms_flops(rn, D, E0)
+            if per_key:
+                fn_["qkv_fwd_item"] = 2.0 * un * D * 3 * D     # the in-projection runs over the distinct keys
+            price(kn, fn_, ())
             price_hbm(kn, nrms_core_bytes(rn, D))
-            gb = rn * (D * 4.0 * 2 + 16.0)                     # table row read + E row written + three index words and the token info
-            price_hbm(kn, {"embed_gather_item": gb})
+            # per-key form (round 4): ONE look-up per distinct key of the batch, the in-projection over those keys, q|k|v expanded to the rows
+            gb = (un if per_key else rn) * (D * 4.0 * 2 + 16.0)     # table row read + E row written + the index words
+            hb = {"embed_gather_item": gb}
+            if per_key:
+                hb["qkv_expand_item"] = rn * (3 * D * 4.0 + 4.0) + un * 3 * D * 4.0          # one 3 KB q|k|v row written per sequence row
+                hb["qkv_bwd_segsum"] = rn * (3 * D * 4.0 + 8.0) + un * 3 * D * 4.0           # every d(qkv) row read once, one sum row per key
+            price_hbm(kn, hb)
             g = kn.get("embed_gather_item", {})
             sec[f"nrms_null_hidden{D}_bs{B}"] = {
                 "workload": f"MIND-small-shaped NRMS hidden={D} bs={B}, trainable 400k x {D} token table (embed/null), full train step",
                 "steps": 60, "warmup": 10, "ms_per_step": round(dn / 60 * 1e3, 4), "value": round(B * 60 / dn, 1), "unit": "impressions/s",
-                "live_token_rows_per_step": round(cn[0] / 60, 1),
+                "live_token_rows_per_step": round(cn[0] / 60, 1), "distinct_keys_per_step": round(cn[6] / 60, 1) if per_key else None,
+                "in_projection": ("once per DISTINCT key of the batch (token / [SEP] / category id), q|k|v expanded to the sequence rows; weight and table "
+                                  "gradients from per-key sums of d(qkv) (exact; LEGO_NRMS_QKV_DEDUP=0: row by row)") if per_key else "row by row",
                 "roofline_gather": {"kernel": "embed_gather_item (lego_expand_rows: token + [SEP] + category look-ups summed in one pass)",
                                     "bound": "hbm", "achieved": round(g.get("gb_per_s", 0.0), 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                     "frac": round(g.get("frac_of_hbm_peak", 0.0), 4), "avg_launch_ms": round(g.get("avg_ms", 0.0), 5),
