@@ -18,4 +18,17 @@ python3 tools/traffic_from_pmc.py $(ls $O/pmc_fetch/*/*counter_collection.csv | 
 python3 tools/pmc_summary.py $O/pmc_issue.json $(ls $O/pmc_issue/*/*counter_collection.csv | head -1) > $O/pmc_issue.log 2>&1
 rm -rf $O/stats $O/stats_serial $O/pmc_fetch $O/pmc_write $O/pmc_issue
 python3 bench.py --model nrms --steps 100 --warmup 10 --no-cpu-baseline --no-secondary > $O/bench.json 2> $O/bench.err
-ls -la gpurun_out/prof_r04 $O; tail -3 gpurun_out/prof_r04.log
+# NRMS with the trainable token table (per-key in-projection): kernel statistics, serial and overlapped, and the bench line
+Q=gpurun_out/prof_r04_nrms_null; rm -rf $Q; mkdir -p $Q
+BN="python3 bench.py --model nrms --embed null --steps 100 --warmup 10 --no-cpu-baseline --no-secondary --no-dist-check"
+rocprofv3 --kernel-trace --stats --output-format csv -d $Q/stats -- $BN > $Q/bench_under_rocprof.json 2> $Q/stats.err
+LEGO_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d $Q/stats_serial -- $BN > $Q/bench_serial_under_rocprof.json 2> $Q/stats_serial.err
+f=$(ls $Q/stats/*/*kernel_trace.csv | head -1); python3 tools/timeline.py $f > $Q/timeline.txt
+cp $(ls $Q/stats/*/*kernel_stats.csv | head -1) $Q/kernel_stats.csv
+cp $(ls $Q/stats_serial/*/*kernel_stats.csv | head -1) $Q/kernel_stats_serial.csv
+rm -rf $Q/stats $Q/stats_serial
+$BN > $Q/bench.json 2> $Q/bench.err
+# BERT-base NAML (config 5): kernel statistics of the native blocks
+rocprofv3 --kernel-trace --stats --output-format csv -d $Q/bert -- python3 tools/bert_naml_bench.py --tune_from 0 --steps 3 --warmup 1 > $Q/bert_bench.txt 2>&1
+cp $(ls $Q/bert/*/*kernel_stats.csv | head -1) $Q/bert_kernel_stats.csv; rm -rf $Q/bert
+ls -la gpurun_out/prof_r04 $O $Q; tail -3 gpurun_out/prof_r04.log
