@@ -1193,8 +1193,10 @@ class NrmsEngine(_Base):
         """per-key in-projection (qkv_dedup): dEu [U, D] is the gradient of the ONE live look-up of every distinct key -- added to the row
         of the table that key belongs to (no two keys share a destination row)"""
         D, V = self.D, self.V
-        call("lego_scatter_add_rows", _ptr(g_spec), D, D, 3, _ptr(self.idx_spec_u), self.Uc, self.cnt(6), _ptr(self.dHu), D, st)
-        call("lego_scatter_add_rows", _ptr(g_cat), D, D, n_cat, _ptr(self.idx_cat_u), self.Uc, self.cnt(6), _ptr(self.dHu), D, st)
+        # (the `_range` entry point = the plain one-atomic-per-element kernel: no two keys share a destination row, so the LDS
+        # pre-reduction of the small-table path -- made for thousands of rows hitting 3 / 18 rows -- would only add its latency: 2 x 18 us)
+        call("lego_scatter_add_rows_range", _ptr(g_spec), D, D, _ptr(self.idx_spec_u), self.Uc, self.cnt(6), _ptr(self.dHu), D, 0, 3, st)
+        call("lego_scatter_add_rows_range", _ptr(g_cat), D, D, _ptr(self.idx_cat_u), self.Uc, self.cnt(6), _ptr(self.dHu), D, 0, n_cat, st)
         if self.touched_rows is not None:
             call("lego_mark_rows", _ptr(self.idx_tok_u), self.Uc, self.cnt(6), V, _ptr(self.touched_rows), st)
         if self.grad_hooks is None:
