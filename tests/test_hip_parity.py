@@ -1200,10 +1200,13 @@ def test_nrms_projection_once_per_distinct_token(planned, glove, monkeypatch):
         batches.append([torch.tensor(np.ascontiguousarray(a)).int().to(dev).contiguous() for a in
                         (rs.randint(0, w["n_items"], size=(B, C)), w["user_hist"][users], np.maximum(w["user_hist_len"][users], 1))])
     out = {}
-    for dedup in ("0", "1"):
+    # forms: row by row / per distinct token (projection, table gradient) / -- trainable table only -- the in-projection per distinct KEY
+    forms = [("0", "0"), ("1", "0")] + ([] if glove else [("1", "1")])
+    for dedup, per_key in forms:
         monkeypatch.setenv("LEGO_NRMS_DEDUP", dedup)
+        monkeypatch.setenv("LEGO_NRMS_QKV_DEDUP", per_key)
         eng = E.NrmsEngine(Pd, tb, B, C, S, heads=8, glove=glove, seed=77)
-        assert eng.dedup == (dedup == "1")
+        assert eng.dedup == (dedup == "1") and eng.qkv_dedup == (per_key == "1")
         G = eng.grads_like()
         if planned:
             eng.enable_plan_slots()
@@ -1217,15 +1220,17 @@ def test_nrms_projection_once_per_distinct_token(planned, glove, monkeypatch):
             eng.backward(G)
             res.append((scores.clone(), float(loss)))
         torch.cuda.synchronize()
-        out[dedup] = (res, {k: v.clone() for k, v in G.items()})
-    (r0, g0), (r1, g1) = out["0"], out["1"]
-    for (s0, l0), (s1, l1) in zip(r0, r1):
-        _close(s1.cpu(), s0.cpu(), rtol=2e-5, what="scores")
-        assert abs(l0 - l1) < 2e-6
+        out[(dedup, per_key)] = (res, {k: v.clone() for k, v in G.items()})
+    r0, g0 = out[forms[0]]
     gmax = max(float(v.abs().max()) for v in g0.values())
-    for k in g0:
-        d = float((g1[k] - g0[k]).abs().max())
-        assert d <= 2e-5 * gmax + 2e-5 * float(g0[k].abs().max()), (k, d, gmax)
+    for form in forms[1:]:
+        r1, g1 = out[form]
+        for (s0, l0), (s1, l1) in zip(r0, r1):
+            _close(s1.cpu(), s0.cpu(), rtol=2e-5, what=f"scores {form}")
+            assert abs(l0 - l1) < 2e-6
+        for k in g0:
+            d = float((g1[k] - g0[k]).abs().max())
+            assert d <= 2e-5 * gmax + 2e-5 * float(g0[k].abs().max()), (form, k, d, gmax)
     assert float(g0["embedding_vocab_table.glove.linear.weight" if glove else "embedding_vocab_table.glove.weight"].abs().max()) > 0
 
 
