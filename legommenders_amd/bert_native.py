@@ -180,9 +180,7 @@ class _Blocks(torch.autograd.Function):
         saved = {}
         if embed:
             pos_w, type_w, g0, b0 = params[:4]
-            lens = (seg_off[1:] - seg_off[:-1]).long()
-            row_seg = torch.repeat_interleave(torch.arange(n, device=dev), lens)
-            pos = torch.arange(R, device=dev) - seg_off[:-1].long()[row_seg]
+            pos = idx.long() % L                      # BertEmbeddings.position_ids: the row's place in its padded sequence (any mask)
             resid0 = (pos_w.detach()[pos] + type_w.detach()[0]).contiguous()       # position + token-type rows (token_type_ids = 0)
             h = torch.empty(R, H, **f)
             mean0, rstd0 = torch.empty(R, **f), torch.empty(R, **f)
@@ -325,7 +323,6 @@ class _Blocks(torch.autograd.Function):
             dh = d_xc
         if need[0]:
             dx_dense.index_copy_(0, ctx.idx.long(), dh)
-        ctx.layers = None
         return (dx_dense.view(n, L, H) if need[0] else None,) + (None,) * (n_fixed - 1) + tuple(grads)
 
 

@@ -422,3 +422,56 @@ def test_native_blocks_equal_the_transformers_route(tune, tmp_path, monkeypatch)
     for k, g in res[False][1].items():
         d = float((res[True][1][k] - g).abs().max())
         assert d <= 2e-3 * float(g.abs().max()) + 2e-6 * gscale, (k, d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("embed", [True, False])
+def test_native_blocks_with_holes_in_the_mask(embed):
+    """`transformers.BertModel(inputs_embeds, attention_mask)` on a mask that is NOT a live prefix (dead positions in the middle of a
+    sequence, one empty sequence): position embeddings follow the padded place of a row, dead keys are never attended, and every
+    live position's hidden state / every gradient equals the module tree's (dropout off; float64 module tree on the CPU)"""
+    import transformers
+    from legommenders_amd import bert_native
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    cfg = transformers.BertConfig(vocab_size=50, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                                  max_position_embeddings=32, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    ref = transformers.BertModel(cfg, add_pooling_layer=False).double().eval()
+    mine = transformers.BertModel(cfg, add_pooling_layer=False)
+    mine.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    mine = mine.to(dev).eval()
+    n, L, H = 6, 12, 64
+    mask = (torch.rand(n, L) < 0.7).long()
+    mask[2] = 0                                                      # an empty sequence
+    mask[0, 0], mask[0, 1], mask[0, 2] = 1, 0, 1                     # a hole right behind the first token
+    x = torch.randn(n, L, H, dtype=torch.float64)
+    w = torch.randn(n, L, H, dtype=torch.float64) * mask[..., None]  # the loss reads live positions only
+    live = mask.bool()
+    live_rows = mask.sum(1) > 0                                      # (an all-dead sequence is softmax over nothing in the module tree)
+    xr = x.clone().requires_grad_(True)
+    if embed:
+        hr = ref(inputs_embeds=xr[live_rows], attention_mask=mask[live_rows]).last_hidden_state
+    else:
+        ext = (1.0 - mask[live_rows][:, None, None, :].double()) * torch.finfo(torch.float64).min
+        hr = ref.encoder(hidden_states=xr[live_rows], attention_mask=ext).last_hidden_state
+    (hr * w[live_rows]).sum().backward()
+    xm = x.float().to(dev).requires_grad_(True)
+    assert bert_native.supported(mine, L) is None
+    hm = bert_native.encoder_forward(mine, xm, mask.to(dev), embed)
+    (hm * w.float().to(dev)).sum().backward()
+    got = hm.detach().cpu().double()
+    assert float(got[~live].abs().max()) == 0.0
+    assert float((got[live_rows][mask[live_rows].bool()] - hr.detach()[mask[live_rows].bool()]).abs().max()) < 2e-5
+    gx = xm.grad.cpu().double()
+    scale = float(xr.grad.abs().max())
+    assert float((gx[live_rows] - xr.grad[live_rows]).abs().max()) < 2e-5 * max(1.0, scale)
+    pm = dict(mine.named_parameters())
+    for k, p in ref.named_parameters():
+        if p.grad is None or float(p.grad.abs().max()) == 0.0:
+            continue
+        if not embed and k.startswith("embeddings."):
+            continue
+        g = pm[k].grad
+        assert g is not None, k
+        d = float((g.cpu().double() - p.grad).abs().max())
+        assert d <= 2e-5 * max(1.0, float(p.grad.abs().max())), (k, d)

@@ -32,13 +32,21 @@ def bwd(*a, **k):
     return r
 
 
-for _ in range(50):
+import time
+for _ in range(300):
     ts.step()
 torch.cuda.synchronize()
-eng.forward, eng.backward = fwd, bwd
+t0 = time.perf_counter()
 for _ in range(200):
     ts.step()
 torch.cuda.synchronize()
+print(kind, "plain: %.1f us per step" % ((time.perf_counter() - t0) / 200 * 1e6))
+eng.forward, eng.backward = fwd, bwd
+t0 = time.perf_counter()
+for _ in range(200):
+    ts.step()
+torch.cuda.synchronize()
+print(kind, "with 4 events per step: %.1f us per step" % ((time.perf_counter() - t0) / 200 * 1e6))
 n = len(ev["f0"])
 m = lambda x, y: sum(a.elapsed_time(b) for a, b in zip(ev[x][20:], ev[y][20:])) / (n - 20) * 1e3
 print(kind, "forward %.1f us, forward end -> backward start %.1f us, backward %.1f us, backward end -> next forward start %.1f us" %
