@@ -13,7 +13,8 @@
  *   - "dyn" arguments are device int32 scalars read by the kernels (ragged row counts produced
  *     by lego_plan_batch), so the host never synchronises on a batch's raggedness
  *   - return value 0 = ok; non-zero = error, message via lego_last_error() (thread-local)
- *   - thread-safety: no global mutable state besides the thread-local error string
+ *   - thread-safety: no global mutable state besides the thread-local error string and the process-wide
+ *     product mode (lego_set_product_mode; set it before launching, not concurrently with launches)
  *
  * Row spaces of one batch (built by lego_plan_batch / lego_plan_dense)
  *   token rows  r in [0,R)      one per live title token; rows of one item instance are contiguous
@@ -28,11 +29,22 @@
 extern "C" {
 #endif
 
-#define LEGO_ABI_VERSION 5
+#define LEGO_ABI_VERSION 6
 #define LEGO_COUNTERS 8
 
 const char* lego_last_error(void);
 int lego_abi_version(void);
+
+/* Product mode of the LARGE dense products (lego_linear_*, lego_conv3_fwd / _bwd_data / _bwd_weight with >= 2048 rows).
+ *   0 (default)  exact f32 on the fp32 matrix instructions: the mode every parity statement of this library is made in
+ *                (the reference computes in torch fp32: model/operators/, model/common/attention.py)
+ *   1            split-bf16: every operand element x = hi + lo (two bf16), a.b = lo_a hi_b + hi_a lo_b + hi_a hi_b on the bf16
+ *                matrix instructions with fp32 accumulation.  OPT-IN throughput mode (about 2x the f32 rate), relative error
+ *                ~4e-6 of the largest output per product: NOT bit-compatible with the exact mode; the Winograd conv entry points
+ *                do not take part (use the direct lego_conv3_* ones).  LEGO_SPLIT_BF16=1 in the environment selects it at load.
+ * lego_set_product_mode returns 0 / an error for an unknown mode; lego_get_product_mode returns the mode. */
+int lego_set_product_mode(int mode);
+int lego_get_product_mode(void);
 
 typedef struct {
     float p;             /* drop probability, 0 = off (eval) */

@@ -22,7 +22,7 @@ U64 = ctypes.c_uint64
 U32 = ctypes.c_uint32
 
 
-ABI_VERSION = 5      # == LEGO_ABI_VERSION of include/lego_hip.h this binding was written against
+ABI_VERSION = 6      # == LEGO_ABI_VERSION of include/lego_hip.h this binding was written against
 
 
 class LegoDropout(ctypes.Structure):
@@ -77,6 +77,7 @@ SIGNATURES = {
     "lego_rowdot_bwd": [P, I, P, I, P, I, I, P, I, P, I, P],
     "lego_relu_bwd": [P, I, P, I, I, I, F, P],
     "lego_adam_step": [P, P, P, P, I64, F, F, F, F, I, F, I, P],
+    "lego_set_product_mode": [I],
     "lego_adam_step_rows": [P, P, P, P, I, I, P, F, F, F, F, I, F, I, P],
     "lego_mark_rows": [P, I, P, I, P, P],
     "lego_sample_negatives": [P, P, P, P, I, I, I, I, U64, U32, U32, U32, P, P, P],
@@ -92,7 +93,7 @@ SIGNATURES = {
 
 
 # entry points that return a VALUE instead of a status (bound separately; tests/test_abi.py checks them against the header too)
-VALUE_FUNCS = {"lego_conv3_wino_du_slabs": [I, I, I]}
+VALUE_FUNCS = {"lego_conv3_wino_du_slabs": [I, I, I], "lego_get_product_mode": []}
 VALUE_FUNCS_I64 = {"lego_sort_rows_temp_bytes": [I]}
 
 
@@ -159,6 +160,20 @@ def lib() -> ctypes.CDLL:
         fn.argtypes = argtypes
     _lib = handle
     return handle
+
+
+EXACT_F32, SPLIT_BF16 = 0, 1
+
+
+def set_product_mode(mode: int) -> None:
+    """process-wide product mode of the large dense products (include/lego_hip.h): EXACT_F32 (default, the parity mode) or
+    SPLIT_BF16 (opt-in, ~2x the rate, relative error ~4e-6 per product).  Engines read it when they are BUILT (the NAML engine
+    takes the direct conv instead of the Winograd one in split mode), so set it before constructing a TrainStep / Evaluator."""
+    call("lego_set_product_mode", int(mode))
+
+
+def product_mode() -> int:
+    return int(lib().lego_get_product_mode())
 
 
 def call(name: str, *args) -> None:

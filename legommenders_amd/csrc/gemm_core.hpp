@@ -112,6 +112,58 @@ struct McShiftRows {       // row kk + (tap-1) of p, valid when the plan says ro
 template <class L, class = void> struct IsDual : std::false_type {};
 template <class L> struct IsDual<L, std::void_t<decltype(L::kDual)>> : std::bool_constant<L::kDual> {};
 
+
+// ------------------------------------------------------------------ split-bf16 operands (opt-in product mode, never the default)
+// x = hi + lo + O(2^-18 |x|) with hi = bf16(x), lo = bf16(x - hi); a product a.b is taken as lo_a hi_b + hi_a lo_b + hi_a hi_b on
+// v_mfma_f32_32x32x16_bf16 (fp32 accumulate): three matrix instructions of 32 cycles per 16 k against eight of 64 for exact f32,
+// relative error ~2^-17 per term.  Loaders, tile configurations and epilogues are shared with the exact kernel; what changes is the
+// LDS image: BOTH operand kinds are held row-major [row][BK + 4 slots] with the 16-byte chunk of 4 consecutive k of a row packed as
+// [h0 h1][l0 l1][h2 h3][l2 l3], so the two ds_read_b128 of a lane for a 16-k step ARE its hi / lo operand registers (no unpacking,
+// no per-element reads).  A K-contiguous operand packs the f32x4 it loaded; an M-contiguous one (reduction index = memory row) loads
+// CONSECUTIVE k rows per thread (kN x 4 block), transposes it in registers and writes one chunk (or half chunk) per matrix row.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned split_pk(float a, float b) {
+    bf16x2_t t = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, t);
+}
+__device__ __forceinline__ u32x2 split_pair(float a, float b) {          // [ha hb][la lb]
+    const unsigned h = split_pk(a, b);
+    return u32x2{h, split_pk(a - __builtin_bit_cast(float, h << 16), b - __builtin_bit_cast(float, h & 0xffff0000u))};
+}
+__device__ __forceinline__ f32x4 split_pack_kc(f32x4 v) {
+    const u32x2 p0 = split_pair(v[0], v[1]), p1 = split_pair(v[2], v[3]);
+    const u32x4 w = {p0[0], p0[1], p1[0], p1[1]};
+    return __builtin_bit_cast(f32x4, w);
+}
+
+// commit of an M-contiguous operand in split mode: thread (rg = tid % PER, kq = tid / PER) holds k rows kN * kq + j (j < kN) of the
+// four matrix rows 4 rg + i; row i's kN values become kN / 4 packed chunks (kN = 2: half a chunk) of the row-major image
+template <int KN, int PER>
+__device__ __forceinline__ void split_commit_mc(float* T_, const f32x4 (&sv)[KN], const bool (&pv)[KN], int tid) {
+    // the lanes of a write share kq and step through rg: rows 16 apart would land on the same banks (row stride 36 slots), so the
+    // chunk index is XORed with bits 4-6 of the row -- uniform over the 16-lane groups of the fragment reads, which undo it
+    const int rg = tid % PER, kq = tid / PER;
+    const int g = (rg >> 2) & 7;                     // = ((4 rg + i) >> 4) & 7
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float* row = T_ + (4 * rg + i) * KC_LD;
+        if constexpr (KN == 2) {
+            *reinterpret_cast<u32x2*>(row + 4 * ((kq >> 1) ^ g) + 2 * (kq & 1)) = split_pair(pv[0] ? sv[0][i] : 0.f, pv[1] ? sv[1][i] : 0.f);
+        } else {
+#pragma unroll
+            for (int c = 0; c < KN / 4; ++c) {
+                const f32x4 v = {pv[4 * c] ? sv[4 * c][i] : 0.f, pv[4 * c + 1] ? sv[4 * c + 1][i] : 0.f,
+                                 pv[4 * c + 2] ? sv[4 * c + 2][i] : 0.f, pv[4 * c + 3] ? sv[4 * c + 3][i] : 0.f};
+                *reinterpret_cast<f32x4*>(row + 4 * ((kq * (KN / 4) + c) ^ g)) = split_pack_kc(v);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ the kernel
 template <int BM, int BN, int WM, int WN, bool STAGGER = false>
 struct TileCfg {
@@ -137,11 +189,13 @@ struct GemmDims {
     int split_k;            // TN only: gridDim.z / taps
 };
 
-template <class Cfg, bool A_MC, bool B_MC, class ALoad, class BLoad, class Epi>
+template <class Cfg, bool A_MC, bool B_MC, class ALoad, class BLoad, class Epi, bool SPLIT = false>
 __global__ __launch_bounds__(Cfg::kThreads) void gemm_kernel(GemmDims dims, ALoad la, BLoad lb, Epi epi) {
     constexpr int BM = Cfg::kBM, BN = Cfg::kBN, TM = Cfg::kTM, TN = Cfg::kTN, NT = Cfg::kThreads, RS = NT / 8;
-    using SA = Stage<A_MC, BM, NT>;
-    using SB = Stage<B_MC, BN, NT>;
+    using SA = Stage<A_MC && !SPLIT, BM, NT>;        // split mode: every image is row-major (see above)
+    using SB = Stage<B_MC && !SPLIT, BN, NT>;
+    static_assert(!SPLIT || !((A_MC && IsDual<ALoad>::value) || (B_MC && IsDual<BLoad>::value)), "no split form of the pair loaders");
+    static_assert(!SPLIT || ((!A_MC || SA::kN % 2 == 0) && (!B_MC || SB::kN % 2 == 0)), "split mode: an M-contiguous operand needs >= 2 k rows per thread");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const As0 = smem;
     float* const Bs0 = smem + 2 * SA::kLdsFloats;
@@ -199,7 +253,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_kernel(GemmDims dims, ALoa
 #pragma unroll
             for (int j = 0; j < SA::kN; ++j) {
                 if constexpr (A2) la.load2(k0 + tid / PER + STEP * j, m0 + (tid % PER) * 4, sa[j], pa[j], sa2[j], pa2[j]);
-                else sa[j] = la.load(k0 + tid / PER + STEP * j, m0 + (tid % PER) * 4, pa[j]);
+                else sa[j] = la.load(SPLIT ? k0 + (tid / PER) * SA::kN + j : k0 + tid / PER + STEP * j, m0 + (tid % PER) * 4, pa[j]);
             }
         } else {
 #pragma unroll
@@ -210,7 +264,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_kernel(GemmDims dims, ALoa
 #pragma unroll
             for (int j = 0; j < SB::kN; ++j) {
                 if constexpr (B2) lb.load2(k0 + tid / PER + STEP * j, n0 + (tid % PER) * 4, sb[j], pb[j], sb2[j], pb2[j]);
-                else sb[j] = lb.load(k0 + tid / PER + STEP * j, n0 + (tid % PER) * 4, pb[j]);
+                else sb[j] = lb.load(SPLIT ? k0 + (tid / PER) * SB::kN + j : k0 + tid / PER + STEP * j, n0 + (tid % PER) * 4, pb[j]);
             }
         } else {
 #pragma unroll
@@ -218,7 +272,9 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_kernel(GemmDims dims, ALoa
         }
     };
     auto commit = [&](float* A_, float* B_) {
-        if constexpr (A_MC) {
+        if constexpr (A_MC && SPLIT) {
+            split_commit_mc<SA::kN, BM / 4>(A_, sa, pa, tid);
+        } else if constexpr (A_MC) {
             constexpr int PER = BM / 4, STEP = NT / PER;
 #pragma unroll
             for (int j = 0; j < SA::kN; ++j) {
@@ -228,10 +284,15 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_kernel(GemmDims dims, ALoa
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < SA::kN; ++j)
-                *reinterpret_cast<f32x4*>(A_ + ((tid >> 3) + RS * j) * KC_LD + (tid & 7) * 4) = zero_unless(pa[j], sa[j]);
+            for (int j = 0; j < SA::kN; ++j) {
+                f32x4 v = zero_unless(pa[j], sa[j]);
+                if constexpr (SPLIT) v = split_pack_kc(v);
+                *reinterpret_cast<f32x4*>(A_ + ((tid >> 3) + RS * j) * KC_LD + (tid & 7) * 4) = v;
+            }
         }
-        if constexpr (B_MC) {
+        if constexpr (B_MC && SPLIT) {
+            split_commit_mc<SB::kN, BN / 4>(B_, sb, pb, tid);
+        } else if constexpr (B_MC) {
             constexpr int PER = BN / 4, STEP = NT / PER;
 #pragma unroll
             for (int j = 0; j < SB::kN; ++j) {
@@ -241,8 +302,11 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_kernel(GemmDims dims, ALoa
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < SB::kN; ++j)
-                *reinterpret_cast<f32x4*>(B_ + ((tid >> 3) + RS * j) * KC_LD + (tid & 7) * 4) = zero_unless(pb[j], sb[j]);
+            for (int j = 0; j < SB::kN; ++j) {
+                f32x4 v = zero_unless(pb[j], sb[j]);
+                if constexpr (SPLIT) v = split_pack_kc(v);
+                *reinterpret_cast<f32x4*>(B_ + ((tid >> 3) + RS * j) * KC_LD + (tid & 7) * 4) = v;
+            }
         }
     };
 
@@ -268,6 +332,31 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_kernel(GemmDims dims, ALoa
         if (more && early) commit(As0 + (buf ^ 1) * SA::kLdsFloats, Bs0 + (buf ^ 1) * SB::kLdsFloats);
         const float* A_ = As0 + buf * SA::kLdsFloats;
         const float* B_ = Bs0 + buf * SB::kLdsFloats;
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int s2 = 0; s2 < BK / 16; ++s2) {
+                u32x4 ah[TM], al[TM], bh[TN], bl[TN];
+                auto frag = [&](const float* T_, int idx, bool swz, u32x4& hi, u32x4& lo) {
+                    const int g = swz ? (idx >> 4) & 7 : 0;         // split_commit_mc's chunk swizzle
+                    const u32x4 c0 = *reinterpret_cast<const u32x4*>(T_ + idx * KC_LD + 4 * ((4 * s2 + lh) ^ g));
+                    const u32x4 c1 = *reinterpret_cast<const u32x4*>(T_ + idx * KC_LD + 4 * ((4 * s2 + 2 + lh) ^ g));
+                    hi = u32x4{c0[0], c0[2], c1[0], c1[2]};
+                    lo = u32x4{c0[1], c0[3], c1[1], c1[3]};
+                };
+#pragma unroll
+                for (int a = 0; a < TM; ++a) frag(A_, (wm * TM + a) * 32 + li, A_MC, ah[a], al[a]);
+#pragma unroll
+                for (int b = 0; b < TN; ++b) frag(B_, (wn * TN + b) * 32 + li, B_MC, bh[b], bl[b]);
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[a]), __builtin_bit_cast(bf16x8, bh[b]), acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[a]), __builtin_bit_cast(bf16x8, bl[b]), acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[a]), __builtin_bit_cast(bf16x8, bh[b]), acc[a][b], 0, 0, 0);
+                    }
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {
             f32x4 fa[TM], fb[TN];
@@ -299,6 +388,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_kernel(GemmDims dims, ALoa
                     for (int b = 0; b < TN; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
         }
+        }
         if (more && !early) commit(As0 + (buf ^ 1) * SA::kLdsFloats, Bs0 + (buf ^ 1) * SB::kLdsFloats);
         __syncthreads();
         buf ^= 1;
@@ -308,9 +398,9 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_kernel(GemmDims dims, ALoa
     epi.template run<TM, TN>(acc, m0 + wm * TM * 32, n0 + wn * TN * 32, li, lh);
 }
 
-template <class Cfg, bool A_MC, bool B_MC>
+template <class Cfg, bool A_MC, bool B_MC, bool SPLIT = false>
 constexpr size_t gemm_lds_bytes() {
-    return 2 * (Stage<A_MC, Cfg::kBM, Cfg::kThreads>::kLdsFloats + Stage<B_MC, Cfg::kBN, Cfg::kThreads>::kLdsFloats) * sizeof(float);
+    return 2 * (Stage<A_MC && !SPLIT, Cfg::kBM, Cfg::kThreads>::kLdsFloats + Stage<B_MC && !SPLIT, Cfg::kBN, Cfg::kThreads>::kLdsFloats) * sizeof(float);
 }
 
 }  // namespace lego

@@ -280,13 +280,13 @@ static void set_drop(Epi& e, const lego_dropout* d, int cols) {
     }
 }
 
-template <class Cfg, bool A_MC, bool B_MC, class EK, class AL, class BL>
+template <class Cfg, bool A_MC, bool B_MC, class EK, bool SPLIT = false, class AL, class BL>
 static int launch(const GemmDims& d, const AL& a, const BL& b, const Epi& e0, int tiles_m, int tiles_n, int gz,
                   hipStream_t st, const char* what) {
     EK e;
     static_cast<EpiArgs&>(e) = e0;
-    auto k = gemm_kernel<Cfg, A_MC, B_MC, AL, BL, EK>;
-    constexpr size_t lds = gemm_lds_bytes<Cfg, A_MC, B_MC>();
+    auto k = gemm_kernel<Cfg, A_MC, B_MC, AL, BL, EK, SPLIT>;
+    constexpr size_t lds = gemm_lds_bytes<Cfg, A_MC, B_MC, SPLIT>();
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -406,9 +406,30 @@ static int launch_light(const GemmDims& d, const AL& a, const BL& b, const Epi& 
     return check_launch(what);
 }
 
+// ---- product mode.  0 (default): exact f32 on v_mfma_f32_32x32x2 / 16x16x4 -- the path's parity contract.  1: split-bf16 (bf16 x 3,
+// fp32 accumulate; gemm_core.hpp) for the large products -- an OPT-IN throughput mode that is not bit-compatible with the reference
+// (relative error ~1e-5 per product); lego_set_product_mode() or LEGO_SPLIT_BF16=1 at load.  Small latency-bound products (user side,
+// fold levels) stay exact in both modes.
+static int g_product_mode = -1;
+static int product_mode() {
+    if (g_product_mode < 0) { const char* e = getenv("LEGO_SPLIT_BF16"); g_product_mode = (e != nullptr && e[0] == '1') ? 1 : 0; }
+    return g_product_mode;
+}
+constexpr int SPLIT_MIN_ROWS = 2048;            // below this the products are latency-bound: nothing to gain, keep them exact
+
+using C128x128s = TileCfg<128, 128, 4, 2, true>;   // split mode: 8 waves of 32 x 64
+using C128x256s = TileCfg<128, 256, 2, 4>;
+
 template <bool B_MC, class EK, class AL, class BL>
 static int launch_rows(const GemmDims& d, const AL& a, const BL& b, const Epi& e, hipStream_t st, const char* what) {
     const int tm = (d.M + 127) / 128;
+    if (product_mode() == 1 && d.M >= SPLIT_MIN_ROWS) {
+        // tools/gemm_variants.py 20-26 (round 4): 128 x 128 on 4 x 2 staggered waves at the path's widths (214 / 154 TFLOP/s-equivalent
+        // at K = 768 / 256 over 26 k rows, against 95 / 83 exact), 128 x 256 for the BERT widths (253-266 against 113-123)
+        if (d.N >= 512) return launch<C128x256s, false, B_MC, EK, true>(d, a, b, e, tm, (d.N + 255) / 256, 1, st, what);
+        if (d.N > 64) return launch<C128x128s, false, B_MC, EK, true>(d, a, b, e, tm, (d.N + 127) / 128, 1, st, what);
+        return launch<C128x64, false, B_MC, EK, true>(d, a, b, e, tm, (d.N + 63) / 64, 1, st, what);
+    }
     // LEGO_STRIP_MAXK (tuning): reductions at least this long skip the row-strip kernels and take the 128 x 128 tile kernel
     static int strip_maxk = -1;
     if (strip_maxk < 0) { const char* e = getenv("LEGO_STRIP_MAXK"); strip_maxk = e != nullptr ? atoi(e) : (1 << 30); }
@@ -491,6 +512,23 @@ template <class AL, class BL>
 static int launch_tn(int M, int N, int K_cap, const int* k_dyn, const AL& a, const BL& b, const Epi& e, int taps, hipStream_t st,
                      const char* what) {
     const int split = pick_split_small(K_cap, M, N);
+    if (product_mode() == 1 && K_cap >= SPLIT_MIN_ROWS) {
+        if constexpr (!IsDual<AL>::value && !IsDual<BL>::value) {
+            // tools/tn_variants.py 20-22 (round 4).  Outputs of >= 36 tiles of 128 x 128 (the BERT block weights): 128 x 128 on 8 waves,
+            // ~1152 workgroups -- 212-250 TFLOP/s-equivalent over 29.6 k rows against 110-115 exact; the path's 256-wide weights: 64 x 64
+            // tiles (the 128-wide ones leave most CUs without a workgroup), 90-108 against 78
+            const int t128 = ((M + 127) / 128) * ((N + 127) / 128);
+            if (t128 * taps >= 36) {
+                int s128 = 1152 / (t128 * taps);
+                const int max_s = (K_cap + 255) / 256;
+                s128 = s128 < 1 ? 1 : (s128 > max_s ? max_s : s128);
+                GemmDims d{M, N, K_cap, nullptr, k_dyn, s128};
+                return launch<TileCfg<128, 128, 4, 2>, true, true, EpiAtomic, true>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, taps * s128, st, what);
+            }
+            GemmDims d{M, N, K_cap, nullptr, k_dyn, split};
+            return launch<C64x64, true, true, EpiAtomic, true>(d, a, b, e, (M + 63) / 64, (N + 63) / 64, taps * d.split_k, st, what);
+        }
+    }
     if constexpr (!IsDual<AL>::value && !IsDual<BL>::value) {
         // 64 x 64 tiles, loads two k tiles ahead (tn_kernel), four workgroups per CU: 27.7 us per launch against 29.7 for the
         // generic tile kernel (one tile ahead) on the path's shapes
@@ -513,6 +551,12 @@ using namespace lego;
 
 extern "C" const char* lego_last_error(void) { return lego::last_error(); }
 extern "C" int lego_abi_version(void) { return LEGO_ABI_VERSION; }
+extern "C" int lego_set_product_mode(int mode) {
+    LEGO_REQUIRE(mode == 0 || mode == 1, "lego_set_product_mode: mode=%d (0 = exact f32, 1 = split-bf16)", mode);
+    lego::g_product_mode = mode;
+    return 0;
+}
+extern "C" int lego_get_product_mode(void) { return lego::product_mode(); }
 
 #define CHECK4(x) LEGO_REQUIRE(((x) & 3) == 0, "%s: " #x "=%d must be a multiple of 4", __func__, (int)(x))
 
@@ -756,6 +800,13 @@ extern "C" int lego_debug_gemm_nt(int variant, const float* x, const float* W, c
         case 9: return launch_strip<false, EpiPlain>(d, a, b, e, st, "dbg9");
         case 10: return launch_dma_strip<false, EpiPlain>(d, a, b, e, st, "dbg10");
         case 13: return launch_dma_strip<false, EpiPlain, KcRows, 4>(d, a, b, e, st, "dbg13");
+        case 20: return launch<TileCfg<128, 128, 2, 4, true>, false, false, EpiPlain, true>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, 1, st, "dbg20");
+        case 21: return launch<TileCfg<256, 128, 4, 2>, false, false, EpiPlain, true>(d, a, b, e, (M + 255) / 256, (N + 127) / 128, 1, st, "dbg21");
+        case 22: return launch<TileCfg<128, 256, 2, 4>, false, false, EpiPlain, true>(d, a, b, e, (M + 127) / 128, (N + 255) / 256, 1, st, "dbg22");
+        case 23: return launch<TileCfg<128, 128, 2, 2>, false, false, EpiPlain, true>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, 1, st, "dbg23");
+        case 24: return launch<TileCfg<256, 128, 4, 2, true>, false, false, EpiPlain, true>(d, a, b, e, (M + 255) / 256, (N + 127) / 128, 1, st, "dbg24");
+        case 25: return launch<TileCfg<64, 128, 1, 4>, false, false, EpiPlain, true>(d, a, b, e, (M + 63) / 64, (N + 127) / 128, 1, st, "dbg25");
+        case 26: return launch<TileCfg<128, 128, 4, 2, true>, false, false, EpiPlain, true>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, 1, st, "dbg26");
         default: return set_error("lego_debug_gemm_nt: unknown variant %d", variant);
     }
 }
@@ -773,6 +824,9 @@ extern "C" int lego_debug_gemm_tn(int variant, int split, const float* g, const 
         case 2: return launch<TileCfg<128, 64, 4, 1>, true, true, EpiAtomic>(d, a, b, e, (N + 127) / 128, (K + 63) / 64, split, st, "tn2");
         case 3: return launch<TileCfg<64, 128, 1, 4>, true, true, EpiAtomic>(d, a, b, e, (N + 63) / 64, (K + 127) / 128, split, st, "tn3");
         case 4: return launch<TileCfg<128, 128, 2, 2>, true, true, EpiAtomic>(d, a, b, e, (N + 127) / 128, (K + 127) / 128, split, st, "tn4");
+        case 20: return launch<TileCfg<128, 128, 4, 2>, true, true, EpiAtomic, true>(d, a, b, e, (N + 127) / 128, (K + 127) / 128, split, st, "tn20");
+        case 21: return launch<TileCfg<64, 64, 2, 2>, true, true, EpiAtomic, true>(d, a, b, e, (N + 63) / 64, (K + 63) / 64, split, st, "tn21");
+        case 22: return launch<TileCfg<128, 128, 2, 2>, true, true, EpiAtomic, true>(d, a, b, e, (N + 127) / 128, (K + 127) / 128, split, st, "tn22");
         default: return set_error("lego_debug_gemm_tn: unknown variant %d", variant);
     }
 }

@@ -308,7 +308,8 @@ class NamlEngine(_Base):
         self.wt = self._f(3, D, D)
         # Winograd F(2,3) conv over row pairs (csrc/gemm_wino.hpp): two thirds of the direct conv's MFMA work.
         # LEGO_WINO=0 keeps the direct three-tap implicit GEMM (also used when D > 256).
-        self.wino = os.environ.get("LEGO_WINO", "1") != "0" and D <= 256 and self.Rc > 0
+        # (the opt-in split-bf16 product mode covers the direct conv entry points only: _lib.set_product_mode)
+        self.wino = os.environ.get("LEGO_WINO", "1") != "0" and D <= 256 and self.Rc > 0 and _lib.product_mode() == _lib.EXACT_F32
         self.Pc = self.NIc * ((self.T + 1) // 2)
         self.pair_info = torch.zeros(max(self.Pc, 1), **i32)
         self.mask_proj = torch.zeros(((self.Rc + 3) // 4) * D + 1, dtype=torch.uint8, device=self.dev)

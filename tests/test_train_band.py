@@ -51,6 +51,20 @@ BANDS = sorted(os.path.basename(f)[len("train_band_"):-len(".json")] for f in gl
 
 @pytest.mark.parametrize("name", BANDS)
 def test_trained_gauc_matches_the_reference_band(name):
+    _check_band(name)
+
+
+def test_trained_gauc_in_split_bf16_mode():
+    """the opt-in split-bf16 product mode (tests/test_split_bf16.py) trains to the same band: NAML, 16 seeds, same tolerance"""
+    from legommenders_amd import _lib
+    _lib.set_product_mode(_lib.SPLIT_BF16)
+    try:
+        _check_band("naml")
+    finally:
+        _lib.set_product_mode(_lib.EXACT_F32)
+
+
+def _check_band(name):
     from legommenders_amd.synthetic import glove_table_np, make_learnable_world
     dev = torch.device("cuda:0")
     band = json.load(open(os.path.join(HERE, "golden", f"train_band_{name}.json")))
