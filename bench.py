@@ -332,7 +332,9 @@ def main():
 
     ts = make_ts(args.model, data, force=args.force_dist, embed=args.embed)
     in_region = {"naml": {"conv3_fwd", "gather_rows_in_step", "expand_rows_in_step"}, "nrms": {"qkv_fwd_item"}}[args.model]
-    dt, timers, loss = timed_steps(ts, args.steps, args.warmup, barrier, args.time_every, tags=in_region)
+    # every bracketed step costs ~0.08 ms of event / barrier-packet overhead (tools/step_profile.py): short runs bracket two steps
+    every = args.time_every if args.steps > 40 or args.time_every == 0 else max(args.time_every, args.steps // 2)
+    dt, timers, loss = timed_steps(ts, args.steps, args.warmup, barrier, every, tags=in_region)
     host_ms = timed_steps.host_s / args.steps * 1e3
     if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -591,6 +593,31 @@ def main():
                                          f"(768 x 12 blocks x 12 heads, random init), item_page_size 64 in the yaml (raised to one call per batch side: same values, "
                                          f"fuller launches; only the LIVE history slots are encoded), hidden={D} bs={B}, "
                                          f"5 000-item world, full plug-in train step (device sampler ids, fwd, bwd, torch Adam), fp32")
+        # OPT-IN product mode (include/lego_hip.h: lego_set_product_mode; never the headline): split-bf16 operands (bf16 x 3, fp32
+        # accumulate) for the large dense products.  Same workloads, same seeds, engines rebuilt in that mode (NAML takes the direct
+        # conv: the Winograd kernels have no split form); logits within ~1e-6 of the oracle, gradients 2e-3 (tests/test_split_bf16.py)
+        from legommenders_amd import _lib as _L
+        _L.set_product_mode(_L.SPLIT_BF16)
+        try:
+            ssec = {"dtype": "split-bf16 (every operand = hi + lo bf16, three bf16 MFMA terms, fp32 accumulate): NOT the parity mode",
+                    "how": "lego_set_product_mode(1) / LEGO_SPLIT_BF16=1; products of >= 2048 rows only, everything else exact f32"}
+            for kind, emb in (("naml", "glove"), ("nrms", "glove"), ("nrms", "null")):
+                tsx = make_ts(kind, data, embed=emb)
+                dx, _, lx = timed_steps(tsx, 100, 20, barrier)
+                ssec[f"{kind}_{emb}_hidden{D}_bs{B}"] = {"steps": 100, "warmup": 20, "ms_per_step": round(dx / 100 * 1e3, 4),
+                                                      "value": round(B * 100 / dx, 1), "unit": "impressions/s", "final_loss": round(float(lx), 5)}
+                del tsx
+                torch.cuda.empty_cache()
+            if not args.no_bert:
+                r = bert_naml_bench.run(batch=B, steps=3, warmup=1, layers=12, hidden=D, tune_from=0)
+                ssec["bert_naml_base_tune_from_0"] = {"steps": 3, "warmup": 1, "ms_per_step": round(r["s_per_step"] * 1e3, 2), "value": r["impressions_per_s"],
+                                                      "unit": "impressions/s", "final_loss": round(r["loss"], 4),
+                                                      "kernels_tflops_equivalent": {k: v["tflops"] for k, v in r["kernels"].items()}}
+                Env.set_lm_cache(False)
+                torch.cuda.empty_cache()
+            sec["split_bf16_opt_in"] = ssec
+        finally:
+            _L.set_product_mode(_L.EXACT_F32)
         extra["secondary"] = sec
 
     if world_size == 1 and not dist_on and not args.no_dist_check and not args.small:
@@ -599,13 +626,15 @@ def main():
         if dist_on:
             torch.distributed.destroy_process_group()
         return
+    from legommenders_amd import _lib as _L0
+    _lib_mode = _L0.product_mode()                 # 0 unless the whole run was started with LEGO_SPLIT_BF16=1
     out = {
         "metric": "train impressions/sec on MIND-small NAML" if args.model == "naml" else "train impressions/sec on MIND-small NRMS",
         "value": round(B * world_size * args.steps / dt, 1), "unit": "impressions/s",
         "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "host_enqueue_ms_per_step": round(host_ms, 4),
         "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32" if _lib_mode == 0 else "split-bf16 (LEGO_SPLIT_BF16=1: opt-in product mode, NOT the parity mode)", "data": "synthetic",
         "config": {"workload": f"MIND-small-shaped {args.model.upper()} hidden={D} bs={B}/GPU GloVe(300d frozen) "
                                f"K=4 negatives S=50 T=30, full train step (sample+fwd+bwd+allreduce+Adam), dropout 0.1"
                                + (" [SMALL WORLD - not the metric config]" if args.small else ""),
