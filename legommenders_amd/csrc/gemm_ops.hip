@@ -1,6 +1,7 @@
 // GEMM-shaped entry points of liblego_hip.so: every dense product of the NAML / NRMS forward and
 // backward pass runs on the fp32 MFMA core in gemm_core.hpp (exact f32; the path's parity bar is
-// 1e-3 on fp32 logits, so no reduced-precision inputs are used).
+// 1e-3 on fp32 logits, so no reduced-precision inputs are used) -- unless the caller opts into the
+// split-bf16 product mode (lego_set_product_mode below; never the default).
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>

@@ -29,14 +29,43 @@ SITE_PROJ, SITE_CONV, SITE_ITEM_ATT, SITE_USER_ATT = 0, 1, 2, 3
 RI_LIVE_BIT = 4        # csrc/common.hpp RI_LIVE
 
 
+# Host side of a launch.  A training step is ~40 launches with ~190 pointer arguments; on a slow host core the enqueue time of the
+# Python loop (0.45-0.76 ms per step across the pool's boxes, tools/cpu_bound.py) brushes the 0.63 ms the device needs, so the
+# per-argument and per-launch Python work is kept minimal: pointers travel as plain ints (ctypes converts them against the
+# binding's argtypes), the current stream is looked up through the raw (id, device, type) triple with ONE Stream object per
+# triple (current_stream() builds a new object per call: 9 us), and its handle is read once per object.
 def _ptr(t: Optional[torch.Tensor], off: int = 0):
     if t is None:
         return None
-    return ctypes.c_void_p(t.data_ptr() + off * t.element_size())
+    return t.data_ptr() + off * t.element_size() if off else t.data_ptr()
+
+
+_CUR_STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}
+
+
+def current_stream(index: Optional[int] = None) -> "torch.cuda.Stream":
+    """current_stream(), one cached Stream object per raw stream"""
+    raw = torch._C._cuda_getCurrentStream(torch.cuda.current_device() if index is None else index)
+    s = _CUR_STREAMS.get(raw)
+    if s is None:
+        s = _CUR_STREAMS[raw] = torch.cuda.Stream(stream_id=raw[0], device_index=raw[1], device_type=raw[2])
+    return s
+
+
+def stream_handle(stream) -> int:
+    """hipStream_t of a torch stream as an int (read once per Stream object)"""
+    h = getattr(stream, "_lego_handle", None)
+    if h is None:
+        h = int(stream.cuda_stream)
+        try:
+            stream._lego_handle = h
+        except AttributeError:
+            pass
+    return h
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return stream_handle(current_stream())
 
 
 def _check(t: torch.Tensor, dtype, name: str):
@@ -78,6 +107,9 @@ class _Base:
     def __init__(self, params: Dict[str, torch.Tensor], tables: ItemTables, B: int, C: int, S: int,
                  seed: int = 2023):
         self.P = params
+        # switches read once per engine (an os.environ look-up per launch site and step is host time the step does not have)
+        self._serial = os.environ.get("LEGO_SERIAL") == "1"      # profiling aid (tools/prof_*.sh): every launch of a step on ONE stream
+        self._one_wait = os.environ.get("LEGO_ONE_WAIT", "0") == "1"
         self.tb = tables
         self.B, self.C, self.S, self.T = B, C, S, tables.T
         self.dev = tables.title_tok.device
@@ -128,7 +160,7 @@ class _Base:
         tok, tlen, width = self._plan_tables()
         call("lego_plan_batch", _ptr(cand), _ptr(hist), _ptr(hist_len), nb or self.B, self.C, self.S, _ptr(tok), _ptr(tlen), width,
              _ptr(b["counters"]), _ptr(b["inst_item"]), _ptr(b["seg_off"]), _ptr(b["hist_off"]), _ptr(b["rowinfo"]),
-             _ptr(b["row_tok"]), ctypes.c_void_p(stream.cuda_stream))
+             _ptr(b["row_tok"]), stream_handle(stream))
 
     def _plan_tables(self):
         return self.tb.title_tok, self.tb.title_len, self.T
@@ -150,7 +182,7 @@ class _Base:
 
     @staticmethod
     def _sp(stream):
-        return ctypes.c_void_p(stream.cuda_stream)
+        return stream_handle(stream)
 
     def kk(self, stream, tag, name, *args):
         """launch on `stream`; with timers on, bracket the launch with HIP events on that same stream"""
@@ -308,8 +340,13 @@ class NamlEngine(_Base):
         self.wt = self._f(3, D, D)
         # Winograd F(2,3) conv over row pairs (csrc/gemm_wino.hpp): two thirds of the direct conv's MFMA work.
         # LEGO_WINO=0 keeps the direct three-tap implicit GEMM (also used when D > 256).
-        # (the opt-in split-bf16 product mode covers the direct conv entry points only: _lib.set_product_mode)
-        self.wino = os.environ.get("LEGO_WINO", "1") != "0" and D <= 256 and self.Rc > 0 and _lib.product_mode() == _lib.EXACT_F32
+        # The opt-in split-bf16 product mode (_lib.set_product_mode) covers the direct conv entry points only: there the forward and the
+        # data gradient take the direct split form (54 / 74 us against Winograd's 92 / 92) while the WEIGHT gradient stays on the exact
+        # Winograd kernel (`wino_dw`: 82 us alone against 95 for three split TN taps; it needs the pair plan, nothing of the forward's form)
+        self.wino_dw = os.environ.get("LEGO_WINO", "1") != "0" and D <= 256 and self.Rc > 0
+        self.wino = self.wino_dw and _lib.product_mode() == _lib.EXACT_F32
+        if os.environ.get("LEGO_SPLIT_WINO_DW", "1") == "0":
+            self.wino_dw = self.wino
         self.Pc = self.NIc * ((self.T + 1) // 2)
         self.pair_info = torch.zeros(max(self.Pc, 1), **i32)
         self.mask_proj = torch.zeros(((self.Rc + 3) // 4) * D + 1, dtype=torch.uint8, device=self.dev)
@@ -317,7 +354,7 @@ class NamlEngine(_Base):
         self._slot_mask_step, self._mask_step = {}, -1
         self.wino_u = self._f(4, D, D)
         self.wino_ut = self._f(4, D, D)                   # the same sets transposed (data gradient)
-        self.wino_slabs = _lib.lib().lego_conv3_wino_du_slabs(D, D, max(self.Pc, 1)) if self.wino else 1
+        self.wino_slabs = _lib.lib().lego_conv3_wino_du_slabs(D, D, max(self.Pc, 1)) if self.wino_dw else 1
         self.wino_du = self._f(self.wino_slabs, 4, D, D)     # one partial result per k split of the weight gradient
         # backward workspace
         self.d_user = self._f(B, D)
@@ -342,7 +379,7 @@ class NamlEngine(_Base):
     # epilogues of the step then read one byte per 4 rows x column instead of running Philox on the critical path
     def prefetch_masks(self, stream, slot):
         b = self._slots[slot]
-        st = ctypes.c_void_p(stream.cuda_stream)
+        st = stream_handle(stream)
         for p, site, key in ((self.p_proj, SITE_PROJ, "mask_proj"), (self.p_conv, SITE_CONV, "mask_conv")):
             if p > 0.0 and self.Rc > 0:
                 call("lego_dropout_mask", ctypes.byref(LegoDropout(p, self.seed, site + 16 * self.step, None)), self.Rc,
@@ -364,7 +401,7 @@ class NamlEngine(_Base):
     def gather_tokens(self, stream=None, into=None, need_perm=True):
         """k1: X[r, :] = glove[row_tok[r], :] for the planned token rows (embedding_hub.py:95, frozen table)"""
         b = self.__dict__ if into is None else into
-        s = torch.cuda.current_stream() if stream is None else stream
+        s = current_stream() if stream is None else stream
         tag = "gather_rows_in_step" if stream is not None else "gather_rows"
         if self.dedup:
             # distinct tokens of the planned rows (uniq / inv / perm, U -> counters[6]), then ONE table row per distinct token
@@ -393,7 +430,7 @@ class NamlEngine(_Base):
     def plan_pairs(self, stream=None, into=None):
         """row pairs of the Winograd conv from the plan's seg_off; the pair count lands in counters[5]"""
         b = self.__dict__ if into is None else into
-        st = _stream() if stream is None else ctypes.c_void_p(stream.cuda_stream)
+        st = _stream() if stream is None else stream_handle(stream)
         call("lego_plan_pairs", _ptr(b["seg_off"]), self.NIc, _ptr(b["counters"], 1), _ptr(b["pair_info"]),
              _ptr(b["counters"], 5), st)
 
@@ -402,7 +439,7 @@ class NamlEngine(_Base):
         b = self._slots[slot]                        # category id of every planned instance: a function of the plan alone
         self.kk(stream, None, "lego_gather_i32", _ptr(self.tb.cat), _ptr(b["inst_item"]), self.NIc, _ptr(b["counters"], 1), _ptr(b["inst_cat"]))
         if self.Rc > 0:
-            if self.wino:
+            if self.wino_dw:
                 self.plan_pairs(stream, self._slots[slot])
             self.gather_tokens(stream, self._slots[slot])
 
@@ -413,8 +450,8 @@ class NamlEngine(_Base):
         if getattr(self, "_side", None) is None:
             self._side = [shared_stream(self.dev, "side0"), shared_stream(self.dev, "side1")]
             self._evs = [torch.cuda.Event() for _ in range(10)]
-        m = torch.cuda.current_stream()
-        if os.environ.get("LEGO_SERIAL") == "1":     # profiling aid: one stream, so per-kernel times do not overlap
+        m = current_stream()
+        if self._serial:                             # profiling aid: one stream, so per-kernel times do not overlap
             return m, m, m
         return m, self._side[0], self._side[1]
 
@@ -474,7 +511,7 @@ class NamlEngine(_Base):
                 _ptr(self.counters), _ptr(self.inst_item), _ptr(self.seg_off), _ptr(self.hist_off),
                 _ptr(self.rowinfo), _ptr(self.row_tok))
         self.kk(m, None, "lego_gather_i32", _ptr(self.tb.cat), _ptr(self.inst_item), self.NIc, self.cnt(1), _ptr(self.inst_cat))
-        if self.wino:
+        if self.wino_dw:
             self.plan_pairs(m)
 
     def _forward_items(self, training, fork_ev=None, zero_loss=False, gathered=False, neck_ev=None):
@@ -495,7 +532,7 @@ class NamlEngine(_Base):
             self.kk(sb, None, "lego_conv3_wino_pack", _ptr(P["item_op.cnn.weight"]), _ptr(self.wino_u), _ptr(self.wino_ut), D, D)
         else:
             self.kk(sb, None, "lego_conv3_pack", _ptr(P["item_op.cnn.weight"]), _ptr(self.wt), D, D)
-        one_wait = os.environ.get("LEGO_ONE_WAIT", "0") == "1"      # A/B: the conv waits ONCE, for the whole side chain (measured 1 % slower)
+        one_wait = self._one_wait                    # A/B: the conv waits ONCE, for the whole side chain (measured 1 % slower)
         if sb is not m and not one_wait:
             ev[8].record(sb)
         if zero_loss:
@@ -629,7 +666,7 @@ class NamlEngine(_Base):
             self._fork(ev[7], m, sb)
             pst = sb
         # ---- conv weight gradient after the data gradient on the main stream (a third stream measured 1-1.5 % slower)
-        if self.wino:
+        if self.wino_dw:
             self.kk(m, "conv3_bwd_weight", "lego_conv3_wino_bwd_weight", _ptr(self.dY), D, _ptr(self.H), D,
                     _ptr(self.pair_info), self.Pc, self.cnt(5), _ptr(self.wino_du), D, D)
             self.kk(m, None, "lego_conv3_wino_unpack_add", _ptr(self.wino_du), self.wino_slabs, _ptr(G["item_op.cnn.weight"]), D, D)
@@ -815,7 +852,7 @@ class NrmsEngine(_Base):
         if self.dedup and self.glove and self.p_proj > 0.0 and os.environ.get("LEGO_NRMS_MASK_AHEAD", "1") != "0":      # 0: in-kernel draws + a mask pass over dE
             b = self._slots[slot]
             call("lego_dropout_mask", ctypes.byref(LegoDropout(self.p_proj, self.seed, SITE_PROJ + 16 * self.step, None)), self.Rc,
-                 _ptr(b["counters"], 0), self.D, _ptr(b["mask_proj"]), ctypes.c_void_p(stream.cuda_stream))
+                 _ptr(b["counters"], 0), self.D, _ptr(b["mask_proj"]), stream_handle(stream))
             self._slot_mask_step[slot] = self.step
 
     def use_slot(self, s):
@@ -845,7 +882,7 @@ class NrmsEngine(_Base):
 
     def plan_on(self, stream, slot, cand, hist, hist_len, nb=None):
         super().plan_on(stream, slot, cand, hist, hist_len, nb)
-        self._long_lists(self._slots[slot], ctypes.c_void_p(stream.cuda_stream), nb)
+        self._long_lists(self._slots[slot], stream_handle(stream), nb)
         if self.Rc > 0:
             self._decode_gather(self._slots[slot], stream)
             self._slot_clean[slot] = bool(self.dedup)
@@ -857,7 +894,7 @@ class NrmsEngine(_Base):
             call("lego_mhsa_long_segments", _ptr(b["hist_off"]), (nb or self.B) if b is not self.__dict__ else self.nb, None, _ptr(b["long_users"]), _ptr(b["long_cnt"], 1), st)
 
     def _decode_gather(self, b, stream):
-        st = ctypes.c_void_p(stream.cuda_stream)
+        st = stream_handle(stream)
         call("lego_nrms_decode_rows", _ptr(b["row_tok"]), self.Rc, _ptr(b["counters"], 0), _ptr(b["idx_tok"]), _ptr(b["idx_spec"]),
              _ptr(b["idx_cat"]), _ptr(b["tokinfo"]), st)
         if self.dedup:
@@ -913,7 +950,7 @@ class NrmsEngine(_Base):
     def _att_fwd(self, pre, ws, x_ptr, rows_dyn, seg_off, n_cap, n_dyn, out, site, training, st, head=False, per_key=False):
         P, D, A = self.P, self.D, self.A
         rows = ws["rows"]
-        m = torch.cuda.current_stream()          # == st; tagged launches are HIP-event timed on it when bench.py asks
+        m = current_stream()          # == st; tagged launches are HIP-event timed on it when bench.py asks
         tg = pre[:4]
         W1, b1 = P[pre + "additive_attention.encoder.0.weight"], P[pre + "additive_attention.encoder.0.bias"]
         Wo, bo = P[pre + "multi_head_attention.out_proj.weight"], P[pre + "multi_head_attention.out_proj.bias"]
@@ -998,7 +1035,7 @@ class NrmsEngine(_Base):
         if sw is not m:
             self._sev[5].record(m)                       # the parameters are final on the main stream (Adam of the last step)
             sw.wait_event(self._sev[5])
-        sp = ctypes.c_void_p(sw.cuda_stream)
+        sp = stream_handle(sw)
         for pre, ws in (("item_op.", self.item_ws), ("user_op.", self.user_ws)):
             Wo, bo = P[pre + "multi_head_attention.out_proj.weight"], P[pre + "multi_head_attention.out_proj.bias"]
             Wl, bl = P[pre + "linear.weight"], P[pre + "linear.bias"]
@@ -1025,8 +1062,8 @@ class NrmsEngine(_Base):
         if getattr(self, "_sw", None) is None:
             self._sw = shared_stream(self.dev, "side0")
             self._sev = [torch.cuda.Event() for _ in range(12)]
-        m = torch.cuda.current_stream()
-        return m, (m if os.environ.get("LEGO_SERIAL") == "1" else self._sw)
+        m = current_stream()
+        return m, (m if self._serial else self._sw)
 
     def _att_bwd(self, pre, ws, G, x_ptr, dx_ptr, rows_dyn, seg_off, n_cap, n_dyn, gout, site, training, st, ev, dx_epi=None, per_key=False):
         """data-gradient chain on the current stream `st`; weight gradients in two groups on the side stream, each behind
@@ -1035,7 +1072,7 @@ class NrmsEngine(_Base):
         P, D, A = self.P, self.D, self.A
         rows = ws["rows"]
         m, sw = self._side()
-        sp = ctypes.c_void_p(sw.cuda_stream)
+        sp = stream_handle(sw)
         if self.fold == 2:
             self._att_bwd_folded(pre, ws, G, rows_dyn, seg_off, n_cap, n_dyn, gout, st, ev, m, sw, sp)
         else:
@@ -1229,7 +1266,7 @@ class NrmsEngine(_Base):
             self._plan(cand, hist, hist_len)
         self._forward_items(training, planned)
         if neck_ev is not None:
-            neck_ev.record(torch.cuda.current_stream())
+            neck_ev.record(current_stream())
         if not self._loss_zeroed:
             self.loss.zero_()
         self._loss_zeroed = False
@@ -1264,7 +1301,7 @@ class NrmsEngine(_Base):
         self._prepare_folds()
         self._folds_fresh = True
         if not (planned and getattr(self, "_slots", None) is not None):      # else: done with the plan (plan_on)
-            self._decode_gather(self.__dict__, torch.cuda.current_stream())
+            self._decode_gather(self.__dict__, current_stream())
         if self.glove and self.dedup:
             E0 = self.E0
             call("lego_linear_fwd", _ptr(self.Xu), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
@@ -1287,7 +1324,7 @@ class NrmsEngine(_Base):
             # rows -- token row where the position holds a token (tokinfo's live bit; idx_tok is -1 elsewhere and not read), plus the
             # special-id and category rows where those indices are >= 0
             if self.qkv_dedup:                       # Eu[u] = the one live look-up of distinct key u (token / [SEP] / category row)
-                self.kk(torch.cuda.current_stream(), "embed_gather_item", "lego_expand_rows", _ptr(P["embedding_vocab_table.glove.weight"]), D,
+                self.kk(current_stream(), "embed_gather_item", "lego_expand_rows", _ptr(P["embedding_vocab_table.glove.weight"]), D,
                         _ptr(self.idx_tok_u), self.Uc, self.cnt(6), D, None, _ptr(self.tokinfo_u),
                         _ptr(P["embedding_vocab_table.__cat_inputer_special_ids.weight"]), D, _ptr(self.idx_spec_u),
                         _ptr(P["embedding_vocab_table.category.weight"]), D, _ptr(self.idx_cat_u), _ptr(self.Eu), D)
@@ -1295,7 +1332,7 @@ class NrmsEngine(_Base):
                               self.items, SITE_ITEM_ATT, training, st, per_key=True)
                 return
             # (tagged: bench.py prices this launch -- the trainable table's row gather, on the step's critical path -- against the HBM roof)
-            self.kk(torch.cuda.current_stream(), "embed_gather_item", "lego_expand_rows", _ptr(P["embedding_vocab_table.glove.weight"]), D,
+            self.kk(current_stream(), "embed_gather_item", "lego_expand_rows", _ptr(P["embedding_vocab_table.glove.weight"]), D,
                     _ptr(self.idx_tok), self.Rc, self.cnt(0), D, None,
                     _ptr(self.tokinfo), _ptr(P["embedding_vocab_table.__cat_inputer_special_ids.weight"]), D, _ptr(self.idx_spec),
                     _ptr(P["embedding_vocab_table.category.weight"]), D, _ptr(self.idx_cat), _ptr(self.E), D)
@@ -1377,7 +1414,7 @@ class NrmsEngine(_Base):
             _, sw_ = self._side()
 
             def side_special():
-                spp = ctypes.c_void_p(sw_.cuda_stream)
+                spp = stream_handle(sw_)
                 with torch.cuda.stream(sw_):
                     torch._foreach_zero_([ws["S_sep"], ws["S_cat"]])
                 call("lego_nrms_special_grads", _ptr(self.seg_off), self.NIc, self.cnt(1), _ptr(self.idx_cat), _ptr(ws["d_qkv"]), 3 * D, 3 * D,

@@ -19,7 +19,7 @@ from typing import Dict, Optional
 import torch
 
 from ._lib import call
-from .engine import ItemTables, NamlEngine, NrmsEngine, _ptr, _stream, shared_stream
+from .engine import ItemTables, NamlEngine, NrmsEngine, _ptr, _stream, current_stream, shared_stream, stream_handle
 
 
 class FlatParams:
@@ -291,7 +291,7 @@ class TrainStep:
         batch_idx = self.batch_idx if batch_idx is None else batch_idx
         epoch, start, nb = self.schedule.at(batch_idx)
         row_user, row_item = d.rows(epoch)
-        st = _stream() if stream is None else ctypes.c_void_p(stream.cuda_stream)
+        st = _stream() if stream is None else stream_handle(stream)
         ru, ri = _ptr(row_user, start), _ptr(row_item, start)
         pos = d.positions(epoch)
         call("lego_sample_negatives", ru, ri, _ptr(d.neg_list), _ptr(d.neg_len), d.neg_cap, nb, self.K, d.n_items,
@@ -305,7 +305,7 @@ class TrainStep:
         slot = batch_idx % 2
         if go is None:
             go = self._go
-            go.record(torch.cuda.current_stream())
+            go.record(current_stream())
         self.pre.wait_event(go)                    # the slot's previous user (batch_idx - 2) is complete by then
         nb = self.sample_batch(batch_idx, slot, self.pre)
         self.engine.plan_on(self.pre, slot, self._cand[slot], self._hist[slot], self._hist_len[slot], nb)
@@ -379,7 +379,7 @@ class TrainStep:
             self.data.ensure_epoch(self.schedule.at(self.batch_idx + 1)[0])   # on this stream, before the events below
             if self._planned_step != self.batch_idx:
                 self._prefetch(self.batch_idx)
-            torch.cuda.current_stream().wait_event(self._ready[slot])
+            current_stream().wait_event(self._ready[slot])
             self.engine.use_slot(slot)
         else:
             self.sample_batch()
@@ -389,7 +389,7 @@ class TrainStep:
         go = neck = None
         if self.prefetch:
             go, neck = self._go, self._neck
-            go.record(torch.cuda.current_stream())         # everything before this step's forward
+            go.record(current_stream())         # everything before this step's forward
         _, loss = self.engine.forward(self.cand, self.hist, self.hist_len, training=True, planned=self.prefetch,
                                       fork_ev=go, neck_ev=neck)
         if self.prefetch:
