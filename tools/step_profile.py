@@ -29,9 +29,11 @@ evs = [torch.cuda.Event(enable_timing=True) for _ in range(N + 1)]
 torch.cuda.synchronize()
 evs[0].record()
 timers = {}
+rows = []
 for i in range(N):
     ts.engine.timers = timers if (i >= 60 and i % 8 == 0) else None
     ts.step()
+    rows.append(ts.engine.counters.clone())          # device copy of the batch's extents (token rows, instances, ..., distinct tokens)
     evs[i + 1].record()
 torch.cuda.synchronize()
 d = [evs[i].elapsed_time(evs[i + 1]) for i in range(N)]
@@ -42,3 +44,9 @@ tagged = [d[i] for i in range(60, N) if i % 8 == 0]
 print(f"steady plain {sum(plain)/len(plain):.4f} ms, steps with tagged-kernel events {sum(tagged)/len(tagged):.4f} ms")
 print(f"mean of steps 5-24 (the driver's window): {sum(d[5:25])/20:.4f} ms; steps 40-59: {sum(d[40:60])/20:.4f}")
 print("steps 0-29:", " ".join(f"{x:.3f}" for x in d[:30]))
+rr = torch.stack(rows).cpu().numpy()
+print("token rows per step, steps 0-29:", rr[:30, 0].tolist())
+import numpy as np
+print("corr(step time, token rows) over steps 30-119 (untagged):", float(np.corrcoef([d[i] for i in range(30, N) if i % 8 != 0], [rr[i, 0] for i in range(30, N) if i % 8 != 0])[0, 1]))
+print("mean token rows steps 5-24: %.0f, steps 40-119: %.0f" % (rr[5:25, 0].mean(), rr[40:, 0].mean()))
+
