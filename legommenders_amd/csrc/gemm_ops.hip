@@ -463,15 +463,19 @@ static int launch_rows(const GemmDims& d, const AL& a, const BL& b, const Epi& e
 //     more CUs busy for a reduction of a few thousand rows).
 constexpr int TN_LONG = 8192;
 
-static int pick_split_small(int rows_cap, int M, int N) {
+static int pick_split_small(int rows_cap, int M, int N, int small_target = 4096) {
     const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
-    // ~1024 workgroups (four per CU).  Outputs of several hundred tiles (BERT's 768 x 3072 FFN weights: 576) take ~2 300 workgroups --
+    // Outputs of several hundred tiles (BERT's 768 x 3072 FFN weights: 576) take ~2 300 workgroups --
     // 1024 / 576 floors to 1 and leaves 44 % of the workgroup slots empty; more, shorter workgroups also hide each other's load
     // latency (LEGO_TN_SPLIT overrides: tuning)
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("LEGO_TN_SPLIT"); forced = e != nullptr ? atoi(e) : 0; }
     // measured on [3072 x 768] over 29.6 k rows (tools/bert_shapes_bench.py): split 1 / 2 / 3 / 4 / 8 = 82 / 98 / 104 / 107 / 105 TFLOP/s
-    int s = tiles > 256 ? (2304 + tiles - 1) / tiles : 1024 / tiles;
+    // small outputs: ~4096 SHORT workgroups rather than ~1024 long ones.  Alone the launch is no faster (more atomics), but these products
+    // run on the side stream next to the main chain's latency-bound kernels, which can only start on a CU when a workgroup retires:
+    // NRMS step 1.035 -> 1.025 ms with the in-projection weight gradient (48 tiles) at 80-128 splits instead of 16, NAML unchanged
+    // (tools/r04_tnsplit.sh, two alternating same-box runs)
+    int s = tiles > 256 ? (2304 + tiles - 1) / tiles : small_target / tiles;
     if (forced > 0) s = forced;
     const int max_s = (rows_cap + 127) / 128;       // at least 128 reduction rows per block
     if (s > max_s) s = max_s;
@@ -526,7 +530,9 @@ static int launch_tn(int M, int N, int K_cap, const int* k_dyn, const AL& a, con
                 GemmDims d{M, N, K_cap, nullptr, k_dyn, s128};
                 return launch<TileCfg<128, 128, 4, 2>, true, true, EpiAtomic, true>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, taps * s128, st, what);
             }
-            GemmDims d{M, N, K_cap, nullptr, k_dyn, split};
+            // (~1024 workgroups here: the split kernel's 64 x 64 tiles are L2-bound, and four times the workgroups cost it 10 % of the
+            // step -- NAML 122.5 k -> 109.8 k impressions/s with the exact kernels' ~4096)
+            GemmDims d{M, N, K_cap, nullptr, k_dyn, pick_split_small(K_cap, M, N, 1024)};
             return launch<C64x64, true, true, EpiAtomic, true>(d, a, b, e, (M + 63) / 64, (N + 63) / 64, taps * d.split_k, st, what);
         }
     }
