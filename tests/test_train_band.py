@@ -54,12 +54,14 @@ def test_trained_gauc_matches_the_reference_band(name):
     _check_band(name)
 
 
-def test_trained_gauc_in_split_bf16_mode():
-    """the opt-in split-bf16 product mode (tests/test_split_bf16.py) trains to the same band: NAML, 16 seeds, same tolerance"""
+@pytest.mark.parametrize("name", ["naml", "nrms_d256"])
+def test_trained_gauc_in_split_bf16_mode(name):
+    """the opt-in split-bf16 product mode (tests/test_split_bf16.py) trains to the same bands, same tolerances: NAML (D = 64, 16 seeds)
+    and NRMS at the headline width (D = 256, B = 64, 8 seeds)"""
     from legommenders_amd import _lib
     _lib.set_product_mode(_lib.SPLIT_BF16)
     try:
-        _check_band("naml")
+        _check_band(name)
     finally:
         _lib.set_product_mode(_lib.EXACT_F32)
 
