@@ -168,7 +168,8 @@ EXACT_F32, SPLIT_BF16 = 0, 1
 def set_product_mode(mode: int) -> None:
     """process-wide product mode of the large dense products (include/lego_hip.h): EXACT_F32 (default, the parity mode) or
     SPLIT_BF16 (opt-in, ~2x the rate, relative error ~4e-6 per product).  Engines read it when they are BUILT (the NAML engine
-    takes the direct conv instead of the Winograd one in split mode), so set it before constructing a TrainStep / Evaluator."""
+    takes the direct conv for the forward and the data gradient in split mode and keeps the exact Winograd weight gradient), so set it
+    before constructing a TrainStep / Evaluator."""
     call("lego_set_product_mode", int(mode))
 
 
