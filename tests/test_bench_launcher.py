@@ -39,3 +39,26 @@ def test_world_size_mismatch_fails_loudly():
     assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr and "{" not in r.stdout
     r = _run(["--gpus", "1"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "{" not in r.stdout
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_the_drivers_command_prints_one_line_with_the_contract_fields():
+    """`python bench.py --gpus 1 --steps K --warmup W` (the driver's command shape) on the small world: exactly one JSON line on
+    stdout, the contract's fields with the metric's names, the live roofline object of the dominant kernel, f32"""
+    import json
+    r = _run(["--gpus", "1", "--steps", "6", "--warmup", "2", "--small", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["metric"] == "train impressions/sec on MIND-small NAML" and j["unit"] == "impressions/s"
+    assert j["n_gpus"] == 1 and j["steps"] == 6 and j["warmup"] == 2 and j["higher_is_better"] is True and j["scaling"] == "weak"
+    assert j["dtype"] == "f32" and j["data"] == "synthetic" and j["vs_baseline"] is None and "workload" in j["config"]
+    assert j["value"] > 0 and abs(j["value"] - 64 * 1e3 / j["ms_per_step"]) < 0.01 * j["value"]
+    roof = j["roofline"]
+    assert roof["bound"] in ("mfma", "hbm") and roof["unit"] in ("TFLOP/s", "GB/s") and roof["peak"] > 0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and "traffic" in roof
+    assert "cpu_baseline" in j and j["cpu_baseline"] is None          # skipped by the flag; the key stays
