@@ -937,13 +937,23 @@ class NrmsEngine(_Base):
 
     def _att_ws(self, rows, Lmax, n_seg):
         D, A, H = self.D, self.A, self.heads
+        # the four parameter-space sums of a folded backward pass share ONE buffer: cleared by one memset (`.zero_()` = a 1.6 us fill
+        # kernel; the multi-tensor zero launch it replaces sat 13-47 us on the side stream next to the attention core, and the weight
+        # gradient behind it then ran into the long-segment attention launch)
+        zs = self._f(A * D + D * D + D + A)
+        Tp, T = zs[:A * D].view(A, D), zs[A * D:A * D + D * D].view(D, D)
+        s_, sp = zs[A * D + D * D:A * D + D * D + D], zs[A * D + D * D + D:]
+        return dict(zsum=zs, Tp=Tp, T=T, s=s_, sp=sp, **self._att_ws_rest(rows, Lmax, n_seg))
+
+    def _att_ws_rest(self, rows, Lmax, n_seg):
+        D, A, H = self.D, self.A, self.heads
         return dict(rows=rows, Lmax=Lmax, qkv=self._f(rows, 3 * D), o=self._f(rows, D), att=self._f(rows, D),
                     lin=self._f(rows, D), t=self._f(rows, A), wrow=self._f(rows),
                     lse=self._f(rows, H) if self.mhsa_recompute else None, probs=None if self.mhsa_recompute else self._f(rows, H, Lmax),
                     d_lin=self._f(rows, D), d_att=self._f(rows, D), d_o=self._f(rows, D), d_qkv=self._f(rows, 3 * D),
                     seg_live=torch.zeros(max(n_seg, 1), dtype=torch.int32, device=self.dev),
-                    Wc=self._f(D, D), bc=self._f(D), T=self._f(D, D), U=self._f(D, D), s=self._f(D),
-                    W2=self._f(A, D), b2=self._f(A), Tp=self._f(A, D), U2=self._f(A, D), sp=self._f(A),
+                    Wc=self._f(D, D), bc=self._f(D), U=self._f(D, D),
+                    W2=self._f(A, D), b2=self._f(A), U2=self._f(A, D),
                     pooled=self._f(n_seg, D), d_pooled=self._f(n_seg, D))
 
     # AttentionOperator.forward over ragged segments
@@ -1166,8 +1176,8 @@ class NrmsEngine(_Base):
         def side_rows():
             if sw is not m:
                 sw.wait_event(ev[0])
-            with torch.cuda.stream(sw):                  # the four sums of this pass start from zero (one multi-tensor launch)
-                torch._foreach_zero_([ws["Tp"], ws["T"], ws["s"], ws["sp"]])
+            with torch.cuda.stream(sw):                  # the four sums of this pass start from zero (one memset: _att_ws)
+                ws["zsum"].zero_()
             call("lego_linear_bwd_weight", _ptr(ws["t"]), A, _ptr(ws["o"]), D, _ptr(ws["Tp"]), D, rows, rows_dyn, A, D, None, None, sp)
 
         def side_params():
