@@ -12,7 +12,8 @@ fp32 arithmetic (exact-f32 MFMA), all inputs resident in HBM before the timed re
 Synthetic MIND-small-shaped data, random-init weights (no dataset / GloVe on disk).
 
 Rank 0 prints ONE JSON line.  `value` / `ms_per_step` come from EXACTLY --steps steps between two
-barrier + synchronize brackets.  Beside it (N = 1 only, all after the timed region, each with its own
+barrier + synchronize brackets, after exactly --warmup untimed steps; before those, half a second of a dummy product wakes the device
+(BENCH_SPIN_MS, default 500; 0 = off: see the comment at its place).  Beside it (N = 1 only, all after the timed region, each with its own
 steps / ms so the driver's wall clock still bounds them):
   roofline           dominant forward GEMM, HIP-event timed on its launch stream inside the timed region;
                      `frac` prices the DIRECT-conv flops, `mfma_issue_frac` the flops the Winograd form really issues
@@ -22,8 +23,9 @@ steps / ms so the driver's wall clock still bounds them):
   roofline_step      the whole step against the fp32 matrix peak: algorithmic flops of its big products / step time (`frac`), and the
                      flops the kernels issue (projection per distinct token, Winograd 2/3) the same way (`issued_frac`)
   long_run           2000 steps of the same configuration when --steps is smaller (a 20-step window is 14 ms)
-  secondary          NRMS config 3 (with its dominant-kernel roofline), the worst-case dense NAML world (every history
-                     50, every title 30 tokens) and a world with MIND-like length statistics are NOT the metric; they are printed so that the number's dependence
+  secondary          NRMS config 3 (with its dominant-kernel roofline, and the trainable-table variant), the worst-case dense NAML world (every history
+                     50, every title 30 tokens), a world with MIND-like length statistics, BERT config 5 and the OPT-IN split-bf16 product
+                     mode (`split_bf16_opt_in`, its dtype stated there) are NOT the metric; they are printed so that the number's dependence
                      on the model and on raggedness is on record
   allreduce_ms       (N > 1 or --force-dist) one RCCL all-reduce of the flat gradient buffer, timed alone
   dist_path_check    (N = 1) the same on a one-rank RCCL communicator created after the timed region: all-reduce alone + 100 steps with it
