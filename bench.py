@@ -419,7 +419,8 @@ def main():
         wino = ("conv3_fwd", "conv3_bwd_data", "conv3_bwd_weight") if getattr(eng, "wino", False) else ()
     else:
         solo, wino = ("qkv_fwd_item", "out_proj_fwd_item", "linear_fwd_item", "outlin_fwd_item", "additive_fwd_item"), ()
-    price(kern, flops_for(rows_tab, inst_tab, uniq_tab if dedup else None), wino)
+    flops_tab = flops_for(rows_tab, inst_tab, uniq_tab if dedup else None)
+    price(kern, flops_tab, wino)
     if args.model == "naml":
         price(kern, naml_small_flops(tagged_steps.hist, D), ())
         price_hbm(kern, naml_stream_bytes(rows_tab, inst_tab, uniq_tab if dedup else rows_tab, D))
@@ -429,13 +430,16 @@ def main():
         price_hbm(kern, nrms_core_bytes(rows_tab, D))
     for k in kern:
         kern[k]["timed"] = "8 steps after the timed region, every tagged kernel bracketed"
-    for k, v in kern_in.items():                   # the kernels bracketed inside the timed region keep those figures
+    for k, v in kern_in.items():
         v["timed"] = "inside the timed region"
-        kern[k] = v
+        if k in solo and k in kern:                # the roofline kernel: the 8 launches after the region are the figure (the driver's 20-step
+            kern[k]["in_region"] = {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()}    # window brackets 2), the
+        else:                                      # in-region one stays beside it; prefetch-stream kernels keep their in-region figures
+            kern[k] = v
     for k in kern:
         kern[k]["overlapped"] = k not in solo and not k.startswith("gather_rows") and not k.startswith("expand_rows")
     traffic, traffic_src = pmc_traffic()
-    roofline = dominant(kern, flops, solo, traffic)
+    roofline = dominant(kern, flops_tab, solo, traffic)       # algorithmic flops of the batches its launches were timed on
     if roofline is not None:
         roofline["traffic_source"] = traffic_src
     roofline_gather = None
@@ -663,6 +667,7 @@ def main():
                    "projection": ("once per DISTINCT token of the batch, expanded to the token rows (exact: the frozen-table "
                                   "projection depends on the token id alone); LEGO_DEDUP=0 projects row by row") if dedup else "row by row"},
         "final_loss": round(final_loss, 5),
+        "device_wakeup_ms": spin_ms, "time_every_effective": every,
         "roofline": roofline, "roofline_gather": roofline_gather, "roofline_step": step_roofline(args.model, flops, dt / args.steps, rows_per_launch, D, E0, wino),
         "kernels": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kern.items()},
     }
@@ -795,7 +800,10 @@ def dominant(kern, flops, solo, traffic):
     _, dom = max(mf)
     r = {"kernel": dom, "bound": "mfma", "achieved": round(kern[dom]["tflops"], 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
          "frac": round(kern[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic.get(dom),
-         "avg_launch_ms": round(kern[dom]["avg_ms"], 5), "algorithmic_flops_per_launch": flops[dom]}
+         "avg_launch_ms": round(kern[dom]["avg_ms"], 5), "launches": kern[dom].get("launches"), "timed": kern[dom].get("timed"),
+         "algorithmic_flops_per_launch": flops[dom]}
+    if "in_region" in kern[dom]:
+        r["in_region"] = kern[dom]["in_region"]
     if "mfma_issue_frac" in kern[dom]:
         r["mfma_issue_frac"] = round(kern[dom]["mfma_issue_frac"], 4)
         r["note"] = "frac prices the direct conv's 2*3*D*D flops per row; the Winograd F(2,3) kernel issues 2/3 of them (mfma_issue_frac)"

@@ -32,6 +32,7 @@ struct WinoArgs {
     int N;                                  // output channels
     const int* pair_info; int P_cap; const int* P_dyn;
     int swap;                               // backward-data: sets 0 and 3 swap weights
+    unsigned x_bytes = 0;                   // gemm_wino2.hpp: extent of x for its buffer descriptor (set by launch_wino2)
 };
 
 template <bool B_MC>

@@ -249,8 +249,9 @@ def mhsa_fwd(x, mask, in_w, in_b, out_w, out_b, heads, drop=None, padded=False):
     xc = gather_rows(x.view(n * L, D), idx, out=xc_[:R])
     qkv = linear_fwd(xc, in_w, in_b, out=qkv_[:R])
     o, lse = o_[:R], lse_[:R]
-    call("lego_mhsa_core_fwd", _ptr(qkv), 3 * D, _ptr(seg_off), n, None, D, heads, _ptr(o), D, _ptr(lse), None, L,
-         _drop(drop), R, 0, None, None, _stream())
+    if R > 0:                                       # an all-masked batch has no rows: lse[:0] is a NULL pointer, which the entry point refuses
+        call("lego_mhsa_core_fwd", _ptr(qkv), 3 * D, _ptr(seg_off), n, None, D, heads, _ptr(o), D, _ptr(lse), None, L,
+             _drop(drop), R, 0, None, None, _stream())
     yc = linear_fwd(o, out_w, out_b)
     y = torch.zeros(n * L, D, dtype=torch.float32, device=x.device)
     y.index_copy_(0, idx.long(), yc)
@@ -272,8 +273,9 @@ def mhsa_bwd(ctx, gy):
     colsum(gyc, gout_b)
     go = linear_bwd_data(gyc, ctx.out_w)
     gqkv = torch.empty(R, 3 * D, dtype=torch.float32, device=dev)
-    call("lego_mhsa_core_bwd", _ptr(ctx.qkv), 3 * D, _ptr(ctx.seg_off), n, None, D, ctx.heads, _ptr(go), D, _ptr(ctx.lse), None, L,
-         _drop(ctx.drop), R, _ptr(gqkv), 3 * D, None, 0, None, None, _stream())
+    if R > 0:
+        call("lego_mhsa_core_bwd", _ptr(ctx.qkv), 3 * D, _ptr(ctx.seg_off), n, None, D, ctx.heads, _ptr(go), D, _ptr(ctx.lse), None, L,
+             _drop(ctx.drop), R, _ptr(gqkv), 3 * D, None, 0, None, None, _stream())
     gin_w = torch.zeros(3 * D, D, dtype=torch.float32, device=dev)
     gin_b = torch.zeros(3 * D, dtype=torch.float32, device=dev)
     linear_bwd_weight(gqkv, ctx.xc, gin_w)

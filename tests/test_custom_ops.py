@@ -158,6 +158,21 @@ def test_ops_autograd_matches_torch_fp32():
 
 
 @pytest.mark.gpu
+def test_mhsa_op_with_every_position_masked():
+    """a batch whose sequences are all empty (R == 0 live rows) through the dispatcher route: zeros out, zero gradients, no error
+    (lse[:0] is a NULL pointer and the entry point refuses NULL lse + NULL probs)"""
+    n, Ls, D, heads = 3, 5, 32, 4
+    x = _r(n, Ls, D, grad=True)
+    mask = torch.zeros(n, Ls, dtype=torch.int32, device=x.device)
+    in_w, in_b = _r(3 * D, D, seed=1, grad=True, scale=0.2), _r(3 * D, seed=2, grad=True)
+    out_w, out_b = _r(D, D, seed=3, grad=True, scale=0.2), _r(D, seed=4, grad=True)
+    y = L.mhsa(x, mask, in_w, in_b, out_w, out_b, heads, 0.1, 11, 3)[0]
+    assert y.shape == (n, Ls, D) and float(y.abs().max()) == 0.0
+    g = torch.autograd.grad(y.sum(), [x, in_w, in_b, out_w, out_b])
+    assert all(float(t.abs().max()) == 0.0 for t in g)
+
+
+@pytest.mark.gpu
 def test_plugin_operators_dispatch_through_torch_ops():
     """model.operators reach the kernels through the dispatcher: a dispatch-mode trace of CNNOperator's forward sees lego_hip ops"""
     from torch.utils._python_dispatch import TorchDispatchMode

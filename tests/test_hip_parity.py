@@ -650,6 +650,58 @@ def test_winograd_conv_matches_direct_and_torch(D, n_items):
         _close(y1[s:e].cpu(), ref, rtol=2e-5, what=f"wino fwd vs torch, item {i} len {e - s}")
 
 
+@pytest.mark.parametrize("D,n_items,lo,hi", [(64, 700, 1, 30), (96, 300, 2, 9), (256, 5, 1, 3), (256, 1, 30, 30), (256, 2100, 1, 30)])
+def test_winograd_conv_with_precomputed_keep_bits(D, n_items, lo, hi):
+    """The training step's form of the Winograd conv: dropout keep bits made ahead of time (lego_dropout_mask) and read by the
+    epilogue -- the round-5 kernel (csrc/gemm_wino2.hpp: row-major epilogue, one 32-bit mask word per 4 columns) -- against the
+    direct three-tap kernels reading the SAME bits: forward (+ bias, ReLU), data gradient and its column sums.  Widths below one
+    column half (64, 96), a plan smaller than one strip, a single full-length item, and rows behind the plan must stay untouched."""
+    import ctypes
+    from legommenders_amd._lib import call, LegoDropout
+    dev = _dev()
+    g = torch.Generator().manual_seed(5 + D + n_items)
+
+    def P(t, off=0):
+        return ctypes.c_void_p(t.data_ptr() + off * t.element_size())
+    lens = torch.randint(lo, hi + 1, (n_items,), generator=g).int()
+    seg = torch.zeros(n_items + 1, dtype=torch.int32)
+    seg[1:] = torch.cumsum(lens, 0)
+    R = int(seg[-1])
+    pos = torch.arange(R) - torch.repeat_interleave(seg[:-1].long(), lens.long())
+    ln = torch.repeat_interleave(lens.long(), lens.long())
+    inst = torch.repeat_interleave(torch.arange(n_items), lens.long())
+    rowinfo = ((pos > 0).int() | ((pos < ln - 1).int() << 1) | 4 | (inst.int() << 8)).int().contiguous().to(dev)
+    cnt = torch.tensor([R, n_items, R + n_items, 0, 0, 0, 0, 0], dtype=torch.int32, device=dev)
+    Pcap = n_items * ((hi + 1) // 2) + 3
+    pair = torch.zeros(Pcap, dtype=torch.int32, device=dev)
+    call("lego_plan_pairs", P(seg.to(dev)), n_items, P(cnt, 1), P(pair), P(cnt, 5), None)
+    hd = torch.randn(R, D, generator=g).to(dev)
+    wd = (torch.randn(D, D, 3, generator=g) * 0.05).to(dev)
+    bd = (torch.randn(D, generator=g) * 0.1).to(dev)
+    gyd = torch.randn(R, D, generator=g).to(dev)
+    wt = torch.zeros(3, D, D, device=dev); u = torch.zeros(4, D, D, device=dev); ut = torch.zeros(4, D, D, device=dev)
+    call("lego_conv3_pack", P(wd), P(wt), D, D, None)
+    call("lego_conv3_wino_pack", P(wd), P(u), P(ut), D, D, None)
+    mask = torch.zeros(((R + 3) // 4) * D + 4, dtype=torch.uint8, device=dev)
+    call("lego_dropout_mask", ctypes.byref(LegoDropout(0.25, 2023, 9, None)), R, P(cnt, 0), D, P(mask), None)
+    dr = ctypes.byref(LegoDropout(0.25, 2023, 9, mask.data_ptr()))
+    y0 = torch.zeros(R, D, device=dev); y1 = torch.full((R + 2, D), 7.0, device=dev)
+    call("lego_conv3_fwd", P(hd), D, P(wt), P(bd), P(rowinfo), P(y0), D, R, P(cnt, 0), D, D, dr, 0, None)
+    call("lego_conv3_wino_fwd", P(hd), D, P(u), P(bd), P(pair), Pcap, P(cnt, 5), P(y1), D, D, D, dr, None)
+    d0 = torch.zeros(R, D, device=dev); d1 = torch.full((R + 2, D), 7.0, device=dev)
+    c0 = torch.zeros(D, device=dev); c1 = torch.zeros(D, device=dev)
+    call("lego_conv3_bwd_data", P(gyd), D, P(wt), P(rowinfo), P(d0), D, R, P(cnt, 0), D, D, dr, P(c0), 0, None)
+    call("lego_conv3_wino_bwd_data", P(gyd), D, P(u), P(ut), P(pair), Pcap, P(cnt, 5), P(d1), D, D, D, dr, P(c1), None)
+    torch.cuda.synchronize()
+    assert float(y1[R:].min()) == 7.0 == float(y1[R:].max()) and float(d1[R:].min()) == 7.0 == float(d1[R:].max())
+    assert float(((y0 == 0) != (y1[:R] == 0)).float().mean()) < 1e-4   # the same elements dropped (a pre-activation within rounding of 0 may differ)
+    keep = float((d0 != 0).float().mean())
+    assert abs(keep - 0.75) < 0.03
+    _close(y1[:R].cpu(), y0.cpu(), rtol=2e-5, what="wino fwd (keep bits) vs direct")
+    _close(d1[:R].cpu(), d0.cpu(), rtol=2e-5, what="wino bwd_data (keep bits) vs direct")
+    _close(c1.cpu(), c0.cpu(), rtol=3e-5, what="wino bwd_data (keep bits) column sums")
+
+
 def test_naml_engine_hidden_512_matches_oracle():
     """Hidden size 512: outside the Winograd kernels' range (N <= 256), so the conv runs as the direct three-tap
     implicit GEMM and every row product as a row-strip kernel with two column panels; logits and all gradients
