@@ -27,6 +27,14 @@ int check_launch(const char* what) {
 }
 const char* last_error() { return g_err; }
 
+// round 5: gemm_tnd.hpp (tnd_ops.hip) -- plain-row weight gradients with the operand fragments straight from global memory
+int tndp_slabs(int Dout, int Din, int P_cap);
+int launch_tndp(const float* gy, int ldg, const float* h, int ldh, const int* pair_info, int P_cap, const int* P_dyn, float* du,
+                int Dout, int Din, hipStream_t st, const char* what);
+bool tnd_ok(int M, int N, int K_cap, int lda, int ldb, int ldc);
+int launch_tnd(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int M, int N, int K_cap, const int* k_dyn,
+               const int* a_row_off, const int* b_row_off, hipStream_t st, const char* what);
+
 
 }  // namespace lego
 #include "gemm_wino.hpp"
@@ -389,6 +397,8 @@ extern "C" int lego_linear_bwd_weight(const float* g, int ldg, const float* x, i
     CHECK4(ldg); CHECK4(ldx); CHECK4(N); CHECK4(K);
     if (M_cap <= 0) return 0;
     // dW[N,K] += sum_r g[r,:]^T x[r,:]: TN product, reduction over the rows
+    if (product_mode() == 0 && tnd_ok(N, K, M_cap, ldg, ldx, lddw))        // round 5: operand fragments straight from global memory (gemm_tnd.hpp)
+        return launch_tnd(g, ldg, x, ldx, dW, lddw, N, K, M_cap, M_dyn, g_row_off_dyn, x_row_off_dyn, (hipStream_t)stream, "lego_linear_bwd_weight");
     McRows a{g, ldg, N, M_cap, g_row_off_dyn};
     McRows b{x, ldx, K, M_cap, x_row_off_dyn};
     Epi e = make_epi(dW, lddw);
@@ -530,6 +540,7 @@ static int convw64_split() {
 
 extern "C" int lego_conv3_wino_du_slabs(int Dout, int Din, int P_cap) {
     if (P_cap < TN_LONG) return 1;                  // short reductions accumulate with atomics into ONE cleared buffer
+    if (product_mode() == 0 && tndp_slabs(Dout, Din, P_cap) > 0) return tndp_slabs(Dout, Din, P_cap);      // round 5: gemm_tnd.hpp
     if (convw64_split() > 1) return convw64_split();
     return tn_split(Dout, Din, P_cap, 4);
 }
@@ -539,6 +550,8 @@ extern "C" int lego_conv3_wino_bwd_weight(const float* gy, int ldg, const float*
     CHECK4(ldg); CHECK4(ldh); CHECK4(Dout); CHECK4(Din);
     if (P_cap <= 0) return 0;
     // du[set][o][c] += sum_pairs dM_set[o] * A_set[c]: four TN products over the pair rows (gridDim.z = 4 * split)
+    if (P_cap >= TN_LONG && product_mode() == 0 && tndp_slabs(Dout, Din, P_cap) > 0)
+        return launch_tndp(gy, ldg, h, ldh, pair_info, P_cap, P_dyn, du, Dout, Din, (hipStream_t)stream, "lego_conv3_wino_bwd_weight");
     McPair a{gy, ldg, Dout, P_cap, pair_info, 1, 0};
     McPair b{h, ldh, Din, P_cap, pair_info, 0, 0};
     Epi e = make_epi(du, Din);

@@ -9,6 +9,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from legommenders_amd import _lib  # noqa: E402
 from legommenders_amd._lib import call  # noqa: E402
 from legommenders_amd.engine import LegoDropout  # noqa: E402
 
@@ -83,10 +84,25 @@ def case(D, NI, lo, hi, seed, p, timing=False):
     e_b = (d0_ - d1_[:R]).abs().max().item()
     sb = d0_.abs().max().item()
     e_c = ((c0 - c1).abs().max() / c0.abs().max()).item()
-    ok = e_f <= 3e-5 * max(scale, 1) and e_b <= 3e-5 * max(sb, 1) and e_c < 1e-4
-    line = f"D={D} NI={NI} len {lo}-{hi} rows {R} pairs {int(cnt[5])} p={p}: fwd {e_f:.2e} (scale {scale:.1f}) bwd {e_b:.2e} (scale {sb:.1f}) colsum rel {e_c:.1e}"
+    # weight gradient: Winograd form over the pairs (slabs + unpack) against the direct three taps
+    S = _lib.lib().lego_conv3_wino_du_slabs(D, D, pair.numel())
+    dwt = torch.zeros(3, D, D, device=dev)
+    du = torch.full((S, 4, D, D), float("nan") if S > 1 else 0.0, device=dev)
+    gw0 = torch.zeros(D, D, 3, device=dev); gw1 = torch.zeros(D, D, 3, device=dev)
+    w0 = lambda: call("lego_conv3_bwd_weight", P(gy), D, P(h), D, P(rowinfo), P(dwt), R, P(cnt, 0), D, D, None)
+    w1 = lambda: call("lego_conv3_wino_bwd_weight", P(gy), D, P(h), D, P(pair), pair.numel(), P(cnt, 5), P(du), D, D, None)
+    w0(); call("lego_conv3_unpack_add", P(dwt), P(gw0), D, D, None)
+    w1(); call("lego_conv3_wino_unpack_add", P(du), S, P(gw1), D, D, None)
+    e_w = (gw0 - gw1).abs().max().item()
+    sw = gw0.abs().max().item()
+    ok = e_f <= 3e-5 * max(scale, 1) and e_b <= 3e-5 * max(sb, 1) and e_c < 1e-4 and e_w <= 3e-5 * max(sw, 1)
+    line = (f"D={D} NI={NI} len {lo}-{hi} rows {R} pairs {int(cnt[5])} p={p}: fwd {e_f:.2e} (scale {scale:.1f}) bwd {e_b:.2e} (scale {sb:.1f}) "
+            f"colsum rel {e_c:.1e} wgrad {e_w:.2e} (scale {sw:.1f}, {S} slabs)")
     if timing:
         line += f" | fwd direct {bench(f0):.1f} us wino {bench(f1):.1f} us | bwd direct {bench(g0):.1f} us wino {bench(g1):.1f} us"
+        if S > 1:                                    # (a single slab is an atomics accumulator: it would have to be cleared between launches)
+            u1 = lambda: call("lego_conv3_wino_unpack_add", P(du), S, P(gw1), D, D, None)
+            line += f" | wgrad direct {bench(w0):.1f} us wino {bench(w1):.1f} us + unpack {bench(u1):.1f} us"
     print(("ok   " if ok else "FAIL ") + line, flush=True)
     return ok
 
