@@ -362,7 +362,13 @@ def main():
     rows_per_launch, inst_per_launch = cs[0] / max(1, args.steps), cs[1] / max(1, args.steps)
     dedup = bool(getattr(ts.engine, "dedup", False))
     uniq_per_launch = cs[6] / max(1, args.steps) if dedup else rows_per_launch     # distinct tokens: the rows the projection runs on
-    # every tagged kernel on a few extra steps AFTER the timed region; the kernels bracketed inside it keep their in-region figures
+    # the roofline kernel on 16 more steps in the timed region's own conditions (only the in-region tags bracketed: bracketing EVERY
+    # kernel serialises the streams and the conv then runs ~8 % faster than it does in the step; the region itself brackets 2 of the
+    # driver's 20 steps, too few for a stable mean) ...
+    ts.counter_sum.zero_()
+    _, tm_roof, _ = timed_steps(ts, 16, 0, barrier, 1, tags=in_region)
+    cs_roof = ts.counter_sum.tolist()
+    # ... and every tagged kernel on a few extra steps; the kernels bracketed inside the region keep their in-region figures
     tm_all, rows_tab, inst_tab = tagged_steps(ts, 8, barrier)
     uniq_tab = tagged_steps.uniq
     kern = kernel_table(tm_all)
@@ -430,16 +436,24 @@ def main():
         price_hbm(kern, nrms_core_bytes(rows_tab, D))
     for k in kern:
         kern[k]["timed"] = "8 steps after the timed region, every tagged kernel bracketed"
+    kern_roof = kernel_table(tm_roof)
+    flops_roof = flops_for(cs_roof[0] / 16, cs_roof[1] / 16, cs_roof[6] / 16 if dedup else None)
+    price(kern_roof, flops_roof, wino)
+    rnd = lambda v: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()}
     for k, v in kern_in.items():
         v["timed"] = "inside the timed region"
-        if k in solo and k in kern:                # the roofline kernel: the 8 launches after the region are the figure (the driver's 20-step
-            kern[k]["in_region"] = {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()}    # window brackets 2), the
-        else:                                      # in-region one stays beside it; prefetch-stream kernels keep their in-region figures
+        if k in solo and k in kern_roof:           # the roofline kernel: 16 launches in the region's conditions are the figure; the region's
+            every_tagged = kern.get(k)             # own 2 launches and the all-kernels-bracketed form stay beside it
+            kern[k] = dict(kern_roof[k], timed="16 steps after the timed region, only the in-region tags bracketed")
+            kern[k]["in_region"] = rnd(v)
+            if every_tagged is not None:
+                kern[k]["every_kernel_bracketed"] = rnd(every_tagged)
+        else:                                      # prefetch-stream kernels keep their in-region figures
             kern[k] = v
     for k in kern:
         kern[k]["overlapped"] = k not in solo and not k.startswith("gather_rows") and not k.startswith("expand_rows")
     traffic, traffic_src = pmc_traffic()
-    roofline = dominant(kern, flops_tab, solo, traffic)       # algorithmic flops of the batches its launches were timed on
+    roofline = dominant(kern, dict(flops_tab, **{k: flops_roof[k] for k in kern_roof if k in flops_roof and k in solo}), solo, traffic)   # flops of the batches its launches were timed on
     if roofline is not None:
         roofline["traffic_source"] = traffic_src
     roofline_gather = None
@@ -580,6 +594,32 @@ def main():
             "conv3_fwd": {k: (round(v, 5) if isinstance(v, float) else v) for k, v in k3.get("conv3_fwd", {}).items()}}
         del t3, dd
         torch.cuda.empty_cache()
+        # the row gather where it IS bound by HBM: (a) the dense world with the projection's token de-duplication
+        # off -- the step then gathers all 105.6 k token rows of a batch (127 MB read + 127 MB written) on the prefetch stream;
+        # (b) the same launch alone, uniform random rows of the 480 MB table, every launch on a cold Infinity Cache (tools/gather_hbm.py)
+        os.environ["LEGO_DEDUP"] = "0"
+        try:
+            dd = DeviceData(dense_world(world), dev, seed=2023)
+            t5 = make_ts("naml", dd)
+            d5, tm5, _ = timed_steps(t5, 24, 6, barrier, 1, tags={"gather_rows_in_step"})
+            c5 = t5.counter_sum.tolist()
+            g5 = kernel_table(tm5).get("gather_rows_in_step", {})
+            b5 = c5[0] / 24 * (E0 * 4 * 2 + 4)
+            gh = {"in_step_dense_dedup_off": {
+                "workload": "dense world, LEGO_DEDUP=0: every token row of the batch gathered (prefetch stream, beside the previous step)",
+                "rows_per_launch": round(c5[0] / 24, 1), "algorithmic_bytes_per_launch": int(b5), "launches": g5.get("launches"),
+                "avg_launch_ms": round(g5.get("avg_ms", 0.0), 5), "ms_per_step": round(d5 / 24 * 1e3, 4),
+                "achieved": round(b5 / (g5["avg_ms"] * 1e-3) / 1e9, 1) if g5.get("avg_ms") else None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(b5 / (g5["avg_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if g5.get("avg_ms") else None}}
+            del t5, dd
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import gather_hbm
+            gh["alone_cold_cache"] = gather_hbm.measure(dev, table=glove)
+            gh["traffic"] = traffic.get("gather_rows_hbm")
+            sec["gather_rows_hbm_bound"] = gh
+        finally:
+            del os.environ["LEGO_DEDUP"]
         # length statistics close to the real MIND-small tables
         dm = DeviceData(mind_like_world(world), dev, seed=2023)
         t4 = make_ts("naml", dm)
@@ -802,8 +842,9 @@ def dominant(kern, flops, solo, traffic):
          "frac": round(kern[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic.get(dom),
          "avg_launch_ms": round(kern[dom]["avg_ms"], 5), "launches": kern[dom].get("launches"), "timed": kern[dom].get("timed"),
          "algorithmic_flops_per_launch": flops[dom]}
-    if "in_region" in kern[dom]:
-        r["in_region"] = kern[dom]["in_region"]
+    for extra in ("in_region", "every_kernel_bracketed"):
+        if extra in kern[dom]:
+            r[extra] = kern[dom][extra]
     if "mfma_issue_frac" in kern[dom]:
         r["mfma_issue_frac"] = round(kern[dom]["mfma_issue_frac"], 4)
         r["note"] = "frac prices the direct conv's 2*3*D*D flops per row; the Winograd F(2,3) kernel issues 2/3 of them (mfma_issue_frac)"

@@ -267,6 +267,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 // 1 152-B rows gathered into registers read at 5.5-5.8 TB/s in this shape): a row is w4 <= 128 pieces of 16 B, lane l moves
 // pieces l and l + 64; the row index is wave-uniform (scalar load), there is no per-element division, and every row's pieces
 // are contiguous in one instruction.  Rows are dealt to waves round-robin so that neighbouring waves write neighbouring rows.
+template <int U, bool NT>
 __global__ __launch_bounds__(256) void gather_rows_wave_kernel(const float* __restrict__ table, int ld_table, int w4,
                                                                const int* __restrict__ idx, int rows_cap,
                                                                const int* __restrict__ rows_dyn, float* __restrict__ out, int ld_out,
@@ -275,7 +276,6 @@ __global__ __launch_bounds__(256) void gather_rows_wave_kernel(const float* __re
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     const int n_waves = gridDim.x * (blockDim.x >> 6);
-    constexpr int U = 4;
     const bool two = lane + 64 < w4, one = lane < w4;
     for (int r0 = wave; r0 < rows; r0 += U * n_waves) {
         f32x4 a[U], b[U];
@@ -290,8 +290,13 @@ __global__ __launch_bounds__(256) void gather_rows_wave_kernel(const float* __re
             a[u] = b[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (src[u] >= 0) {
                 const f32x4* row = reinterpret_cast<const f32x4*>(table + (size_t)src[u] * ld_table);
-                if (one) a[u] = row[lane];
-                if (two) b[u] = row[lane + 64];
+                if constexpr (NT) {         // once-read rows: streaming loads leave the caches to data that is used again
+                    if (one) a[u] = __builtin_nontemporal_load(row + lane);
+                    if (two) b[u] = __builtin_nontemporal_load(row + lane + 64);
+                } else {
+                    if (one) a[u] = row[lane];
+                    if (two) b[u] = row[lane + 64];
+                }
             }
         }
 #pragma unroll
@@ -301,6 +306,9 @@ __global__ __launch_bounds__(256) void gather_rows_wave_kernel(const float* __re
             f32x4* dst = reinterpret_cast<f32x4*>(out + (size_t)r * ld_out);
             if (accumulate) {
                 if (src[u] >= 0) { if (one) dst[lane] += a[u]; if (two) dst[lane + 64] += b[u]; }
+            } else if constexpr (NT) {
+                if (one) __builtin_nontemporal_store(a[u], dst + lane);
+                if (two) __builtin_nontemporal_store(b[u], dst + lane + 64);
             } else {
                 if (one) dst[lane] = a[u];
                 if (two) dst[lane + 64] = b[u];
@@ -1669,10 +1677,21 @@ extern "C" int lego_gather_rows(const float* table, int ld_table, int width, con
     static int wave_form = -1;                       // LEGO_GATHER_WAVE=0: the flat float4 stream (A/B)
     if (wave_form < 0) { const char* v = getenv("LEGO_GATHER_WAVE"); wave_form = (v != nullptr && v[0] == '0') ? 0 : 1; }
     if (wave_form && width >= 64 * 4 && width <= 128 * 4) {          // rows of 1-2 KB: one wave per row, 16 waves per CU
-        const int want_blocks = (rows_cap + 4 * 4 - 1) / (4 * 4);     // 4 waves per block x 4 rows in flight
-        const int blocks = want_blocks < 1024 ? (want_blocks > 0 ? want_blocks : 1) : 1024;
-        hipLaunchKernelGGL(gather_rows_wave_kernel, dim3(blocks), dim3(256), 0, ST, table, ld_table, width / 4, idx, rows_cap, rows_dyn, out,
-                           ld_out, accumulate);
+        static int gu = -1, gnt = -1, gb = -1;               // LEGO_GATHER_U / _NT / _BLOCKS: rows in flight per wave, streaming accesses, grid (A/B)
+        if (gu < 0) { const char* v = getenv("LEGO_GATHER_U"); gu = v != nullptr ? atoi(v) : 4; }
+        // streaming (nt) loads and stores when the launch moves more than the caches hold between two uses of a line: uniform random
+        // 1 200-byte rows of the 480 MB table, cold Infinity Cache, 105.6 k rows: 67.5 -> 54.4 us (0.47 -> 0.58 of 8 TB/s, read + write
+        // bytes; tools/gather_hbm.py); a Zipf index stream (rows repeat) is faster with the default policy, so small launches keep it
+        if (gnt < 0) { const char* v = getenv("LEGO_GATHER_NT"); gnt = v != nullptr ? atoi(v) : 2; }
+        if (gb < 0) { const char* v = getenv("LEGO_GATHER_BLOCKS"); gb = v != nullptr ? atoi(v) : 1024; }
+        const int want_blocks = (rows_cap + 4 * gu - 1) / (4 * gu);   // 4 waves per block x U rows in flight
+        const int blocks = want_blocks < gb ? (want_blocks > 0 ? want_blocks : 1) : gb;
+#define LEGO_GATHER_GO(U_, NT_) hipLaunchKernelGGL((gather_rows_wave_kernel<U_, NT_>), dim3(blocks), dim3(256), 0, ST, table, ld_table, width / 4, idx, rows_cap, rows_dyn, out, ld_out, accumulate)
+        const bool nt = gnt == 1 || (gnt == 2 && !accumulate && (long long)rows_cap * width * 4 >= (64ll << 20));
+        if (gu == 8) { if (nt) LEGO_GATHER_GO(8, true); else LEGO_GATHER_GO(8, false); }
+        else if (gu == 2) { if (nt) LEGO_GATHER_GO(2, true); else LEGO_GATHER_GO(2, false); }
+        else { if (nt) LEGO_GATHER_GO(4, true); else LEGO_GATHER_GO(4, false); }
+#undef LEGO_GATHER_GO
         return check_launch("lego_gather_rows");
     }
     const long long total = (long long)rows_cap * (width / 4);

@@ -214,7 +214,12 @@ class Legommender(nn.Module):
             else:
                 clicks = self.get_item_content(batch, self.cm.history_col)
         else:
-            clicks = self.user_op.inputer.get_embeddings(batch[self.cm.history_col])
+            hist = batch[self.cm.history_col]
+            if isinstance(hist, torch.Tensor):                       # id-only batch: the sample the resampler's user inputer would have
+                m = batch[self.cm.mask_col].to(Env.device)           # built (resampler.py:222-226) -- ids, pads UNSET, the clicks mask
+                hist = {"input_ids": {self.cm.history_col: torch.where(m > 0, hist.to(Env.device).long(), torch.full_like(m, Env.UNSET).long())},
+                        "attention_mask": m}
+            clicks = self.user_op.inputer.get_embeddings(hist)
         return self.user_op(clicks, mask=batch[self.cm.mask_col].to(Env.device))
 
     # The reference pads every history to `max_click_num` slots with item 0 and ENCODES the pads (resampler.py:222-223; the
@@ -284,8 +289,14 @@ class Legommender(nn.Module):
             batch[self.cm.item_col] = batch[self.cm.item_col].unsqueeze(1)
         if self._one_call_ok(batch):
             item_embeddings, user_embeddings = self._encode_items_once(batch)
-        else:
+        elif self.config.use_item_content:
             item_embeddings = self.get_item_content(batch, self.cm.item_col)
+            user_embeddings = self.get_user_content(batch)
+        else:
+            # ID-based models (config/model/naml_id.yaml, legommender.py:237-248): no item operator -- a candidate is the embedding of
+            # its item id, looked up in the table of the HISTORY column's vocabulary; the clicked items go through the user inputer
+            vocab_name = self.config.user_ut.meta.features[self.cm.history_col].tokenizer.vocab.name
+            item_embeddings = self.eh(vocab_name, col_name=self.cm.history_col)(batch[self.cm.item_col].to(Env.device))
             user_embeddings = self.get_user_content(batch)
         if self.use_neg_sampling:
             scores = self._predict_for_neg_sampling(item_embeddings, user_embeddings)
@@ -307,7 +318,7 @@ class Legommender(nn.Module):
 
     def get_parameters(self) -> Tuple[List[nn.Parameter], List[nn.Parameter]]:
         pretrained, other = [], []
-        signals = self.item_op.get_pretrained_parameter_names()
+        signals = self.item_op.get_pretrained_parameter_names() if self.item_op is not None else []      # ID-based models have no item operator
         for name, param in self.named_parameters():
             if not param.requires_grad:
                 continue

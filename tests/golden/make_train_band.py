@@ -38,13 +38,21 @@ from legommenders_amd.synthetic import glove_table_np, init_naml_params, init_nr
 WORLD = dict(seed=0, n_items=1200, n_users=6000, n_rows=19200, V=3000, T=16, S=20, n_cat=18, neg_cap=20, p_pref=0.8,
              p_topic=0.5, pool=30, n_dev_users=4000, dev_neg=8)
 HYPER = dict(D=64, B=32, lr=1e-3, epochs=2, dropout=0.1, heads=8, K=4, glove_seed=77)
-# band name -> (model kind, overrides of HYPER, seeds)
+# band name -> (model kind, overrides of HYPER, seeds[, overrides of WORLD])
 BANDS = {
     "naml":      ("naml", dict(D=64, B=32, epochs=3), tuple(range(11, 27))),
     "nrms":      ("nrms", dict(D=64, B=32, epochs=10), tuple(range(11, 35))),      # 24 seeds: its seed std (0.003) is 3x NAML's
-    "naml_d256": ("naml", dict(D=256, B=64, epochs=3), tuple(range(11, 19))),
-    "nrms_d256": ("nrms", dict(D=256, B=64, epochs=5), tuple(range(11, 19))),
+    "naml_d256": ("naml", dict(D=256, B=64, epochs=3), tuple(range(11, 27))),      # round 5: 16 seeds at the headline width too
+    "nrms_d256": ("nrms", dict(D=256, B=64, epochs=5), tuple(range(11, 27))),
+    # round 5: a MIND-shaped world -- titles of up to 30 tokens, histories of up to 50 clicks (the bench's T / S), same generator
+    "naml_mind": ("naml", dict(D=64, B=32, epochs=2), tuple(range(11, 19)), dict(T=30, S=50)),
 }
+
+
+def band_world(band):
+    return dict(WORLD, **(BANDS[band][3] if len(BANDS[band]) > 3 else {}))
+
+
 METRICS = ["GAUC", "NDCG@10", "MRR"]
 CACHE = os.environ.get("LEGO_BAND_CACHE", "/tmp/lego_band_cache")     # one json per (band, seed): the generator is resumable
 
@@ -182,11 +190,11 @@ def run_seed(kind, w, seed):
 def one(band, seed):
     """one (band, seed) run in THIS process (single thread: eight of them side by side use the cores better than one
     eight-thread run of these small products); result -> CACHE/<band>_<seed>.json"""
-    kind, over, _ = BANDS[band]
+    kind, over = BANDS[band][:2]
     HYPER.update(over)
     MG.install_stubs()
     torch.set_num_threads(1)
-    w = make_learnable_world(**WORLD)
+    w = make_learnable_world(**band_world(band))
     t0 = time.time()
     init, r = run_seed(kind, w, seed)
     r["seconds"] = round(time.time() - t0, 1)
@@ -197,7 +205,7 @@ def one(band, seed):
 
 
 def assemble(band):
-    kind, over, seeds = BANDS[band]
+    kind, over, seeds = BANDS[band][:3]
     done = [json.load(open(os.path.join(CACHE, f"{band}_{s}.json"))) for s in seeds
             if os.path.exists(os.path.join(CACHE, f"{band}_{s}.json"))]
     if len(done) < len(seeds):
@@ -207,7 +215,7 @@ def assemble(band):
     for d in done:
         inits.update(d["init"])
     g = np.array([r["after"]["GAUC"] for r in runs])
-    out = dict(kind=kind, band=band, world=WORLD, hyper=dict(HYPER, **over, **inits), metrics=METRICS, runs=runs,
+    out = dict(kind=kind, band=band, world=band_world(band), hyper=dict(HYPER, **over, **inits), metrics=METRICS, runs=runs,
                init="legommenders_amd.synthetic.init_%s_params(D, A, V, n_cat, seed=run seed, glove=glove_table_np(glove_seed, V))" % kind,
                mean={m: float(np.mean([r["after"][m] for r in runs])) for m in METRICS},
                spread={m: float(np.max([r["after"][m] for r in runs]) - np.min([r["after"][m] for r in runs])) for m in METRICS},

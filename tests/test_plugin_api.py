@@ -99,6 +99,66 @@ def test_legommender_routes_match_reference(name, route):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nested", [False, True])
+def test_id_based_model_matches_reference(nested):
+    """`use_item_content: false` (config/model/naml_id.yaml; model/legommender.py:237-248, lego_config.py:120-192): no item operator,
+    candidates and clicked items are embeddings of their item ids, AdaOperator pools the history -- loss, every gradient (the
+    [n_items, D] id table included) and the test-phase logits against the fixture generated from the reference
+    (tests/golden/make_golden_id.py).  `nested`: the history as the reference's resampler ships it (the user inputer's nested sample,
+    pads UNSET) instead of an id tensor."""
+    from legommenders_amd.loader.class_hub import ClassHub
+    from legommenders_amd.loader.column_map import ColumnMap
+    from legommenders_amd.loader.embedding_hub import EmbeddingHub
+    from legommenders_amd.loader.env import Env
+    from legommenders_amd.loader.tables import Feature, Table, Vocab
+    from legommenders_amd.model.lego_config import LegoConfig
+    from legommenders_amd.model.legommender import Legommender
+    dev = torch.device("cuda:0")
+    meta, P, G, tables, batch, logits, loss = load_model_fixture("naml_id_d64")
+    assert meta["kind"] == "naml_id"
+    Env.set_device(dev)
+    D = meta["D"]
+    n_items = tables["title_tok"].shape[0]
+    item_v, user_v = Vocab("item_id", n_items), Vocab("user_id", tables["user_hist"].shape[0])
+    item_ut = Table([Feature("item_id", item_v), Feature("title@glove", Vocab("glove", meta["V"]), 30), Feature("category", Vocab("category", 18))],
+                    {"item_id": np.arange(n_items), "title@glove": (tables["title_tok"], tables["title_len"]), "category": tables["cat"]}, "item_id")
+    user_ut = Table([Feature("user_id", user_v), Feature("history", item_v, 50)],
+                    {"user_id": np.arange(user_v.size), "history": (tables["user_hist"], tables["user_hist_len"])}, "user_id")
+    ops, preds = ClassHub.operators(), ClassHub.predictors()
+    lc = LegoConfig(hidden_size=D, item_hidden_size=D, neg_count=4, use_item_content=False,
+                    user_config={"inputer_config": {"use_cls_token": False, "use_sep_token": False}})
+    lc.set_component_classes(None, ops["Ada"], preds["Dot"])
+    lc.set_item_ut(item_ut, ["title@glove", "category"])
+    lc.set_user_ut(user_ut, ["history"])
+    lc.set_column_map(ColumnMap(item_col="item_id", user_col="user_id", history_col="history", neg_col="neg", label_col="click", group_col="user_id"))
+    eh = EmbeddingHub(embedding_dim=D, transformation="auto", transformation_dropout=0.0)
+    eh.register_vocab(item_v)                                    # loader/manager.py:323-324
+    lc.set_embedding_hub(eh)
+    lc.build_components()
+    lc.register_inputer_vocabs()
+    assert lc.item_operator is None
+    model = Legommender(lc).to(dev)
+    assert set(P) == set(model.state_dict()), set(P) ^ set(model.state_dict())
+    model.load_state_dict({k: torch.tensor(v) for k, v in P.items()})
+    mask = (torch.arange(50)[None] < torch.tensor(batch["hist_len"])[:, None]).long()
+    hist = torch.tensor(batch["hist"])
+    if nested:
+        hist = {"input_ids": {"history": torch.where(mask > 0, hist, torch.full_like(hist, -1))}, "attention_mask": mask}
+    ids = {"item_id": torch.tensor(batch["cand"]), "history": hist, "__clicks_mask__": mask}
+    Env.train()
+    model.train()
+    out = model(batch=dict(ids))
+    assert abs(float(out) - loss) < 2e-5 * max(1.0, abs(loss))
+    out.backward()
+    _check_grads(model, G, "naml_id_d64")
+    Env.test()
+    model.eval()
+    with torch.no_grad():
+        scores = model(batch=dict(ids))
+    assert float(np.abs(scores.cpu().numpy() - logits).max()) < 1e-4 * max(1.0, float(np.abs(logits).max()))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["naml_glove_d64", "nrms_glove_d64"])
 def test_unfrozen_pretrained_table_matches_oracle(name):
     """`load_pretrained_embedding(..., frozen=False)` (loader/embedding_hub.py:171,262: the GloVe table fine-tunes): the plug-in

@@ -66,6 +66,30 @@ def test_trained_gauc_in_split_bf16_mode(name):
         _lib.set_product_mode(_lib.EXACT_F32)
 
 
+def _keep_report(name, band, seeds, report, runs):
+    """the measured means beside the reference's, kept as a file (they lived only in prose): merged into
+    $LEGO_BAND_REPORT, or gpurun_out/train_band_report.json when that directory exists (copied to profiles/r05_train_band.json)"""
+    from legommenders_amd import _lib
+    path = os.environ.get("LEGO_BAND_REPORT")
+    if path is None:
+        d = os.path.join(os.path.dirname(HERE), "gpurun_out")
+        if not os.path.isdir(d):
+            return
+        path = os.path.join(d, "train_band_report.json")
+    try:
+        out = json.load(open(path))
+    except (OSError, ValueError):
+        out = {}
+    key = name + ("" if _lib.product_mode() == _lib.EXACT_F32 else "@split_bf16")
+    out[key] = {"kind": band["kind"], "seeds": len(seeds), "hyper": {k: band["hyper"][k] for k in ("D", "B", "epochs")},
+                "world": {k: band["world"][k] for k in ("T", "S", "n_items", "n_users", "n_rows", "V", "n_dev_users")},
+                "metrics": {m: {"mi355x_mean": r[0], "reference_mean": r[1], "tolerance": r[2], "abs_diff": round(abs(r[0] - r[1]), 4),
+                                "reference_seed_std": round(float(band["std"][m]), 4)} for m, r in report.items()},
+                "mi355x_per_seed_GAUC": [round(float(a["GAUC"]), 4) for _, a, _ in runs],
+                "reference_per_seed_GAUC": [round(float(r["after"]["GAUC"]), 4) for r in band["runs"]]}
+    json.dump(out, open(path, "w"), indent=1, sort_keys=True)
+
+
 def _check_band(name):
     from legommenders_amd.synthetic import glove_table_np, make_learnable_world
     dev = torch.device("cuda:0")
@@ -93,6 +117,7 @@ def _check_band(name):
             # plateau the statistical slack on top of it stays below 0.002 (tol <= 0.004)
             assert tol <= 0.004 or len(seeds) < 16, (name, tol)
     print(name, "mean (hip, reference, tolerance):", report)
+    _keep_report(name, band, seeds, report, runs)
     # (2) training did what it did for the reference: clearly above chance and above the untrained model
     g_after = np.mean([a["GAUC"] for _, a, _ in runs])
     g_before = np.mean([b["GAUC"] for b, _, _ in runs])
