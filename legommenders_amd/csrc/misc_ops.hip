@@ -4,6 +4,7 @@
 // coalesced 16-B accesses, no MFMA.
 #include "../../include/lego_hip.h"
 #include <stdlib.h>
+#include <type_traits>
 #include "common.hpp"
 
 namespace lego {
@@ -521,20 +522,29 @@ __device__ __forceinline__ void atomic_add_row(float* out_row, int col0, int wid
         if (c < width) atomicAdd(out_row + c, v);
     }
 }
+__device__ __forceinline__ void atomic_add_row(float* out_row, int col0, int width, const float& acc, int lane) {
+    if (col0 + lane < width) atomicAdd(out_row + col0 + lane, acc);           // one column per lane: already 256 contiguous bytes
+}
 
+// VEC = columns per lane: 4 (a wave covers 256 columns of a row with one 16-byte load per lane) or 1 (64 columns, a dword per lane).
+// Round 5: VEC = 1 is the default -- the launch has R / 32 waves per column slice, and with 256-column slices that is ~840 waves for a
+// NAML batch (3 per CU: every wave waits out its two batches of 16 dependent-free row loads with nothing beside it); four times the
+// slices = four times the waves for the same loads, groups and atomics per column (LEGO_SEGSUM_VEC=4: the round-3 form).
+template <int VEC>
 __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float* __restrict__ g, int ld_g, int width, const int* __restrict__ perm,
                                                                const int* __restrict__ inv, const int* __restrict__ sorted_keys,
                                                                int R_cap, const int* __restrict__ R_dyn, float* out, int ld_out,
                                                                const uint8_t* __restrict__ keep_mask, float keep_scale,
                                                                const int* __restrict__ rowinfo) {
+    using V = std::conditional_t<VEC == 4, f32x4, float>;
     const int R = R_dyn != nullptr ? min(R_cap, *R_dyn) : R_cap;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     const int p0 = wave * kSegRows;
     if (p0 >= R) return;
     const int n = min(kSegRows, R - p0);
-    const int col0 = blockIdx.y * 256;
-    const int c = col0 + 4 * lane;
+    const int col0 = blockIdx.y * 64 * VEC;
+    const int c = col0 + VEC * lane;
     const bool in = c < width;
     // lanes 0 .. kSegRows + 1: position p0 - 1 + lane (one before and one past the chunk, for the two boundary decisions)
     const int pp = p0 - 1 + lane;
@@ -547,9 +557,9 @@ __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float* __re
     const int u_before = __shfl(my_u, 0, 64);                     // -1 when p0 == 0
     int cur = __shfl(my_u, 1, 64);
     bool began_here = cur != u_before;
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    V acc = V{};
     for (int b0 = 0; b0 < n; b0 += kSegBatch) {
-        f32x4 v[kSegBatch];
+        V v[kSegBatch];
         int uu[kSegBatch];
 #pragma unroll
         for (int j = 0; j < kSegBatch; ++j) {
@@ -558,11 +568,16 @@ __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float* __re
             uu[j] = __shfl(my_u, 1 + i, 64);
             const int live = __shfl(my_live, 1 + i, 64);                // by every lane: the source lane may have `in` == false
             const bool take = b0 + j < n && in && live != 0;            // a masked row adds nothing
-            v[j] = take ? *reinterpret_cast<const f32x4*>(g + (size_t)row * ld_g + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            v[j] = take ? *reinterpret_cast<const V*>(g + (size_t)row * ld_g + c) : V{};
             if (keep_mask != nullptr && take) {      // Dropout backward of the row: byte [(row / 4) * width + col], bit row % 4
-                const uint32_t kw = *reinterpret_cast<const uint32_t*>(keep_mask + (uint64_t)(row >> 2) * (uint64_t)width + (uint64_t)c);
+                if constexpr (VEC == 4) {
+                    const uint32_t kw = *reinterpret_cast<const uint32_t*>(keep_mask + (uint64_t)(row >> 2) * (uint64_t)width + (uint64_t)c);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[j][i] = (kw >> (8 * i + (row & 3))) & 1u ? v[j][i] * keep_scale : 0.f;
+                    for (int i2 = 0; i2 < 4; ++i2) v[j][i2] = (kw >> (8 * i2 + (row & 3))) & 1u ? v[j][i2] * keep_scale : 0.f;
+                } else {
+                    const uint32_t kb = keep_mask[(uint64_t)(row >> 2) * (uint64_t)width + (uint64_t)c];
+                    v[j] = (kb >> (row & 3)) & 1u ? v[j] * keep_scale : 0.f;
+                }
             }
         }
 #pragma unroll
@@ -570,9 +585,9 @@ __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float* __re
             if (b0 + j < n) {
                 if (uu[j] != cur) {                                // wave-uniform: the group ended inside the chunk
                     float* dst = out + (size_t)cur * ld_out;
-                    if (began_here) { if (in) *reinterpret_cast<f32x4*>(dst + c) = acc; }
+                    if (began_here) { if (in) *reinterpret_cast<V*>(dst + c) = acc; }
                     else atomic_add_row(dst, col0, width, acc, lane);
-                    acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                    acc = V{};
                     cur = uu[j];
                     began_here = true;
                 }
@@ -582,7 +597,7 @@ __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float* __re
     }
     const int u_after = __shfl(my_u, 1 + n, 64);                   // -1 past the end of the rows
     float* dst = out + (size_t)cur * ld_out;
-    if (began_here && (p0 + n >= R || u_after != cur)) { if (in) *reinterpret_cast<f32x4*>(dst + c) = acc; }
+    if (began_here && (p0 + n >= R || u_after != cur)) { if (in) *reinterpret_cast<V*>(dst + c) = acc; }
     else atomic_add_row(dst, col0, width, acc, lane);
 }
 
@@ -1759,8 +1774,13 @@ extern "C" int lego_segment_sum_rows(const float* g, int ld_g, int width, const 
         const long long tot = (long long)U_cap * (width / 4);
         hipLaunchKernelGGL(zero_rows_kernel, dim3((int)((tot + 255) / 256 < 2048 ? (tot + 255) / 256 : 2048)), dim3(256), 0, ST, out, ld_out, width, U_cap, U_dyn);
     }
-    hipLaunchKernelGGL(segment_sum_rows_kernel, dim3((R_cap + 4 * kSegRows - 1) / (4 * kSegRows), (width + 255) / 256), dim3(256), 0, ST, g, ld_g, width, perm, inv, sorted_keys, R_cap, R_dyn, out, ld_out,
-                       dropping ? dr.mask : (const uint8_t*)nullptr, dropping ? 1.f / (1.f - dr.p) : 1.f, rowinfo);
+    static int vec = -1;
+    if (vec < 0) { const char* v = getenv("LEGO_SEGSUM_VEC"); vec = (v != nullptr && v[0] == '4') ? 4 : 1; }
+    const dim3 gx((R_cap + 4 * kSegRows - 1) / (4 * kSegRows), (width + 64 * vec - 1) / (64 * vec));
+    const uint8_t* km = dropping ? dr.mask : (const uint8_t*)nullptr;
+    const float ks = dropping ? 1.f / (1.f - dr.p) : 1.f;
+    if (vec == 4) hipLaunchKernelGGL(segment_sum_rows_kernel<4>, gx, dim3(256), 0, ST, g, ld_g, width, perm, inv, sorted_keys, R_cap, R_dyn, out, ld_out, km, ks, rowinfo);
+    else hipLaunchKernelGGL(segment_sum_rows_kernel<1>, gx, dim3(256), 0, ST, g, ld_g, width, perm, inv, sorted_keys, R_cap, R_dyn, out, ld_out, km, ks, rowinfo);
     return check_launch("lego_segment_sum_rows");
 }
 
