@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LEGO_ABI_VERSION 6
+#define LEGO_ABI_VERSION 7
 #define LEGO_COUNTERS 8
 
 const char* lego_last_error(void);
@@ -101,6 +101,23 @@ int64_t lego_sort_rows_temp_bytes(int n);
 int lego_expand_rows(const float* src, int ld_src, const int32_t* inv, int rows_cap, const int32_t* rows_dyn, int width,
                      const lego_dropout* drop, const int32_t* rowinfo /*nullable*/, const float* add_a, int ld_a, const int32_t* idx_a,
                      const float* add_b, int ld_b, const int32_t* idx_b, float* out, int ld_out, void* stream);
+/* NRMS, GloVe projection (round 5, csrc/dropcorr_ops.hip): the attention in-projection of nn.MultiheadAttention
+ * (attention_operator.py:49-55) once per DISTINCT key with an exact sparse correction for the Dropout that embedding_hub.py:95-96
+ * puts in front of it.  qkvu[k,:] = Eu[k,:] W^T (no bias) over the distinct keys; wt = W^T, [D][N] row-major.  For a token row r
+ * (live bit of rowinfo[r]) of key k = inv[r]:  out[r,:] = s (qkvu[k,:] - sum over the coordinates c the site DROPPED in row r of
+ * eu[k,c] wt[c,:]) + bias,  s = 1 / (1 - p); for the other rows ([SEP] / category positions, no Dropout): out[r,:] = qkvu[k,:] + bias.
+ * drop NULL or p == 0: plain expansion.  The keep bits must be precomputed (lego_dropout_mask over [rows, D]).  D <= 256. */
+int lego_qkv_expand_dropcorr(const float* qkvu, int ldq, const float* eu, int lde, const float* wt, int ldw, const float* bias /*nullable*/,
+                             const int32_t* inv, const int32_t* rowinfo, const lego_dropout* drop /*nullable*/, int rows_cap,
+                             const int32_t* rows_dyn, int D, int N, float* out, int ldo, void* stream);
+/* ... its data gradient's correction: deu[inv[r], c] -= g[r,:] . wt[c,:] for every coordinate c dropped in token row r (float atomics);
+ * deu holds (sum over the key's rows of g) W on entry, and s is applied afterwards (lego_scale_mask_rows) */
+int lego_dropcorr_bwd(const float* g, int ldg, const float* wt, int ldw, const int32_t* inv, const int32_t* rowinfo,
+                      const lego_dropout* drop /*nullable*/, int rows_cap, const int32_t* rows_dyn, int D, int N, float* deu, int ldd,
+                      void* stream);
+/* x[r,:] = live_r ? scale * x[r,:] : 0 (live bit of rowinfo[r]) */
+int lego_scale_mask_rows(float* x, int ld, int rows_cap, const int32_t* rows_dyn, int width, const int32_t* rowinfo, float scale,
+                         void* stream);
 /* out[u,:] = sum over rows r with inv[r] == u of g[r,:] (u < U; perm = the rows grouped by inv): the per-token sums the
  * projection's weight gradient is formed from.  out[0:U] must be zero on entry: zero_first = 1 clears it here, 0 = the caller
  * has (lego_zero_rows, e.g. on another stream ahead of time). */

@@ -22,7 +22,7 @@ U64 = ctypes.c_uint64
 U32 = ctypes.c_uint32
 
 
-ABI_VERSION = 6      # == LEGO_ABI_VERSION of include/lego_hip.h this binding was written against
+ABI_VERSION = 7      # == LEGO_ABI_VERSION of include/lego_hip.h this binding was written against
 
 
 class LegoDropout(ctypes.Structure):
@@ -45,6 +45,9 @@ SIGNATURES = {
     "lego_unique_tokens": [P, I, P, I, P, U32, P, P, P, P, P, P, P, P, P, P],
     "lego_sort_rows": [P, I, P, P, P, I64, P],
     "lego_expand_rows": [P, I, P, I, P, I, P, P, P, I, P, P, I, P, P, I, P],
+    "lego_qkv_expand_dropcorr": [P, I, P, I, P, I, P, P, P, P, I, P, I, I, P, I, P],
+    "lego_dropcorr_bwd": [P, I, P, I, P, P, P, I, P, I, I, P, I, P],
+    "lego_scale_mask_rows": [P, I, I, P, I, P, F, P],
     "lego_segment_sum_rows": [P, I, I, P, P, I, P, P, P, I, I, P, I, P, P, P],
     "lego_zero_rows": [P, I, I, I, P, P],
     "lego_scatter_add_rows_range": [P, I, I, P, I, P, P, I, I, I, P],

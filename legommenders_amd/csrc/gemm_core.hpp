@@ -187,6 +187,7 @@ struct GemmDims {
     const int* m_dyn;       // optional device scalar overriding M (NT/NN) ...
     const int* k_dyn;       // ... or K (TN: reduction over the dynamic row count)
     int split_k;            // TN only: gridDim.z / taps
+    int abl = 0;            // tuning build only (LEGO_DMA_ABL): ablation bits of the LDS-DMA row-strip kernel, see gemm_dma.hpp
 };
 
 template <class Cfg, bool A_MC, bool B_MC, class ALoad, class BLoad, class Epi, bool SPLIT = false>

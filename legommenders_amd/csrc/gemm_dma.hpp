@@ -25,6 +25,12 @@
 
 namespace lego {
 
+#ifdef LEGO_TUNING_HOOKS
+#define LEGO_DMA_ABL_OF(d) ((d).abl)
+#else
+#define LEGO_DMA_ABL_OF(d) 0          // the product kernel has no ablation branches
+#endif
+
 #ifndef DMA_PIN
 #define DMA_PIN 3
 #endif
@@ -49,7 +55,8 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_dst_uniform) {
 // 4 x 4 (ONE wave per SIMD with up to 512 registers: half the LDS fragment reads per MFMA, a 4-wave barrier, no partner wave to
 // arbitrate the matrix pipe with -- and none to hide a stall behind)
 template <int NF, bool B_MC, int NW, class BLoad, class Epi>
-__device__ __forceinline__ void dma_pass(const KcRows& la, const BLoad& lb, Epi& epi, char* lds, int m0, int m_end, int n0, int K) {
+__device__ __forceinline__ void dma_pass(const KcRows& la, const BLoad& lb, Epi& epi, char* lds, int m0, int m_end, int n0, int K, int abl = 0) {
+    // abl (tuning build, LEGO_DMA_ABL): 1 no DMA in the loop, 4 no wait / barrier in the loop, 8 no epilogue, 32 no MFMAs -- timing only
     constexpr int STAGE = dma_stage_bytes<B_MC>();
     constexpr int CF = 16 / NW, AI = 16 / NW, BI = 32 / NW;     // column fragments per wave; glds per wave and tile for A / B
     static_assert(NW == 4 || NW == 8, "8 x 2 or 4 x 4 waves x column fragments");
@@ -122,6 +129,15 @@ __device__ __forceinline__ void dma_pass(const KcRows& la, const BLoad& lb, Epi&
         for (int b = 0; b < CF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 fa0[NF], fb0[CF], fa1[NF], fb1[CF];
     auto mfma_j = [&](const f32x4 (&fa)[NF], const f32x4 (&fb)[CF], int j) {
+#ifdef LEGO_TUNING_HOOKS
+        if (abl & 32) {
+#pragma unroll
+            for (int a = 0; a < NF; ++a)
+#pragma unroll
+                for (int b = 0; b < CF; ++b) asm volatile("" : "+v"(acc[a][b]) : "v"(fa[a][j]), "v"(fb[b][j]));
+            return;
+        }
+#endif
 #pragma unroll
         for (int a = 0; a < NF; ++a)
 #pragma unroll
@@ -149,7 +165,7 @@ __device__ __forceinline__ void dma_pass(const KcRows& la, const BLoad& lb, Epi&
     read_frags(0, 0, fa0, fb0);
     int sc = 0, sn = 2;                                     // stage of tile t, stage of tile t + 2
     auto body = [&](int t) {
-        if (t + 2 < T) issue(t + 2, sn);
+        if (t + 2 < T && !(abl & 1)) issue(t + 2, sn);
         read_frags(sc, 1, fa1, fb1);
         if (DMA_PIN & 1) __builtin_amdgcn_sched_barrier(0);   // F1's reads go out BEFORE the F0 MFMAs (left alone, hipcc sinks them
                                                                // behind 38 MFMAs and then waits lgkmcnt(0) right behind each group)
@@ -165,7 +181,8 @@ __device__ __forceinline__ void dma_pass(const KcRows& la, const BLoad& lb, Epi&
 #pragma unroll
         for (int j = 0; j < 3; ++j) mfma_j(fa1, fb1, j);
         if (t + 1 < T) {
-            if (t + 2 < T) wait_one_in_flight();
+            if (abl & 5) { if (!(abl & 4)) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); }
+            else if (t + 2 < T) wait_one_in_flight();
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             const int s1 = sc == 2 ? 0 : sc + 1;
             read_frags(s1, 0, fa0, fb0);
@@ -178,6 +195,14 @@ __device__ __forceinline__ void dma_pass(const KcRows& la, const BLoad& lb, Epi&
     for (int t = 0; t < T; ++t) body(t);
     asm volatile("s_barrier" ::: "memory");                // every DMA has landed (vmcnt(0) above) and every wave has read its last
                                                             // fragments: the stages are free for the epilogue's row tiles
+    if (abl & 8) {
+#pragma unroll
+        for (int a = 0; a < NF; ++a)
+#pragma unroll
+            for (int b = 0; b < CF; ++b) asm volatile("" :: "v"(acc[a][b]));
+        asm volatile("s_barrier" ::: "memory");
+        return;
+    }
     const bool rows_form = epi.rows_form_ok();
     float* tile = reinterpret_cast<float*>(lds) + wave * (NF * 16 * 32);
     auto slab = [&](auto hh) {                               // one 32-column slab of the wave's columns
@@ -224,10 +249,10 @@ __global__ __launch_bounds__(NW * 64) void dma_strip_kernel(GemmDims dims, KcRow
         const int m_end = min(strip_end, m0 + sp.sub);
         const int nf = (m_end - m0 + 15) >> 4;              // block-uniform
         switch (nf) {
-            case 1: case 2: dma_pass<2, B_MC, NW>(la, lb, epi, lds, m0, m_end, n0, K); break;
-            case 3: case 4: dma_pass<4, B_MC, NW>(la, lb, epi, lds, m0, m_end, n0, K); break;
-            case 5: case 6: dma_pass<6, B_MC, NW>(la, lb, epi, lds, m0, m_end, n0, K); break;
-            default: dma_pass<7, B_MC, NW>(la, lb, epi, lds, m0, m_end, n0, K); break;
+            case 1: case 2: dma_pass<2, B_MC, NW>(la, lb, epi, lds, m0, m_end, n0, K, LEGO_DMA_ABL_OF(dims)); break;
+            case 3: case 4: dma_pass<4, B_MC, NW>(la, lb, epi, lds, m0, m_end, n0, K, LEGO_DMA_ABL_OF(dims)); break;
+            case 5: case 6: dma_pass<6, B_MC, NW>(la, lb, epi, lds, m0, m_end, n0, K, LEGO_DMA_ABL_OF(dims)); break;
+            default: dma_pass<7, B_MC, NW>(la, lb, epi, lds, m0, m_end, n0, K, LEGO_DMA_ABL_OF(dims)); break;
         }
     }
 }

@@ -132,6 +132,13 @@ static int launch_dma_strip(const GemmDims& d, const KcRows& a, const BL& b, con
         if (dma_waves() == 4) return launch_dma_strip<B_MC, EK, BL, 4>(d, a, b, e0, st, what);
     EK e;
     static_cast<EpiArgs&>(e) = e0;
+#ifdef LEGO_TUNING_HOOKS
+    GemmDims dd = d;
+    { static int abl = -1; if (abl < 0) { const char* v = getenv("LEGO_DMA_ABL"); abl = v != nullptr ? atoi(v) : 0; } dd.abl = abl; }
+    const GemmDims& d_ = dd;
+#else
+    const GemmDims& d_ = d;
+#endif
     auto k = dma_strip_kernel<B_MC, NW, BL, EK>;
     constexpr size_t lds = dma_lds_bytes<B_MC>();
     static bool attr_done = false;
@@ -140,7 +147,7 @@ static int launch_dma_strip(const GemmDims& d, const KcRows& a, const BL& b, con
         attr_done = true;
     }
     const int n_panels = (d.N + STRIP_BN - 1) / STRIP_BN;
-    hipLaunchKernelGGL(k, dim3(num_cus() / n_panels * n_panels), dim3(NW * 64), lds, st, d, a, b, e);
+    hipLaunchKernelGGL(k, dim3(num_cus() / n_panels * n_panels), dim3(NW * 64), lds, st, d_, a, b, e);
     return check_launch(what);
 }
 

@@ -15,17 +15,22 @@ static int tnd_num_cus() {
     return n;
 }
 
-// LEGO_TND: 0 = the tile kernels of gemm_tn.hpp (default), 1 = tnd_kernel for plain-row weight gradients (opt-in: see DESIGN.md section 5);
+// LEGO_TND: 0 = the tile kernels of gemm_tn.hpp everywhere, 1 (default) = tnd_kernel for plain-row weight gradients whose OUTPUT has
+// LEGO_TND_MIN_NK <= M N <= LEGO_TND_MAX_NK elements (defaults 128 K .. 1 M).  Measured (tools/tnd_check.py, profiles/r05_tnd.txt):
+// 768 x 256 over 30.7 k rows (NRMS in-projection) 135 -> 106-125 us, 768 x 768 over 29.6 k (BERT) 318 -> 265-288 us, NRMS step
+// 1.048 -> 1.020 ms; the 256 x 256 / 256 x 300 gradients of NAML are 15-20 % faster alone (45 -> 37 us) but the step is not (its
+// side-stream launches then hold every CU's registers and LDS while the main stream's next kernel waits): they keep the tile kernels;
+// 3072 x 768 (BERT FFN) is 6 % slower (the 64 x 64 wave tiles re-read the operands 48 x 12 times from L2).
 // LEGO_TND_WGS = workgroups aimed at (default 2 per CU), LEGO_TND_MIN_ROWS = smallest reduction it takes
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e != nullptr ? atoi(e) : dflt; }
-int tnd_mode() { static int v = -1; if (v < 0) v = env_int("LEGO_TND", 0); return v; }
+int tnd_mode() { static int v = -1; if (v < 0) v = env_int("LEGO_TND", 1); return v; }
 
 bool tnd_ok(int M, int N, int K_cap, int lda, int ldb, int ldc) {
-    static int min_rows = -1;
+    static int min_rows = -1, max_nk = -1, min_nk = -1;
     if (min_rows < 0) min_rows = env_int("LEGO_TND_MIN_ROWS", 2048);
-    static int max_nk = -1;
-    if (max_nk < 0) max_nk = env_int("LEGO_TND_MAX_NK", 1 << 30);
-    if (tnd_mode() == 0 || K_cap < min_rows || M < 4 || N < 4 || (long long)M * N > max_nk) return false;
+    if (max_nk < 0) max_nk = env_int("LEGO_TND_MAX_NK", 1 << 20);
+    if (min_nk < 0) min_nk = env_int("LEGO_TND_MIN_NK", 1 << 17);
+    if (tnd_mode() == 0 || K_cap < min_rows || M < 4 || N < 4 || (long long)M * N > max_nk || (long long)M * N < min_nk) return false;
     if ((lda & 3) || (ldb & 3) || (M & 3) || (N & 3)) return false;
     const unsigned long long lim = 0x7FFF0000ull;          // 32-bit byte offsets, with room for the ring's reads past the range
     return ((unsigned long long)K_cap + 64) * (unsigned long long)lda * 4ull < lim && ((unsigned long long)K_cap + 64) * (unsigned long long)ldb * 4ull < lim;

@@ -821,6 +821,40 @@ class NrmsEngine(_Base):
             self.QKVu = self._f(self.Uc, 3 * D)
             self.dQKVu = self._f(self.Uc, 3 * D)
             self._kconst = {k: torch.tensor(k, **i32) for k in (-1, 0, 2, RI_LIVE_BIT)}
+        # GloVe projection, round 5: the same per-key in-projection WITH the Dropout that sits between the projection and the attention
+        # (embedding_hub.py:95-96): a token row is s (m_r . h_k), so W E_r = s (W h_k - sum over the dropped coordinates c of h_k[c] W[:, c])
+        # -- the per-key product plus ~26 multiply-adds of a 3D-vector per row (csrc/dropcorr_ops.hip); the data gradient splits the same
+        # way.  The weight gradient stays the dense product over the rows (its correction is a 10 %-dense sparse product), so the row
+        # embeddings E are still expanded -- on the side stream, for the backward pass only.  Needs the site's keep bits ahead of time
+        # (TrainStep draws them with the plan); a step without them, or LEGO_NRMS_DROPCORR=0, runs the in-projection row by row.
+        self.dropcorr = self.dedup and glove and D <= 256 and os.environ.get("LEGO_NRMS_DROPCORR", "1") != "0"
+        # the backward pass of that form (per-key sums of d(qkv), a product over the keys, lego_dropcorr_bwd) is opt-in: measured, its three
+        # launches cost more than the row-by-row data gradient they replace, so by default only the FORWARD
+        # in-projection runs per key and the backward pass is the row form over the same key space
+        self.dropcorr_bwd = self.dropcorr and os.environ.get("LEGO_NRMS_DROPCORR_BWD", "0") == "1"
+        if self.dropcorr:
+            n_cat = P["embedding_vocab_table.category.weight"].shape[0]
+            self.Vk = self.V + 1 + n_cat
+            self.Uc = min(self.Rc, self.Vk)
+            self.uq_stamp = torch.zeros(self.Vk, **i32)
+            self.uq_rank = torch.zeros(self.Vk, **i32)
+            self.uq_bsum = torch.zeros((self.Vk + 1023) // 1024 + 1, **i32)
+            self.uq_cnt = torch.zeros(self.Uc + 1, **i32)
+            self.uq_start = torch.zeros(self.Uc + 1, **i32)
+            self.uniq = torch.zeros(self.Uc, **i32)
+            self.row_key = torch.zeros(self.Rc, **i32)
+            self.idx_tok_u, self.idx_spec_u = torch.zeros(self.Uc, **i32), torch.zeros(self.Uc, **i32)
+            self.idx_cat_u, self.tokinfo_u = torch.zeros(self.Uc, **i32), torch.zeros(self.Uc, **i32)
+            self.Xu = self._f(self.Uc, self.E0)
+            self.Hu = self._f(self.Uc, D)
+            self.dHu = self._f(self.Uc, D)                              # d(Eu): per-key gradient rows
+            self.Eu = self._f(self.Uc, D)
+            self.QKVu = self._f(self.Uc, 3 * D)
+            self.dQKVu = self._f(self.Uc, 3 * D)
+            self.WinT = self._f(D, 3 * D)
+            self.iota_u = torch.arange(self.Uc, **i32)
+            self._kconst = {k: torch.tensor(k, **i32) for k in (-1, 0, 2, RI_LIVE_BIT)}
+        self.keyspace = self.qkv_dedup or self.dropcorr
         self.X = (self._f(1, self.E0) if self.dedup else self._f(self.Rc, self.E0)) if glove else None
         self.E = self._f(self.Rc, D)
         self.dE = self._f(self.Rc, D)
@@ -844,7 +878,7 @@ class NrmsEngine(_Base):
         if getattr(self, "_slots", None) is None and (self.glove or self.dedup):
             self._PLAN_FIELDS = NrmsEngine._PLAN_FIELDS + (
                 (("Xu", "mask_proj") if self.glove else ()) + ("uniq", "inv", "perm", "keys_sorted", "dHu") if self.dedup else ("X",)) + (
-                ("idx_tok_u", "idx_spec_u", "idx_cat_u", "tokinfo_u") if self.qkv_dedup else ())
+                ("idx_tok_u", "idx_spec_u", "idx_cat_u", "tokinfo_u") if self.keyspace else ())
         return super().enable_plan_slots()
 
     def prefetch_masks(self, stream, slot):
@@ -865,6 +899,8 @@ class NrmsEngine(_Base):
 
     _dhu_zeroed = False
     _cur_slot = None
+    _dc_active = False
+    _dc_drop = None
 
     def _dhu_consumed(self):
         """backward has added into dHu: the current slot's rows are not clean any more"""
@@ -902,20 +938,14 @@ class NrmsEngine(_Base):
             self._uq_epoch = self._uq_epoch % 0x7FFFFFF0 + 1
             self._uq_begin(stream)
             keys, nkeys = b["row_tok"], self.V
-            if self.qkv_dedup:                       # every position gets a key >= 0: tokens as they are, [SEP] (-2) -> V, category -(3+c) -> V+1+c
+            if self.keyspace:                        # every position gets a key >= 0: tokens as they are, [SEP] (-2) -> V, category -(3+c) -> V+1+c
                 with torch.cuda.stream(stream):
                     torch.where(b["row_tok"] >= 0, b["row_tok"], (self.V - 2) - b["row_tok"], out=self.row_key)
                 keys, nkeys = self.row_key, self.Vk
             call("lego_unique_tokens", _ptr(keys), self.Rc, _ptr(b["counters"], 0), nkeys, _ptr(self.uq_stamp), self._uq_epoch,
                  _ptr(self.uq_rank), _ptr(self.uq_bsum), _ptr(b["uniq"]), _ptr(b["inv"]), _ptr(self.uq_cnt), _ptr(self.uq_start), None,
                  _ptr(self.uq_keys), _ptr(b["counters"], 6), st)
-            if self.glove:
-                call("lego_gather_rows", _ptr(self.P["embedding_vocab_table.glove.embedding.weight"]), E0, E0, _ptr(b["uniq"]),
-                     self.Uc, _ptr(b["counters"], 6), _ptr(b["Xu"]), E0, 0, st)
-            call("lego_sort_rows", _ptr(self.uq_keys), self.Rc, _ptr(b["keys_sorted"]), _ptr(b["perm"]), _ptr(self.uq_temp),
-                 self.uq_temp.numel(), st)
-            self._uq_end(stream)
-            if self.qkv_dedup:                       # the distinct keys back into per-table row indices (-1 = not this table's)
+            if self.keyspace:                        # the distinct keys back into per-table row indices (-1 = not this table's)
                 with torch.cuda.stream(stream):
                     u, V = b["uniq"], self.V
                     c = self._kconst
@@ -923,6 +953,14 @@ class NrmsEngine(_Base):
                     torch.where(u == V, c[2], c[-1], out=b["idx_spec_u"])             # [SEP] = id 2 of the special vocabulary
                     torch.where(u > V, u - (V + 1), c[-1], out=b["idx_cat_u"])
                     torch.where(u < V, c[RI_LIVE_BIT], c[0], out=b["tokinfo_u"])
+            if self.glove:                           # table rows of the distinct tokens (key space: zero rows for the [SEP] / category keys)
+                call("lego_gather_rows", _ptr(self.P["embedding_vocab_table.glove.embedding.weight"]), E0, E0,
+                     _ptr(b["idx_tok_u"] if self.keyspace else b["uniq"]), self.Uc, _ptr(b["counters"], 6), _ptr(b["Xu"]), E0, 0, st)
+            call("lego_sort_rows", _ptr(self.uq_keys), self.Rc, _ptr(b["keys_sorted"]), _ptr(b["perm"]), _ptr(self.uq_temp),
+                 self.uq_temp.numel(), st)
+            self._uq_end(stream)
+            if self.keyspace:
+                pass
             elif b is not self.__dict__:             # a plan slot: its per-token sums start from rows cleared here, off the main stream
                 call("lego_zero_rows", _ptr(b["dHu"]), self.D, self.D, self.Uc, _ptr(b["counters"], 6), st)
         elif self.glove:
@@ -966,7 +1004,13 @@ class NrmsEngine(_Base):
         Wo, bo = P[pre + "multi_head_attention.out_proj.weight"], P[pre + "multi_head_attention.out_proj.bias"]
         Wl, bl = P[pre + "linear.weight"], P[pre + "linear.bias"]
         w2 = P[pre + "additive_attention.encoder.2.weight"]
-        if per_key:                                  # x_ptr = Eu [U, D]: project the distinct keys, expand q|k|v to the sequence rows
+        if per_key == "dropcorr":                    # x_ptr = Eu [U, D]: q|k|v of the distinct keys (no bias), then the rows with the
+            self.kk(m, "qkv_fwd_" + tg, "lego_linear_fwd", x_ptr, D, _ptr(P[pre + "multi_head_attention.in_proj_weight"]), D,     # sparse Dropout correction
+                    None, _ptr(self.QKVu), 3 * D, self.Uc, self.cnt(6), 3 * D, D, 0, None, None, None, None)
+            self.kk(m, "qkv_expand_" + tg, "lego_qkv_expand_dropcorr", _ptr(self.QKVu), 3 * D, x_ptr, D, _ptr(self.WinT), 3 * D,
+                    _ptr(P[pre + "multi_head_attention.in_proj_bias"]), _ptr(self.inv), _ptr(self.tokinfo), self._dc_drop, rows, rows_dyn,
+                    D, 3 * D, _ptr(ws["qkv"]), 3 * D)
+        elif per_key:                                # x_ptr = Eu [U, D]: project the distinct keys, expand q|k|v to the sequence rows
             self.kk(m, "qkv_fwd_" + tg, "lego_linear_fwd", x_ptr, D, _ptr(P[pre + "multi_head_attention.in_proj_weight"]), D,
                     _ptr(P[pre + "multi_head_attention.in_proj_bias"]), _ptr(self.QKVu), 3 * D, self.Uc, self.cnt(6), 3 * D, D, 0,
                     None, None, None, None)
@@ -1092,6 +1136,29 @@ class NrmsEngine(_Base):
                 self.drop(self.p_att, site, training), rows, _ptr(ws["d_qkv"]), 3 * D,
                 _ptr(G[pre + "multi_head_attention.in_proj_bias"]))      # bias gradient = column sums of d_qkv, fused
         self.kk(m, "mhsa_core_bwd_" + pre[:4], *core, *self._part(pre, ws))
+        if per_key == "dropcorr":
+            # data gradient per key: dEu = (sum over the key's rows of d(qkv)) W_in, minus the dropped coordinates' share row by row;
+            # weight gradient: the dense product over the rows, d(qkv)^T E, on the side stream (E: expanded there in the forward pass)
+            W_in = P[pre + "multi_head_attention.in_proj_weight"]
+            self.kk(m, "qkv_bwd_segsum", "lego_segment_sum_rows", _ptr(ws["d_qkv"]), 3 * D, 3 * D, _ptr(self.perm), _ptr(self.inv), rows,
+                    _ptr(self.keys_sorted), rows_dyn, _ptr(self.dQKVu), 3 * D, self.Uc, self.cnt(6), 1, None, None)
+            if sw is not m:
+                ev[1].record(m)                      # (d_qkv is final since the attention core)
+
+            def side2d():
+                if sw is not m:
+                    sw.wait_event(ev[1])
+                call("lego_linear_bwd_weight", _ptr(ws["d_qkv"]), 3 * D, _ptr(self.E), D,
+                     _ptr(G[pre + "multi_head_attention.in_proj_weight"]), D, rows, rows_dyn, 3 * D, D, None, None, sp)
+            if self.fold == 2:
+                self._deferred.append(side2d)
+            else:
+                side2d()
+            self.kk(m, "qkv_bwd_data", "lego_linear_bwd_data", _ptr(self.dQKVu), 3 * D, _ptr(W_in), D, dx_ptr, D, self.Uc, self.cnt(6), 3 * D, D, 0,
+                    None, 0, 1.0, None, None, None, None, None)
+            self.kk(m, "qkv_bwd_dropcorr", "lego_dropcorr_bwd", _ptr(ws["d_qkv"]), 3 * D, _ptr(self.WinT), 3 * D, _ptr(self.inv), _ptr(self.tokinfo),
+                    self._dc_drop, rows, rows_dyn, D, 3 * D, dx_ptr, D)
+            return
         if per_key:
             # d(qkv) summed per distinct key, then both products of the in-projection's backward over the ~4.5 k keys instead of the
             # ~31 k sequence rows: dW_in = dQKVu^T Eu (side stream), dEu = dQKVu W_in (x_ptr = Eu, dx_ptr = dEu)
@@ -1312,6 +1379,36 @@ class NrmsEngine(_Base):
         self._folds_fresh = True
         if not (planned and getattr(self, "_slots", None) is not None):      # else: done with the plan (plan_on)
             self._decode_gather(self.__dict__, current_stream())
+        self._dc_active = False
+        dp = self.drop(self.p_proj, SITE_PROJ, training) if self.dropcorr else None
+        if self.dropcorr and (dp is None or self._mask_step == self.step):        # (keep bits drawn ahead of time, or nothing to drop)
+            E0 = self.E0
+            spec, catw = P["embedding_vocab_table.__cat_inputer_special_ids.weight"], P["embedding_vocab_table.category.weight"]
+            m, sw = self._side()
+            if dp is not None:                       # W_in^T for the two correction kernels (768 KB, once per step)
+                with torch.cuda.stream(m):
+                    self.WinT.copy_(P["item_op.multi_head_attention.in_proj_weight"].t())
+            # Hu = projection of the distinct TOKEN keys ([SEP] / category keys: zero rows of Xu, masked next) ...
+            call("lego_linear_fwd", _ptr(self.Xu), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
+                 _ptr(P["embedding_vocab_table.glove.linear.bias"]), _ptr(self.Hu), D, self.Uc, self.cnt(6), D, E0, 0,
+                 None, None, None, None, st)
+            # ... Eu[k] = the ONE live look-up of key k: the token's projection, or the [SEP] / category row (identity expansion)
+            call("lego_expand_rows", _ptr(self.Hu), D, _ptr(self.iota_u), self.Uc, self.cnt(6), D, None, _ptr(self.tokinfo_u),
+                 _ptr(spec), D, _ptr(self.idx_spec_u), _ptr(catw), D, _ptr(self.idx_cat_u), _ptr(self.Eu), D, st)
+            if training:
+                # the row embeddings E (Dropout applied per row) are needed by the in-projection's WEIGHT gradient only: side stream
+                if sw is not m:
+                    self._sev[8].record(m)
+                    sw.wait_event(self._sev[8])
+                call("lego_expand_rows", _ptr(self.Eu), D, _ptr(self.inv), self.Rc, self.cnt(0), D, dp, _ptr(self.tokinfo),
+                     _ptr(spec), D, _ptr(self.idx_spec), _ptr(catw), D, _ptr(self.idx_cat), _ptr(self.E), D, stream_handle(sw))
+            self._dc_active = True
+            self._dc_drop = dp
+            self._att_fwd("item_op.", self.item_ws, _ptr(self.Eu), self.cnt(0), self.seg_off, self.NIc, self.cnt(1),
+                          self.items, SITE_ITEM_ATT, training, st, per_key="dropcorr")
+            return
+        # (a training step whose keep bits were NOT drawn with the plan falls through to the row-by-row in-projection below: the key space
+        # serves it too -- the [SEP] / category keys have zero rows in Xu and the live bit of tokinfo masks their rows)
         if self.glove and self.dedup:
             E0 = self.E0
             call("lego_linear_fwd", _ptr(self.Xu), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
@@ -1397,6 +1494,28 @@ class NrmsEngine(_Base):
             # the data gradient of the in-projection lands in dE already masked + dropout-scaled, with the projection's bias gradient as
             # its column sums (one epilogue instead of two more passes over dE: 20 + 18-26 us of the main stream's tail)
             epi = (_ptr(self.tokinfo), self.drop(self.p_proj, SITE_PROJ, training), _ptr(G["embedding_vocab_table.glove.linear.bias"]))
+        if self.dropcorr_bwd and self._dc_active:
+            E0 = self.E0
+            self._att_bwd("item_op.", self.item_ws, G, _ptr(self.Eu), _ptr(self.dHu), self.cnt(0), self.seg_off, self.NIc,
+                          self.cnt(1), self.d_items, SITE_ITEM_ATT, training, st, sev[2:4], per_key="dropcorr")
+            # dHu = d(Eu): the [SEP] / category keys' rows are those tables' gradients (one key per table row) ...
+            call("lego_scatter_add_rows_range", _ptr(g_spec), D, D, _ptr(self.idx_spec_u), self.Uc, self.cnt(6), _ptr(self.dHu), D, 0, 3, st)
+            call("lego_scatter_add_rows_range", _ptr(g_cat), D, D, _ptr(self.idx_cat_u), self.Uc, self.cnt(6), _ptr(self.dHu), D, 0, n_cat, st)
+            # ... the token keys' rows, times the Dropout's 1 / (1 - p), go on into the projection: bias = column sums, weight = dHu^T Xu
+            dp = self._dc_drop
+            call("lego_scale_mask_rows", _ptr(self.dHu), D, self.Uc, self.cnt(6), D, _ptr(self.tokinfo_u),
+                 1.0 / (1.0 - self.p_proj) if dp is not None else 1.0, st)
+            call("lego_colsum", _ptr(self.dHu), D, self.Uc, self.cnt(6), None, D, _ptr(G["embedding_vocab_table.glove.linear.bias"]), st)
+            self.kk(m, "proj_bwd_weight", "lego_linear_bwd_weight", _ptr(self.dHu), D, _ptr(self.Xu), E0,
+                    _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Uc, self.cnt(6), D, E0, None, None)
+            for side in self._deferred:
+                side()
+            self._deferred = ()
+            if sw is not m:
+                sev[4].record(sw)
+                m.wait_event(sev[4])
+            self.step = step_save
+            return
         if self.qkv_dedup:
             self._att_bwd("item_op.", self.item_ws, G, _ptr(self.Eu), _ptr(self.dHu), self.cnt(0), self.seg_off, self.NIc,
                           self.cnt(1), self.d_items, SITE_ITEM_ATT, training, st, sev[2:4], per_key=True)

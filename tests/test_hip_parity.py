@@ -72,6 +72,33 @@ def test_linear_family_matches_torch():
             _close(dW.cpu(), gy.T @ x, what=f"linear_bwd_weight {M}x{N}x{Kd}")
 
 
+@pytest.mark.parametrize("R,cap,N,K,ldg,ldx,off", [(8300, 8300, 768, 256, 768, 256, False), (4097, 105600, 512, 260, 520, 264, True),
+                                                     (2049, 2600, 1024, 128, 1024, 128, False), (1, 4000, 768, 256, 768, 256, False)])
+def test_weight_gradient_without_lds_staging(R, cap, N, K, ldg, ldx, off):
+    """lego_linear_bwd_weight on outputs of 128 K .. 1 M elements takes the round-5 kernel (csrc/gemm_tnd.hpp: operand fragments straight
+    from global memory, eight k sub-ranges summed in LDS per workgroup): against a float64 product, with a live row count below the
+    capacity the launch is sized for, a device row offset, padded rows and NaN behind the live rows (nothing past them may be read as data)"""
+    import ctypes
+    from legommenders_amd._lib import call
+    dev = _dev()
+    g_ = torch.Generator().manual_seed(R + N)
+    goff = 5 if off else 0
+
+    def P(t, o=0):
+        return None if t is None else ctypes.c_void_p(t.data_ptr() + o * t.element_size())
+    g = torch.randn(cap + goff + 1, ldg, generator=g_).to(dev)
+    x = torch.randn(cap + 1, ldx, generator=g_).to(dev)
+    g[goff + R:] = float("nan")
+    x[R:] = float("nan")
+    dW = torch.randn(N, K, generator=g_).to(dev)
+    ref = dW.double() + g[goff:goff + R, :N].double().T @ x[:R, :K].double()
+    cnt = torch.tensor([R, goff], dtype=torch.int32, device=dev)
+    call("lego_linear_bwd_weight", P(g), ldg, P(x), ldx, P(dW), K, cap, P(cnt, 0), N, K, P(cnt, 1) if off else None, None, None)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(dW).all())
+    _close(dW.cpu(), ref.float().cpu(), rtol=2e-5, what=f"weight gradient {R}/{cap} x {N} x {K}")
+
+
 def test_conv3_matches_torch_conv1d():
     from legommenders_amd import kernels as K
     dev = _dev()
@@ -1253,12 +1280,18 @@ def test_nrms_projection_once_per_distinct_token(planned, glove, monkeypatch):
                         (rs.randint(0, w["n_items"], size=(B, C)), w["user_hist"][users], np.maximum(w["user_hist_len"][users], 1))])
     out = {}
     # forms: row by row / per distinct token (projection, table gradient) / -- trainable table only -- the in-projection per distinct KEY
-    forms = [("0", "0"), ("1", "0")] + ([] if glove else [("1", "1")])
+    # (GloVe, round 5: "1", "2" = the in-projection per distinct key WITH the sparse Dropout correction -- csrc/dropcorr_ops.hip -- which the
+    # planned form takes; the un-planned form has no keep bits ahead of time and falls back to the row-by-row product in the key space)
+    # "3" = "2" plus the per-key backward pass (opt-in, LEGO_NRMS_DROPCORR_BWD=1)
+    forms = [("0", "0"), ("1", "0")] + ([("1", "2"), ("1", "3")] if glove else [("1", "1")])
     for dedup, per_key in forms:
         monkeypatch.setenv("LEGO_NRMS_DEDUP", dedup)
-        monkeypatch.setenv("LEGO_NRMS_QKV_DEDUP", per_key)
+        monkeypatch.setenv("LEGO_NRMS_QKV_DEDUP", "1" if per_key == "1" else "0")
+        monkeypatch.setenv("LEGO_NRMS_DROPCORR", "1" if per_key in ("2", "3") else "0")
+        monkeypatch.setenv("LEGO_NRMS_DROPCORR_BWD", "1" if per_key == "3" else "0")
         eng = E.NrmsEngine(Pd, tb, B, C, S, heads=8, glove=glove, seed=77)
-        assert eng.dedup == (dedup == "1") and eng.qkv_dedup == (per_key == "1")
+        assert eng.dedup == (dedup == "1") and eng.qkv_dedup == (per_key == "1") and eng.dropcorr == (per_key in ("2", "3"))
+        assert eng.dropcorr_bwd == (per_key == "3")
         G = eng.grads_like()
         if planned:
             eng.enable_plan_slots()
@@ -1269,6 +1302,7 @@ def test_nrms_projection_once_per_distinct_token(planned, glove, monkeypatch):
                 eng.prefetch_masks(torch.cuda.current_stream(), i % 2)     # keep bits with the plan: expansion and per-token sums read them
                 eng.use_slot(i % 2)
             scores, loss = eng.forward(*ids, training=True, planned=planned)
+            assert eng._dc_active == (per_key in ("2", "3") and planned)
             eng.backward(G)
             res.append((scores.clone(), float(loss)))
         torch.cuda.synchronize()
@@ -1284,6 +1318,70 @@ def test_nrms_projection_once_per_distinct_token(planned, glove, monkeypatch):
             d = float((g1[k] - g0[k]).abs().max())
             assert d <= 2e-5 * gmax + 2e-5 * float(g0[k].abs().max()), (form, k, d, gmax)
     assert float(g0["embedding_vocab_table.glove.linear.weight" if glove else "embedding_vocab_table.glove.weight"].abs().max()) > 0
+
+
+@pytest.mark.parametrize("D,R,U,p", [(256, 3000, 500, 0.1), (64, 700, 90, 0.25), (128, 257, 40, 0.5), (256, 5, 3, 0.1), (128, 9001, 700, 0.1),
+                                     (256, 6000, 300, 0.9)])
+def test_in_projection_per_key_with_dropout_correction(D, R, U, p):
+    """csrc/dropcorr_ops.hip against the dense row-by-row form it replaces (embedding_hub.py:95-96 + attention_operator.py:49-55):
+    q|k|v rows  E_r W^T + b  with  E_r = keep_r . Eu[k] / (1 - p)  for token rows and  Eu[k]  for the others, from the per-key product
+    Eu W^T and the sparse correction; and the data gradient's correction  dEu[k][c] -= g_r . W[:, c]  over the dropped coordinates --
+    same keep bits (lego_dropout_mask), float64 references; plus the plain expansion (no Dropout) and the row scaling / masking"""
+    import ctypes
+    from legommenders_amd._lib import call, LegoDropout
+    dev = _dev()
+    g_ = torch.Generator().manual_seed(D + R)
+    N = 3 * D
+
+    def P(t, o=0):
+        return None if t is None else ctypes.c_void_p(t.data_ptr() + o * t.element_size())
+    Eu = torch.randn(U, D, generator=g_)
+    W = torch.randn(N, D, generator=g_) * 0.1
+    b = torch.randn(N, generator=g_)
+    inv = torch.randint(0, U, (R,), generator=g_).int()
+    live = (torch.rand(R, generator=g_) < 0.85)
+    rowinfo = (live.int() * 4).int()                                # RI_LIVE = bit 2
+    cnt = torch.tensor([R], dtype=torch.int32, device=dev)
+    Eu_d, W_d, b_d, inv_d, ri_d = Eu.to(dev), W.to(dev), b.to(dev), inv.to(dev), rowinfo.to(dev)
+    WT_d = W_d.t().contiguous()
+    QKVu_d = (Eu.double() @ W.double().T).float().to(dev)
+    mask = torch.zeros(((R + 3) // 4) * D + 4, dtype=torch.uint8, device=dev)
+    call("lego_dropout_mask", ctypes.byref(LegoDropout(p, 99, 7, None)), R, P(cnt), D, P(mask), None)
+    dr = ctypes.byref(LegoDropout(p, 99, 7, mask.data_ptr()))
+    mk = mask[: ((R + 3) // 4) * D].view(-1, D).cpu()
+    rr = torch.arange(R)
+    keep = ((mk[rr // 4].int() >> (rr % 4)[:, None].int()) & 1).bool()                     # [R, D]
+    assert abs(float(keep.float().mean()) - (1 - p)) < 0.03
+    scale = 1.0 / (1.0 - p)
+    E = torch.where(live[:, None], Eu[inv.long()] * keep * scale, Eu[inv.long()]).double()
+    ref = (E @ W.double().T + b.double())
+    out = torch.full((R + 1, N), 7.0, device=dev)
+    call("lego_qkv_expand_dropcorr", P(QKVu_d), N, P(Eu_d), D, P(WT_d), N, P(b_d), P(inv_d), P(ri_d), dr, R + 1, P(cnt), D, N, P(out), N, None)
+    torch.cuda.synchronize()
+    assert float(out[R].min()) == 7.0 == float(out[R].max())                               # rows past the live count untouched
+    _close(out[:R].cpu(), ref.float(), rtol=3e-5, what="q|k|v rows, per key + dropout correction")
+    # no Dropout: plain expansion
+    out2 = torch.zeros(R, N, device=dev)
+    call("lego_qkv_expand_dropcorr", P(QKVu_d), N, P(Eu_d), D, None, N, P(b_d), P(inv_d), P(ri_d), None, R, P(cnt), D, N, P(out2), N, None)
+    _close(out2.cpu(), (Eu[inv.long()].double() @ W.double().T + b.double()).float(), rtol=3e-5, what="q|k|v rows, plain expansion")
+    # backward correction
+    g = torch.randn(R, N, generator=g_)
+    deu0 = torch.randn(U, D, generator=g_)
+    deu = deu0.clone().to(dev)
+    call("lego_dropcorr_bwd", P(g.to(dev)), N, P(WT_d), N, P(inv_d), P(ri_d), dr, R, P(cnt), D, N, P(deu), D, None)
+    gw = g.double() @ W.double()                                                            # [R, D]: g_r . W[:, c]
+    corr = torch.zeros(U, D, dtype=torch.float64).index_add_(0, inv.long(), gw * ((~keep) & live[:, None]))
+    _close(deu.cpu(), (deu0.double() - corr).float(), rtol=3e-5, what="data-gradient correction")
+    # together: dEu = s * (sum_r g_r W - corr) equals the dense form  sum_r s keep_r . (g_r W)  for the token rows
+    dense = torch.zeros(U, D, dtype=torch.float64).index_add_(0, inv.long(), gw * keep * live[:, None] * scale)
+    sums = torch.zeros(U, N, dtype=torch.float64).index_add_(0, inv.long(), g.double() * live[:, None])
+    deu2 = (sums @ W.double()).float().to(dev)
+    call("lego_dropcorr_bwd", P(g.to(dev)), N, P(WT_d), N, P(inv_d), P(ri_d), dr, R, P(cnt), D, N, P(deu2), D, None)
+    ulive = torch.zeros(U, dtype=torch.int32)
+    ulive[::2] = 4
+    call("lego_scale_mask_rows", P(deu2), D, U, None, D, P(ulive.to(dev)), scale, None)
+    want = dense.float() * (ulive[:, None] != 0)
+    _close(deu2.cpu(), want, rtol=5e-5, what="per-key data gradient = dense form")
 
 
 @pytest.mark.parametrize("D,A", [(256, 256), (96, 40), (32, 0)])
