@@ -11,7 +11,7 @@
 //     offsets into a buffer descriptor (a neighbour the plan says does not exist is an offset past the extent: the hardware range
 //     check returns zeros), the k tile is the scalar offset.  The combination is one packed multiply-add per two elements.
 //   * (tried and dropped: staggering the two waves of a SIMD -- waves 4-7 staging before the first k group's MFMAs, waves 0-3 after
-//     them -- measured 4 % SLOWER here, 82.8 against 79.2 us; profiles/r05_wino2_modes.txt.)
+//     them -- measured 4 % SLOWER here, 82.8 against 79.2 us; profiles/r05_wino2_ablation.txt.)
 //   * the epilogue is row-major: the accumulators go through an LDS tile [2 x 64 pairs][128 + 4] and leave as 16-byte stores, a
 //     wave instruction covering the 512 contiguous bytes of two output rows; bias, keep bits (one 32-bit load per 4 columns) and
 //     the column sums are applied on that side.  The fragment-shaped epilogue stored 4 x 64 B per instruction, one dword per lane.

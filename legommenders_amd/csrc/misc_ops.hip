@@ -269,11 +269,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 // pieces l and l + 64; the row index is wave-uniform (scalar load), there is no per-element division, and every row's pieces
 // are contiguous in one instruction.  Rows are dealt to waves round-robin so that neighbouring waves write neighbouring rows.
 template <int U, bool NT>
-__global__ __launch_bounds__(256) void gather_rows_wave_kernel(const float* __restrict__ table, int ld_table, int w4,
-                                                               const int* __restrict__ idx, int rows_cap,
-                                                               const int* __restrict__ rows_dyn, float* __restrict__ out, int ld_out,
-                                                               int accumulate) {
-    const int rows = rows_dyn != nullptr ? min(rows_cap, *rows_dyn) : rows_cap;
+__device__ __forceinline__ void gather_rows_wave_body(const float* __restrict__ table, int ld_table, int w4, const int* __restrict__ idx, int rows,
+                                                      float* __restrict__ out, int ld_out, int accumulate) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     const int n_waves = gridDim.x * (blockDim.x >> 6);
@@ -316,6 +313,24 @@ __global__ __launch_bounds__(256) void gather_rows_wave_kernel(const float* __re
             }
         }
     }
+}
+
+// NT = the launch MAY stream (its capacity is HBM-sized); whether it does is decided on the LIVE row count, which only the device
+// knows: a de-duplicated batch moves ~5 MB through a launch sized for 127 MB, and its rows are read again by the projection
+// right behind it -- those stay ordinary loads / stores (stream_bytes = 0: always stream, the LEGO_GATHER_NT=1 tuning form)
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void gather_rows_wave_kernel(const float* __restrict__ table, int ld_table, int w4,
+                                                               const int* __restrict__ idx, int rows_cap,
+                                                               const int* __restrict__ rows_dyn, float* __restrict__ out, int ld_out,
+                                                               int accumulate, long long stream_bytes) {
+    const int rows = rows_dyn != nullptr ? min(rows_cap, *rows_dyn) : rows_cap;
+    if constexpr (NT) {
+        if ((long long)rows * w4 * 16 >= stream_bytes) {         // block-uniform
+            gather_rows_wave_body<U, true>(table, ld_table, w4, idx, rows, out, ld_out, accumulate);
+            return;
+        }
+    }
+    gather_rows_wave_body<U, false>(table, ld_table, w4, idx, rows, out, ld_out, accumulate);
 }
 
 
@@ -1701,7 +1716,7 @@ extern "C" int lego_gather_rows(const float* table, int ld_table, int width, con
         if (gb < 0) { const char* v = getenv("LEGO_GATHER_BLOCKS"); gb = v != nullptr ? atoi(v) : 1024; }
         const int want_blocks = (rows_cap + 4 * gu - 1) / (4 * gu);   // 4 waves per block x U rows in flight
         const int blocks = want_blocks < gb ? (want_blocks > 0 ? want_blocks : 1) : gb;
-#define LEGO_GATHER_GO(U_, NT_) hipLaunchKernelGGL((gather_rows_wave_kernel<U_, NT_>), dim3(blocks), dim3(256), 0, ST, table, ld_table, width / 4, idx, rows_cap, rows_dyn, out, ld_out, accumulate)
+#define LEGO_GATHER_GO(U_, NT_) hipLaunchKernelGGL((gather_rows_wave_kernel<U_, NT_>), dim3(blocks), dim3(256), 0, ST, table, ld_table, width / 4, idx, rows_cap, rows_dyn, out, ld_out, accumulate, gnt == 1 ? 0ll : (64ll << 20))
         const bool nt = gnt == 1 || (gnt == 2 && !accumulate && (long long)rows_cap * width * 4 >= (64ll << 20));
         if (gu == 8) { if (nt) LEGO_GATHER_GO(8, true); else LEGO_GATHER_GO(8, false); }
         else if (gu == 2) { if (nt) LEGO_GATHER_GO(2, true); else LEGO_GATHER_GO(2, false); }

@@ -308,6 +308,7 @@ class NamlEngine(_Base):
         # and 2 x 64 us of serialised int atomics on the prefetch stream -- slower than not de-duplicating.)  LEGO_DEDUP_BWD=0: off
         self.dedup_bwd = self.dedup and os.environ.get("LEGO_DEDUP_BWD", "1") != "0"
         self.proj_side = os.environ.get("LEGO_PROJ_SIDE", "0") == "1"
+        self.unpack_side = os.environ.get("LEGO_UNPACK_SIDE", "0") == "1"
         V = P["embedding_vocab_table.glove.embedding.weight"].shape[0]
         self.V = V
         self.Uc = min(self.Rc, V) if self.dedup else 0
@@ -669,7 +670,11 @@ class NamlEngine(_Base):
         if self.wino_dw:
             self.kk(m, "conv3_bwd_weight", "lego_conv3_wino_bwd_weight", _ptr(self.dY), D, _ptr(self.H), D,
                     _ptr(self.pair_info), self.Pc, self.cnt(5), _ptr(self.wino_du), D, D)
-            self.kk(m, None, "lego_conv3_wino_unpack_add", _ptr(self.wino_du), self.wino_slabs, _ptr(G["item_op.cnn.weight"]), D, D)
+            ust = m
+            if self.unpack_side:                     # A/B (LEGO_UNPACK_SIDE=1): the slabs' unpack beside the projection's tail, not in front of it
+                self._fork(ev[8], m, sb)
+                ust = sb
+            self.kk(ust, None, "lego_conv3_wino_unpack_add", _ptr(self.wino_du), self.wino_slabs, _ptr(G["item_op.cnn.weight"]), D, D)
         else:
             self.kk(m, "conv3_bwd_weight", "lego_conv3_bwd_weight", _ptr(self.dY), D, _ptr(self.H), D, _ptr(self.rowinfo),
                     _ptr(self.dwt), self.Rc, self.cnt(0), D, D)
@@ -901,6 +906,7 @@ class NrmsEngine(_Base):
     _cur_slot = None
     _dc_active = False
     _dc_drop = None
+    _dc_e_pending = False
 
     def _dhu_consumed(self):
         """backward has added into dHu: the current slot's rows are not clean any more"""
@@ -959,7 +965,7 @@ class NrmsEngine(_Base):
             call("lego_sort_rows", _ptr(self.uq_keys), self.Rc, _ptr(b["keys_sorted"]), _ptr(b["perm"]), _ptr(self.uq_temp),
                  self.uq_temp.numel(), st)
             self._uq_end(stream)
-            if self.keyspace:
+            if self.qkv_dedup:                       # (its backward pass clears dEu in the sums' launch)
                 pass
             elif b is not self.__dict__:             # a plan slot: its per-token sums start from rows cleared here, off the main stream
                 call("lego_zero_rows", _ptr(b["dHu"]), self.D, self.D, self.Uc, _ptr(b["counters"], 6), st)
@@ -1388,6 +1394,9 @@ class NrmsEngine(_Base):
             if dp is not None:                       # W_in^T for the two correction kernels (768 KB, once per step)
                 with torch.cuda.stream(m):
                     self.WinT.copy_(P["item_op.multi_head_attention.in_proj_weight"].t())
+            if self._dc_e_pending and sw is not m:   # a forward pass with no backward behind it left its row expansion un-joined: it reads Eu
+                m.wait_event(self._sev[9])
+            self._dc_e_pending = False
             # Hu = projection of the distinct TOKEN keys ([SEP] / category keys: zero rows of Xu, masked next) ...
             call("lego_linear_fwd", _ptr(self.Xu), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
                  _ptr(P["embedding_vocab_table.glove.linear.bias"]), _ptr(self.Hu), D, self.Uc, self.cnt(6), D, E0, 0,
@@ -1395,13 +1404,17 @@ class NrmsEngine(_Base):
             # ... Eu[k] = the ONE live look-up of key k: the token's projection, or the [SEP] / category row (identity expansion)
             call("lego_expand_rows", _ptr(self.Hu), D, _ptr(self.iota_u), self.Uc, self.cnt(6), D, None, _ptr(self.tokinfo_u),
                  _ptr(spec), D, _ptr(self.idx_spec_u), _ptr(catw), D, _ptr(self.idx_cat_u), _ptr(self.Eu), D, st)
-            if training:
+            if not getattr(self, "_eval_only", False):
                 # the row embeddings E (Dropout applied per row) are needed by the in-projection's WEIGHT gradient only: side stream
+                # (every forward pass a backward pass may follow -- the parity tests differentiate the eval-mode forward too)
                 if sw is not m:
                     self._sev[8].record(m)
                     sw.wait_event(self._sev[8])
                 call("lego_expand_rows", _ptr(self.Eu), D, _ptr(self.inv), self.Rc, self.cnt(0), D, dp, _ptr(self.tokinfo),
                      _ptr(spec), D, _ptr(self.idx_spec), _ptr(catw), D, _ptr(self.idx_cat), _ptr(self.E), D, stream_handle(sw))
+                if sw is not m:
+                    self._sev[9].record(sw)
+                    self._dc_e_pending = True
             self._dc_active = True
             self._dc_drop = dp
             self._att_fwd("item_op.", self.item_ws, _ptr(self.Eu), self.cnt(0), self.seg_off, self.NIc, self.cnt(1),
@@ -1480,6 +1493,7 @@ class NrmsEngine(_Base):
         self._have_d_pooled = head
         m, sw = self._side()
         sev = self._sev if sw is not m else [None] * 6
+        self._dc_e_pending = False                   # (this pass ends with the side stream joined: the forward's row expansion with it)
         self._deferred = []
         self._att_bwd("user_op.", self.user_ws, G, _ptr(self.items, self.BC * D), _ptr(self.d_items, self.BC * D),
                       self.cnt(3), self.hist_off, B, None, self.d_user, SITE_USER_ATT, training, st, sev[0:2])

@@ -1274,7 +1274,7 @@ def test_nrms_projection_once_per_distinct_token(planned, glove, monkeypatch):
     tb = E.ItemTables(w["title_tok"], w["title_len"], w["cat"], dev)
     rs = np.random.RandomState(3)
     batches = []
-    for _ in range(2):
+    for _ in range(5):                               # five steps over two plan slots: every slot is planned and used again
         users = rs.randint(0, 300, size=B)
         batches.append([torch.tensor(np.ascontiguousarray(a)).int().to(dev).contiguous() for a in
                         (rs.randint(0, w["n_items"], size=(B, C)), w["user_hist"][users], np.maximum(w["user_hist_len"][users], 1))])
@@ -1318,6 +1318,33 @@ def test_nrms_projection_once_per_distinct_token(planned, glove, monkeypatch):
             d = float((g1[k] - g0[k]).abs().max())
             assert d <= 2e-5 * gmax + 2e-5 * float(g0[k].abs().max()), (form, k, d, gmax)
     assert float(g0["embedding_vocab_table.glove.linear.weight" if glove else "embedding_vocab_table.glove.weight"].abs().max()) > 0
+
+
+def test_nrms_training_trajectory_per_key_in_projection(monkeypatch):
+    """TrainStep (plan slots, keep bits drawn with the plan, Adam) over 40 steps, NRMS with the GloVe projection and Dropout on: the per-key
+    in-projection with the sparse Dropout correction (default) against the row-by-row form -- same seeds and dropout streams, so the
+    per-step losses agree to rounding (tools/nrms_dropcorr_trajectory.py: to 1e-6 for 150 steps at the bench shape).  This is the check that
+    a plan slot used AGAIN carries nothing over from its previous step (round 5: the per-token sums of a re-used slot were not cleared
+    in the key space -- two single-use slots, as the two-step parity test above had them, could not see it)."""
+    from legommenders_amd.synthetic import glove_like, init_nrms_params, make_world
+    from legommenders_amd.train_step import DeviceData, TrainStep
+    dev = _dev()
+    D, B, V = 128, 16, 3000
+    w = make_world(seed=9, n_items=700, n_users=300, n_rows=2000, V=V)
+    glove = glove_like(V, 300, seed=4, device=dev)
+    traj = {}
+    for form in ("0", "1"):
+        monkeypatch.setenv("LEGO_NRMS_DROPCORR", form)
+        P = init_nrms_params(D=D, V=V, n_cat=w["n_cat"], heads=8, glove=glove, seed=6)
+        ts = TrainStep("nrms", P, DeviceData(w, dev, seed=5), B, K=4, seed=5, glove=True, dropout=True, lr=1e-3, total_steps=0, tail="drop")
+        assert ts.engine.dropcorr == (form == "1")
+        losses = [ts.step().clone() for _ in range(40)]
+        torch.cuda.synchronize()
+        assert ts.engine._dc_active == (form == "1")
+        traj[form] = np.array([float(x) for x in losses])
+        del ts
+    d = np.abs(traj["1"] - traj["0"])
+    assert d.max() < 2e-5, (int(d.argmax()), float(d.max()), traj["0"][:6], traj["1"][:6])
 
 
 @pytest.mark.parametrize("D,R,U,p", [(256, 3000, 500, 0.1), (64, 700, 90, 0.25), (128, 257, 40, 0.5), (256, 5, 3, 0.1), (128, 9001, 700, 0.1),

@@ -1,7 +1,10 @@
 """Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs of `LEGO_SERIAL=1 bench.py`) into
 profiles/rNN_traffic.json, which bench.py reads for `roofline.traffic`.
 
-    python tools/traffic_from_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> profiles/r01_traffic.json
+    python tools/traffic_from_pmc.py <fetch_counter_collection.csv>[,<more>] <write_counter_collection.csv>[,<more>] profiles/r01_traffic.json
+
+(comma-separated lists; an entry `gather_rows_hbm=<csv>` is a pass over `tools/gather_hbm.py 105600 8 --uniform-only`: its row-gather launches are
+the HBM-sized ones -- the kernel is the one the step uses, it decides to stream on the live row count -- and take that tag)
 
 Units and corrections follow MI355X_MICROARCH.md: both counters are in KiB; on gfx950 FETCH_SIZE counts the 128-B
 requests of 16-B-per-lane coalesced reads at 64 B, so the fetched bytes are doubled."""
@@ -11,8 +14,12 @@ from collections import defaultdict
 
 def tag_of(name):
     n = name.replace("lego::", "")
-    if n.startswith("gather_rows_kernel") or n.startswith("gather_rows_wave_kernel"):
+    if n.startswith("void gather_rows") or n.startswith("gather_rows_kernel") or n.startswith("gather_rows_wave_kernel"):
         return "gather_rows"
+    if "wino2_kernel" in n:               # one kernel for both directions (round 5): a training step launches forward, then data gradient
+        return "wino2"
+    if "tndp_kernel" in n:
+        return "conv3_bwd_weight"
     if "wino_kernel<false>" in n:
         return "conv3_fwd"
     if "wino_kernel<true>" in n:
@@ -36,14 +43,30 @@ def tag_of(name):
     return None
 
 
-def per_kernel(path, counter):
+def per_kernel(paths, counter):
     vals = defaultdict(list)
-    for r in csv.DictReader(open(path)):
-        if r.get("Counter_Name") != counter:
-            continue
-        t = tag_of(r["Kernel_Name"])
-        if t is not None:
-            vals[t].append(float(r["Counter_Value"]))
+    for path in paths.split(","):
+        retag = None
+        if "=" in path:
+            retag, path = path.split("=", 1)
+        rows = [r for r in csv.DictReader(open(path)) if r.get("Counter_Name") == counter]
+        disp = {}                                  # one value per dispatch, in dispatch order
+        for i, r in enumerate(rows):
+            key = int(r["Dispatch_Id"]) if r.get("Dispatch_Id") else i
+            if key not in disp:
+                disp[key] = [r["Kernel_Name"], 0.0]
+            disp[key][1] += float(r["Counter_Value"])
+        nth = 0
+        for key in sorted(disp):
+            name, v = disp[key]
+            t = tag_of(name)
+            if retag is not None:
+                t = retag if t == "gather_rows" else None
+            if t == "wino2":
+                t = ("conv3_fwd", "conv3_bwd_data")[nth % 2]
+                nth += 1
+            if t is not None:
+                vals[t].append(v)
     return vals
 
 
