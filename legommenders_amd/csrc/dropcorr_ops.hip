@@ -53,7 +53,13 @@ __device__ __forceinline__ uint32_t keep_word(const uint8_t* __restrict__ mask, 
 // and fetches the inputs of four rows at a time, one group of four ahead of the arithmetic, with no branch around the loads (indices
 // past the run are clamped) so the compiler's counted waits stay exact.  (Round 5's first forms: one coordinate per turn off the ballot
 // mask, every step waiting on the one before, 93 us at the bench batch; then the four-entry turns with the loads still row by row:
-// 96 us -- the waves were sitting on the two trips per row, not on the arithmetic.)
+// 96 us -- the waves were sitting on the two trips per row, not on the arithmetic.  With both: 88 us, of which 21 the plain
+// expansion, 18 keep words + list, 49 the correction's arithmetic = vector-ALU issue: 2 v_readlane + v_add + v_pk_fma per coordinate
+// and 128 columns.  Two forms that move work off the vector ALU, built and measured slower (tools/dropcorr_time.py): the address on
+// the scalar side with ds_read_addtid_b32 (LDS address = M0 + offset + 4 lane; one v_readlane + one v_pk_fma per coordinate): 140 us --
+// a write of M0 waits for the LDS reads in flight that used the old value, so the reads of a turn run one after the other; the
+// coordinates straight off four ballot masks with s_ff1 / s_and chains instead of the list: 121 us -- the dependent scalar chain and the
+// per-mask padding of the four-coordinate turns cost more than the list they save.)
 constexpr int DC_LIST = 256;               // list entries per wave (= the widest row: D <= 256)
 struct Rows4 {
     f32x2_t q[4];
