@@ -354,6 +354,13 @@ int lego_gather_history(const int32_t* row_user, const int32_t* user_hist /*[n_u
  * look-up index columns (-1 = column absent at that position) and a live-bit word for token rows. */
 int lego_nrms_decode_rows(const int32_t* row_tok, int R_cap, const int32_t* R_dyn, int32_t* idx_tok,
                           int32_t* idx_special, int32_t* idx_cat, int32_t* tokinfo, void* stream);
+/* (round 5) key space of the per-key in-projection: row_key[r] = row_tok[r] for tokens, V for [SEP] (-2), V + 1 + c for category c
+ * (-(3 + c)) -- every position of a ConcatInputer sequence (concat_inputer.py:96-114) is a function of that one id; and, for the
+ * DISTINCT keys lego_unique_tokens finds in that space, the row index in each of the three tables (-1 = not this table's; [SEP] is
+ * row 2 of the special-id table) + RI_LIVE for token keys. */
+int lego_nrms_key_rows(const int32_t* row_tok, int R_cap, const int32_t* R_dyn, int V, int32_t* row_key, void* stream);
+int lego_nrms_decode_keys(const int32_t* uniq, int U_cap, const int32_t* U_dyn, int V, int32_t* idx_tok, int32_t* idx_special,
+                          int32_t* idx_cat, int32_t* keyinfo, void* stream);
 /* Backward of ConcatInputer's two small look-ups (concat_inputer.py:96-114: token + special-id + category embeddings are summed
  * per position): an item's sequence is [title..., SEP, category, SEP], so rows L-3 and L-1 of each segment add into the [SEP]
  * row g_sep[width] of the special-id table and row L-2 into row idx_cat[beg+L-2] of g_cat. */

@@ -35,6 +35,8 @@ SIGNATURES = {
     "lego_plan_dense": [P, I, I, P, P, P, P],
     "lego_gather_rows": [P, I, I, P, I, P, P, I, I, P],
     "lego_nrms_decode_rows": [P, I, P, P, P, P, P, P],
+    "lego_nrms_key_rows": [P, I, P, I, P, P],
+    "lego_nrms_decode_keys": [P, I, P, I, P, P, P, P, P],
     "lego_nrms_special_grads": [P, I, P, P, P, I, I, P, P, I, I, P],
     "lego_mask_dropout_rows": [P, I, I, P, I, P, P, P, P],
     "lego_small_rows_matmul_add": [P, I, P, I, P, I, P, I, P, I, I, P],

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include "../../include/lego_hip.h"
 #include "gemm_strip.hpp"
+#include <atomic>
 #include "gemm_oneshot.hpp"
 #include "gemm_epi.hpp"
 
@@ -198,10 +199,17 @@ static int launch_light(const GemmDims& d, const AL& a, const BL& b, const Epi& 
 // fp32 accumulate; gemm_core.hpp) for the large products -- an OPT-IN throughput mode that is not bit-compatible with the reference
 // (relative error ~1e-5 per product); lego_set_product_mode() or LEGO_SPLIT_BF16=1 at load.  Small latency-bound products (user side,
 // fold levels) stay exact in both modes.
-static int g_product_mode = -1;
+// (process-wide, read at every launch, written by lego_set_product_mode from any thread: an atomic.  Engines cache which conv entry points
+// they use when they are built -- engine.py refuses to step an engine built in the other mode)
+static std::atomic<int> g_product_mode{-1};
 static int product_mode() {
-    if (g_product_mode < 0) { const char* e = getenv("LEGO_SPLIT_BF16"); g_product_mode = (e != nullptr && e[0] == '1') ? 1 : 0; }
-    return g_product_mode;
+    int m = g_product_mode.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("LEGO_SPLIT_BF16");
+        m = (e != nullptr && e[0] == '1') ? 1 : 0;
+        g_product_mode.store(m, std::memory_order_relaxed);
+    }
+    return m;
 }
 constexpr int SPLIT_MIN_ROWS = 2048;            // below this the products are latency-bound: nothing to gain, keep them exact
 
@@ -347,7 +355,7 @@ extern "C" const char* lego_last_error(void) { return lego::last_error(); }
 extern "C" int lego_abi_version(void) { return LEGO_ABI_VERSION; }
 extern "C" int lego_set_product_mode(int mode) {
     LEGO_REQUIRE(mode == 0 || mode == 1, "lego_set_product_mode: mode=%d (0 = exact f32, 1 = split-bf16)", mode);
-    lego::g_product_mode = mode;
+    lego::g_product_mode.store(mode, std::memory_order_relaxed);
     return 0;
 }
 extern "C" int lego_get_product_mode(void) { return lego::product_mode(); }

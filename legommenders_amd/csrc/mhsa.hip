@@ -16,11 +16,12 @@
 // -- 4.3 KB per wave, so occupancy is set by registers (3-4 waves per SIMD), not by the 23 KB per wave of staged Q / K / V /
 // dOut tiles the previous version held (6 waves per CU: 134 + 69 us per NRMS step for the item side; this one: see DESIGN).
 // Segments of 33..64 rows run as 2 x 2 tiles in a second instantiation on a small grid (launched only when Lmax > 32).
-// Round 4: the probabilities are NOT saved.  The forward pass keeps one float per (row, head) -- the log-sum-exp of the row's
-// scaled scores -- and the backward pass recomputes S^T = K Q^T (hd/2 MFMAs per tile, operands the wave reads anyway, in their
-// other register shape) and p = exp(s - lse), and redraws the dropout keep bits from the same Philox counters: the
-// [rows, heads, L] round trip (32 MB written + 32 MB read per NRMS step, a fifth of both kernels' traffic) is gone.  `probs`
-// survives as an optional debug output of the forward (tests read the keep decisions from its sign bits: p >= 0 kept, -p dropped).
+// Round 4: two ways to hand the softmax to the backward pass.  `probs`: the forward saves the (sign-tagged) probabilities, the backward
+// reads them -- the engine's default, measured faster (backward 63 against 80 us).  `lse`: the forward keeps one float
+// per (row, head) -- the log-sum-exp of the row's scaled scores -- and the backward recomputes S^T = K Q^T (hd/2 MFMAs per tile, operands
+// the wave reads anyway, in their other register shape) and p = exp(s - lse), and redraws the dropout keep bits from the same Philox
+// counters: no [rows, heads, L] round trip (32 MB written + 32 MB read per NRMS step).  LEGO_MHSA_RECOMPUTE=1 selects it in the engine;
+// the plug-in route (kernels.mhsa_fwd / ops.mhsa) always takes it -- its saved tensors then have static shapes and are 30x smaller.
 #include "../../include/lego_hip.h"
 #include "common.hpp"
 

@@ -629,6 +629,29 @@ __global__ void nrms_decode_rows_kernel(const int* __restrict__ row_tok, int R_c
     tokinfo[r] = v >= 0 ? RI_LIVE : 0;
 }
 
+// Key space of the per-key in-projection (engine.NrmsEngine.keyspace): every position of a ConcatInputer sequence is a function of ONE id --
+// tokens keep theirs, [SEP] (-2 in row_tok) becomes V, category c (-(3 + c)) becomes V + 1 + c -- and, after lego_unique_tokens over that
+// space, the distinct keys go back to per-table row indices (-1 = not this table's).  (Round 5: these were fifteen torch element-wise
+// launches per planned batch on the prefetch stream.)
+__global__ void nrms_key_rows_kernel(const int* __restrict__ row_tok, int R_cap, const int* __restrict__ R_dyn, int V, int* __restrict__ row_key) {
+    const int R = R_dyn != nullptr ? min(R_cap, *R_dyn) : R_cap;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int v = row_tok[r];
+    row_key[r] = v >= 0 ? v : (V - 2) - v;
+}
+__global__ void nrms_decode_keys_kernel(const int* __restrict__ uniq, int U_cap, const int* __restrict__ U_dyn, int V, int* __restrict__ idx_tok,
+                                        int* __restrict__ idx_special, int* __restrict__ idx_cat, int* __restrict__ keyinfo) {
+    const int U = U_dyn != nullptr ? min(U_cap, *U_dyn) : U_cap;
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U) return;
+    const int k = uniq[u];
+    idx_tok[u] = k < V ? k : -1;
+    idx_special[u] = k == V ? 2 : -1;                   // [SEP] = 2 (concat_inputer.py:27-30)
+    idx_cat[u] = k > V ? k - (V + 1) : -1;
+    keyinfo[u] = k < V ? RI_LIVE : 0;
+}
+
 // Gradients of the two small embedding tables of ConcatInputer (concat_inputer.py:58-114) straight from the segment
 // layout: an item's sequence is [title..., SEP, category, SEP], so of its L rows exactly three feed these tables -- rows
 // L-3 and L-1 the [SEP] row of the special-id table, row L-2 the item's category row.  One workgroup per 32 items, one wave
@@ -1805,6 +1828,19 @@ extern "C" int lego_nrms_decode_rows(const int32_t* row_tok, int R_cap, const in
     hipLaunchKernelGGL(nrms_decode_rows_kernel, dim3((R_cap + 255) / 256), dim3(256), 0, ST, row_tok, R_cap, R_dyn, idx_tok,
                        idx_special, idx_cat, tokinfo);
     return check_launch("lego_nrms_decode_rows");
+}
+
+extern "C" int lego_nrms_key_rows(const int32_t* row_tok, int R_cap, const int32_t* R_dyn, int V, int32_t* row_key, void* stream) {
+    if (R_cap <= 0) return 0;
+    hipLaunchKernelGGL(nrms_key_rows_kernel, dim3((R_cap + 255) / 256), dim3(256), 0, ST, row_tok, R_cap, R_dyn, V, row_key);
+    return check_launch("lego_nrms_key_rows");
+}
+
+extern "C" int lego_nrms_decode_keys(const int32_t* uniq, int U_cap, const int32_t* U_dyn, int V, int32_t* idx_tok, int32_t* idx_special,
+                                     int32_t* idx_cat, int32_t* keyinfo, void* stream) {
+    if (U_cap <= 0) return 0;
+    hipLaunchKernelGGL(nrms_decode_keys_kernel, dim3((U_cap + 255) / 256), dim3(256), 0, ST, uniq, U_cap, U_dyn, V, idx_tok, idx_special, idx_cat, keyinfo);
+    return check_launch("lego_nrms_decode_keys");
 }
 
 extern "C" int lego_mask_dropout_rows(float* x, int ld, int R_cap, const int32_t* R_dyn, int width, const int32_t* rowinfo,

@@ -345,7 +345,8 @@ class NamlEngine(_Base):
         # data gradient take the direct split form (54 / 74 us against Winograd's 92 / 92) while the WEIGHT gradient stays on the exact
         # Winograd kernel (`wino_dw`: 82 us alone against 95 for three split TN taps; it needs the pair plan, nothing of the forward's form)
         self.wino_dw = os.environ.get("LEGO_WINO", "1") != "0" and D <= 256 and self.Rc > 0
-        self.wino = self.wino_dw and _lib.product_mode() == _lib.EXACT_F32
+        self._built_mode = _lib.product_mode()       # (forward() refuses a step in the other mode: the conv entry points are chosen here)
+        self.wino = self.wino_dw and self._built_mode == _lib.EXACT_F32
         if os.environ.get("LEGO_SPLIT_WINO_DW", "1") == "0":
             self.wino_dw = self.wino
         self.Pc = self.NIc * ((self.T + 1) // 2)
@@ -477,6 +478,8 @@ class NamlEngine(_Base):
         m, sb, sc = self._lanes()
         ev = self._evs
         _check(cand, torch.int32, "cand"); _check(hist, torch.int32, "hist"); _check(hist_len, torch.int32, "hist_len")
+        if _lib.product_mode() != self._built_mode:
+            raise _lib.LegoHipError("the product mode (lego_set_product_mode) changed after this engine was built: build engines in the mode they run in")
         self._training = training
         if not planned:
             self._plan(cand, hist, hist_len)
@@ -825,7 +828,6 @@ class NrmsEngine(_Base):
             self.Eu = self._f(self.Uc, D)
             self.QKVu = self._f(self.Uc, 3 * D)
             self.dQKVu = self._f(self.Uc, 3 * D)
-            self._kconst = {k: torch.tensor(k, **i32) for k in (-1, 0, 2, RI_LIVE_BIT)}
         # GloVe projection, round 5: the same per-key in-projection WITH the Dropout that sits between the projection and the attention
         # (embedding_hub.py:95-96): a token row is s (m_r . h_k), so W E_r = s (W h_k - sum over the dropped coordinates c of h_k[c] W[:, c])
         # -- the per-key product plus ~26 multiply-adds of a 3D-vector per row (csrc/dropcorr_ops.hip); the data gradient splits the same
@@ -858,7 +860,6 @@ class NrmsEngine(_Base):
             self.dQKVu = self._f(self.Uc, 3 * D)
             self.WinT = self._f(D, 3 * D)
             self.iota_u = torch.arange(self.Uc, **i32)
-            self._kconst = {k: torch.tensor(k, **i32) for k in (-1, 0, 2, RI_LIVE_BIT)}
         self.keyspace = self.qkv_dedup or self.dropcorr
         self.X = (self._f(1, self.E0) if self.dedup else self._f(self.Rc, self.E0)) if glove else None
         self.E = self._f(self.Rc, D)
@@ -945,20 +946,14 @@ class NrmsEngine(_Base):
             self._uq_begin(stream)
             keys, nkeys = b["row_tok"], self.V
             if self.keyspace:                        # every position gets a key >= 0: tokens as they are, [SEP] (-2) -> V, category -(3+c) -> V+1+c
-                with torch.cuda.stream(stream):
-                    torch.where(b["row_tok"] >= 0, b["row_tok"], (self.V - 2) - b["row_tok"], out=self.row_key)
+                call("lego_nrms_key_rows", _ptr(b["row_tok"]), self.Rc, _ptr(b["counters"], 0), self.V, _ptr(self.row_key), st)
                 keys, nkeys = self.row_key, self.Vk
             call("lego_unique_tokens", _ptr(keys), self.Rc, _ptr(b["counters"], 0), nkeys, _ptr(self.uq_stamp), self._uq_epoch,
                  _ptr(self.uq_rank), _ptr(self.uq_bsum), _ptr(b["uniq"]), _ptr(b["inv"]), _ptr(self.uq_cnt), _ptr(self.uq_start), None,
                  _ptr(self.uq_keys), _ptr(b["counters"], 6), st)
             if self.keyspace:                        # the distinct keys back into per-table row indices (-1 = not this table's)
-                with torch.cuda.stream(stream):
-                    u, V = b["uniq"], self.V
-                    c = self._kconst
-                    torch.where(u < V, u, c[-1], out=b["idx_tok_u"])
-                    torch.where(u == V, c[2], c[-1], out=b["idx_spec_u"])             # [SEP] = id 2 of the special vocabulary
-                    torch.where(u > V, u - (V + 1), c[-1], out=b["idx_cat_u"])
-                    torch.where(u < V, c[RI_LIVE_BIT], c[0], out=b["tokinfo_u"])
+                call("lego_nrms_decode_keys", _ptr(b["uniq"]), self.Uc, _ptr(b["counters"], 6), self.V, _ptr(b["idx_tok_u"]), _ptr(b["idx_spec_u"]),
+                     _ptr(b["idx_cat_u"]), _ptr(b["tokinfo_u"]), st)
             if self.glove:                           # table rows of the distinct tokens (key space: zero rows for the [SEP] / category keys)
                 call("lego_gather_rows", _ptr(self.P["embedding_vocab_table.glove.embedding.weight"]), E0, E0,
                      _ptr(b["idx_tok_u"] if self.keyspace else b["uniq"]), self.Uc, _ptr(b["counters"], 6), _ptr(b["Xu"]), E0, 0, st)
