@@ -655,8 +655,9 @@ def main():
             import bert_naml_bench
             from legommenders_amd.loader.env import Env
             bsec = {}
-            # (two warm-up steps: the second still grows the caching allocator -- 15 GB of saved activations -- and with one the three timed
-            # steps read 165 ms where the same process settles at 127, tools/bert_naml_bench.py)
+            # (two warm-up steps, and tools/bert_naml_bench.py synchronises after every step: with the host running steps ahead the caching
+            # allocator is asked for the next step's 15 GB of saved activations before the previous step's are back, and the timed steps
+            # paid for fresh segments -- 165-213 ms per step in this process against 122-128 ms)
             for name, tf, st in (("tune_from_0", 0, 5), ("tune_from_9_cached_layer", 9, 10)):
                 r = bert_naml_bench.run(batch=B, steps=st, warmup=2, layers=12, hidden=D, tune_from=tf)
                 bsec[name] = {"steps": st, "warmup": 2, "ms_per_step": round(r["s_per_step"] * 1e3, 2), "value": r["impressions_per_s"],

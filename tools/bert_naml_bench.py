@@ -80,11 +80,19 @@ def run(batch=64, steps=5, warmup=2, layers=12, hidden=256, tune_from=0, n_items
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    # one device sync per step (a step is ~125 ms: the sync costs nothing): un-synchronised, the host runs several steps ahead, each step's
+    # ~15 GB of saved activations is requested before the previous step's are back in the caching allocator, and the timed steps pay for
+    # fresh hipMalloc segments -- 165-213 ms per step inside bench.py's process against 122-128 ms for the same steps taken one at a time
+    step_ms = []
     for _ in range(a.steps):
+        t1 = time.perf_counter()
         loss = step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / a.steps
+        torch.cuda.synchronize()
+        step_ms.append(round((time.perf_counter() - t1) * 1e3, 1))
+    dt = sum(step_ms) / 1e3 / a.steps
+    if os.environ.get("LEGO_BERT_STEP_TIMES") == "1":
+        print("bert_naml_bench step times (ms):", step_ms, "allocated GB", round(torch.cuda.memory_allocated() / 2**30, 2),
+              "reserved GB", round(torch.cuda.memory_reserved() / 2**30, 2), file=sys.stderr, flush=True)
     n_par = sum(p.numel() for p in model.parameters() if p.requires_grad)
     # per-product table of the native blocks: two more steps with every product launch bracketed by HIP events (outside the timing above)
     kernels = None
