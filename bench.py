@@ -661,6 +661,7 @@ def main():
             for name, tf, st in (("tune_from_0", 0, 5), ("tune_from_9_cached_layer", 9, 10)):
                 r = bert_naml_bench.run(batch=B, steps=st, warmup=2, layers=12, hidden=D, tune_from=tf)
                 bsec[name] = {"steps": st, "warmup": 2, "ms_per_step": round(r["s_per_step"] * 1e3, 2), "value": r["impressions_per_s"],
+                              "timing": r["timing"], "step_ms": r["step_ms"], "ms_per_step_mean": round(r["s_per_step_mean"] * 1e3, 2),
                               "unit": "impressions/s", "bert_blocks_run": r["bert_layers_run"], "trainable_params": r["trainable_params"],
                               "layer_cache_s": r["layer_cache_s"], "layer_cache_GB": r["layer_cache_GB"], "final_loss": round(r["loss"], 4),
                               "item_page_size_yaml": r["item_page_size"], "item_page_effective": r["effective_item_page"],
