@@ -216,9 +216,22 @@ constexpr int SPLIT_MIN_ROWS = 2048;            // below this the products are l
 using C128x128s = TileCfg<128, 128, 4, 2, true>;   // split mode: 8 waves of 32 x 64
 using C128x256s = TileCfg<128, 256, 2, 4>;
 
+// round 5: plain-row NT / NN products on rows2_kernel (gemm_rows2.hpp, rows2_ops.hip)
+bool rows2_ok(const float* x, int ldx, const float* w, int ldw, int M_cap, int N, int K, const EpiArgs& e, bool b_mc, bool accum, bool reluref);
+int launch_rows2(const float* x, int ldx, const float* w, int ldw, int M_cap, const int* M_dyn, int N, int K, const EpiArgs& e, bool b_mc, bool accum,
+                 bool reluref, hipStream_t st, const char* what);
+
 template <bool B_MC, class EK, class AL, class BL>
 static int launch_rows(const GemmDims& d, const AL& a, const BL& b, const Epi& e, hipStream_t st, const char* what) {
     const int tm = (d.M + 127) / 128;
+    if constexpr (std::is_same<AL, KcRows>::value && (std::is_same<BL, KcRows>::value || std::is_same<BL, McRows>::value) &&
+                  (std::is_same<EK, EpiPlain>::value || std::is_same<EK, EpiAccum>::value || std::is_same<EK, EpiAccumRelu>::value)) {
+        constexpr bool acc_ = !std::is_same<EK, EpiPlain>::value, ref_ = std::is_same<EK, EpiAccumRelu>::value;
+        static_assert(B_MC == std::is_same<BL, McRows>::value, "an M-contiguous B operand is the NN form");
+        if (product_mode() == 0 && a.row_off_dyn == nullptr && b.row_off_dyn == nullptr && e.row_off_dyn == nullptr && d.k_dyn == nullptr &&
+            rows2_ok(a.p, a.ld, b.p, b.ld, d.M, d.N, d.K, e, B_MC, acc_, ref_))
+            return launch_rows2(a.p, a.ld, b.p, b.ld, d.M, d.m_dyn, d.N, d.K, e, B_MC, acc_, ref_, st, what);
+    }
     if (product_mode() == 1 && d.M >= SPLIT_MIN_ROWS) {
         // tools/gemm_variants.py 20-26 (round 4): 128 x 128 on 4 x 2 staggered waves at the path's widths (214 / 154 TFLOP/s-equivalent
         // at K = 768 / 256 over 26 k rows, against 95 / 83 exact), 128 x 256 for the BERT widths (253-266 against 113-123)

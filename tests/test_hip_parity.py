@@ -72,6 +72,61 @@ def test_linear_family_matches_torch():
             _close(dW.cpu(), gy.T @ x, what=f"linear_bwd_weight {M}x{N}x{Kd}")
 
 
+@pytest.mark.parametrize("nn", [False, True])
+@pytest.mark.parametrize("R,cap,N,K,kind", [(8200, 8200, 256, 256, "tanh"), (9001, 9100, 128, 64, "relu"), (1, 9000, 256, 256, "plain"), (8500, 8500, 260, 96, "nobias"),
+                                            (10000, 30000, 256, 768, "plain"), (113, 8192, 256, 32, "accum"), (27613, 109120, 256, 256, "accum_relu")])
+def test_plain_row_products_two_workgroups_per_cu(R, cap, N, K, kind, nn, monkeypatch):
+    """csrc/gemm_rows2.hpp (round 5: B fragments from global memory, two workgroups per CU) through the entry points that dispatch to it --
+    lego_linear_fwd (NT: bias, tanh / ReLU) and lego_linear_bwd_data (NN: accumulate, ReLU' reference, column sums) -- against float64,
+    launches sized for a capacity with the live row count on the device; rows past the count and columns past N must stay untouched.
+    (linear.weight products of attention_operator.py:59-61,70-77 and their data gradients.)"""
+    import ctypes
+    from legommenders_amd._lib import call
+    dev = _dev()
+    if (kind in ("tanh", "relu", "nobias")) and nn:
+        pytest.skip("activation / bias epilogues belong to the forward (NT) entry point")
+    g_ = torch.Generator().manual_seed(R + N + K)
+
+    def P(t):
+        return None if t is None else ctypes.c_void_p(t.data_ptr())
+    ldo = N + 4 if kind == "nobias" else N
+    cnt = torch.tensor([R], dtype=torch.int32, device=dev)
+    x = torch.randn(cap + 1, K, generator=g_).to(dev)
+    x[R:] = float("nan")
+    if not nn:
+        W = (torch.randn(N, K, generator=g_) * 0.05).to(dev)
+        b = None if kind == "nobias" else torch.randn(N, generator=g_).to(dev)
+        act = {"tanh": 2, "relu": 1}.get(kind, 0)
+        out = torch.full((cap + 1, ldo), 7.0, device=dev)
+        if kind in ("accum", "accum_relu"):
+            pytest.skip("the forward entry point has no accumulate form")
+        call("lego_linear_fwd", P(x), K, P(W), K, P(b), P(out), ldo, cap, P(cnt), N, K, act, None, None, None, None, None)
+        want = x[:R].double() @ W.double().T + (b.double() if b is not None else 0.0)
+        want = torch.tanh(want) if act == 2 else (want.clamp_min(0) if act == 1 else want)
+        got = out[:R, :N]
+        assert float(out[R:].min()) == 7.0 == float(out[R:].max())
+        if ldo > N:
+            assert float(out[:, N:].min()) == 7.0 == float(out[:, N:].max())
+    else:                                            # dx[R, N] (+)= g[R, K] . W[K, N]
+        W = (torch.randn(K, N, generator=g_) * 0.05).to(dev)
+        dx0 = torch.randn(cap + 1, N, generator=g_).to(dev)
+        ref = torch.randn(cap + 1, N, generator=g_).to(dev)
+        cs = torch.zeros(N, device=dev)
+        dx = dx0.clone()
+        accumulate, relu = int(kind in ("accum", "accum_relu")), kind == "accum_relu"
+        call("lego_linear_bwd_data", P(x), K, P(W), N, P(dx), N, cap, P(cnt), K, N, accumulate, P(ref) if relu else None, N, 1.25 if relu else 1.0,
+             None, None, P(cs), None, None, None)
+        want = x[:R].double() @ W.double()
+        if accumulate:
+            want = want + dx0[:R].double()
+        if relu:
+            want = torch.where(ref[:R] > 0, 1.25 * want, torch.zeros_like(want))
+        got = dx[:R]
+        assert torch.equal(dx[R:], dx0[R:])
+        _close(cs.cpu(), want.sum(0).float().cpu(), rtol=2e-5, what="column sums")
+    _close(got.cpu(), want.float().cpu(), rtol=3e-5, what=f"product {kind} nn={nn}")
+
+
 @pytest.mark.parametrize("R,cap,N,K,ldg,ldx,off", [(8300, 8300, 768, 256, 768, 256, False), (4097, 105600, 512, 260, 520, 264, True),
                                                      (2049, 2600, 1024, 128, 1024, 128, False), (1, 4000, 768, 256, 768, 256, False)])
 def test_weight_gradient_without_lds_staging(R, cap, N, K, ldg, ldx, off):

@@ -28,7 +28,7 @@ def main():
     for f in files:
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
-            if not any(t in k for t in ("strip", "gemm", "wino", "oneshot", "pool", "tower", "gather_rows", "adam", "tnd", "tn_kernel", "dropcorr", "mhsa")):
+            if not any(t in k for t in ("strip", "gemm", "wino", "oneshot", "pool", "tower", "gather_rows", "adam", "tnd", "tn_kernel", "dropcorr", "mhsa", "rows2")):
                 continue
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     res = {}

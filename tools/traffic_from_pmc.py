@@ -20,6 +20,9 @@ def tag_of(name):
         return "wino2"
     if "tndp_kernel" in n:
         return "conv3_bwd_weight"
+    m = re.search(r"rows2_kernel<(\w+), (\w+), (\w+)>", n)            # round 5: plain-row products, <NN form, accumulate, ReLU reference>
+    if m:
+        return "rows2<%s,%s>" % ("NN" if m.group(1) == "true" else "NT", "accum+relu'" if m.group(3) == "true" else ("accum" if m.group(2) == "true" else "plain"))
     if "wino_kernel<false>" in n:
         return "conv3_fwd"
     if "wino_kernel<true>" in n:
