@@ -19,7 +19,7 @@
 // NAML step 53 -> 45 and 58 -> 47-50 us, step 0.576 -> 0.555 ms.  Outputs wider than 256 columns (more column blocks re-reading every A
 // strip) stay on the row-strip kernels: N = 768 158 against 133 us at two workgroups per CU.
 // Epilogue kinds: bias + activation (none / ReLU / tanh), or accumulate onto C [+ ReLU' mask from a reference] + column sums.
-// Needs K % 32 == 0, N % 4 == 0, 16-byte aligned rows, A of < 2 GiB, no dropout / live-bit epilogue; everything else stays on the
+// Needs K % 4 == 0 (a partial last k tile reads zeros), N % 4 == 0, 16-byte aligned rows, A of < 2 GiB, no dropout / live-bit epilogue; everything else stays on the
 // row-strip kernels (gemm_ops.hip: launch_rows).  LEGO_ROWS2=0 turns it off (A/B).
 #pragma once
 #include "gemm_epi.hpp"
@@ -49,7 +49,8 @@ __device__ __forceinline__ void rows2_pass(const Rows2Args& w, const EpiArgs& e,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, g4 = lane >> 4;
     const int N = w.N;
-    const int KT = w.K / BK;
+    const int K = w.K;
+    const int KT = (K + BK - 1) / BK;                       // K % 4 == 0; a partial last tile reads zeros past K (offset selects below)
     float* const As0 = lds;
 
     // ---- A fetch stream (branch-free: the k loop is one basic block, hipcc's s_waitcnt vmcnt stays counted)
@@ -63,10 +64,13 @@ __device__ __forceinline__ void rows2_pass(const Rows2Args& w, const EpiArgs& e,
     }
     int fkt = 0;
     f32x4 sa[AN];
+    const int kposA = (tid & 7) * 4;                        // this thread's four reduction indices inside a tile
     auto fetchA = [&]() {
-        const int ko = __builtin_amdgcn_readfirstlane(min(fkt, KT - 1)) * (BK * 4);     // past the last tile: a re-read, never committed to a live stage
+        const int kt_ = __builtin_amdgcn_readfirstlane(min(fkt, KT - 1));               // past the last tile: a re-read, never committed to a live stage
+        const int ko = kt_ * (BK * 4);
+        const bool in = kposA < K - kt_ * BK;               // (all true except in a partial last tile: there the offset becomes kNone -> zeros)
 #pragma unroll
-        for (int j = 0; j < AN; ++j) sa[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, rowo[j], ko, 0));
+        for (int j = 0; j < AN; ++j) sa[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, in ? rowo[j] : kNone, ko, 0));
         ++fkt;
     };
     auto commit = [&](float* A_) {
@@ -82,10 +86,12 @@ __device__ __forceinline__ void rows2_pass(const Rows2Args& w, const EpiArgs& e,
     f32x4 sb0, sb1;
     auto fetchB = [&]() {
         if constexpr (!B_MC) {
-            const int ko = __builtin_amdgcn_readfirstlane(min(bkt, KT - 1)) * (BK * 4);
-            sb0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, vb, ko, 0));
-            sb1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, vb, ko + 64, 0));
-        } else {        // the lane's four reduction indices of a k group are four ROWS of w: eight dword loads per tile (each a 64-byte run per 16 lanes)
+            const int kt_ = __builtin_amdgcn_readfirstlane(min(bkt, KT - 1));
+            const int ko = kt_ * (BK * 4);
+            const int lim = K - kt_ * BK;
+            sb0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, 4 * g4 < lim ? vb : kNone, ko, 0));
+            sb1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, 16 + 4 * g4 < lim ? vb : kNone, ko + 64, 0));
+        } else {        // (rows of w past K are past the descriptor's extent: zeros without a select)        // the lane's four reduction indices of a k group are four ROWS of w: eight dword loads per tile (each a 64-byte run per 16 lanes)
             const int ko = __builtin_amdgcn_readfirstlane(min(bkt, KT - 1)) * BK * ldw4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {

@@ -31,17 +31,17 @@ static int rows2_max_n() {         // wider outputs: more column blocks re-read 
     if (v < 0) { const char* e = getenv("LEGO_ROWS2_MAX_N"); v = e != nullptr ? atoi(e) : 256; }
     return v;
 }
-static int rows2_wgs_per_cu() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("LEGO_ROWS2_WGS"); v = (e != nullptr && atoi(e) > 0) ? atoi(e) : 2; }
-    return v;
+static int rows2_wgs_per_cu(int nblk) {    // workgroups per CU over the launch: 2 (= resident) for one or two column blocks, 3 for more (tools/rows2_check.py:
+    static int v = -1;                       // N = 768 at 2 / 3 / 4 / 6 per CU = 158 / 116 / 132 / 120 us)
+    if (v < 0) { const char* e = getenv("LEGO_ROWS2_WGS"); v = (e != nullptr && atoi(e) > 0) ? atoi(e) : 0; }
+    return v > 0 ? v : (nblk <= 2 ? 2 : 3);
 }
 
 // x [M, K] rows (no row offset), w [N, K] rows; e: C, bias, act, [accumulate is the template kind], relu_ref, colsum
 bool rows2_ok(const float* x, int ldx, const float* w, int ldw, int M_cap, int N, int K, const EpiArgs& e, bool b_mc, bool accum, bool reluref) {
     if (rows2_mode() == 0 || M_cap < rows2_min_rows()) return false;
     if (N > rows2_max_n()) return false;
-    if (K % BK != 0 || (N & 3) != 0 || (ldx & 3) != 0 || (ldw & 3) != 0 || (e.ldc & 3) != 0) return false;
+    if ((K & 3) != 0 || K < 4 || (N & 3) != 0 || (ldx & 3) != 0 || (ldw & 3) != 0 || (e.ldc & 3) != 0) return false;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(e.C)) & 15) return false;
     if (e.bias != nullptr && (reinterpret_cast<uintptr_t>(e.bias) & 15)) return false;
     if (e.drop.p > 0.f || e.rowinfo != nullptr || e.tap_stride != 0) return false;
@@ -60,7 +60,7 @@ int launch_rows2(const float* x, int ldx, const float* w, int ldw, int M_cap, co
     const int nblk = (N + R2_BN - 1) / R2_BN;
     // strips: rows2_wgs_per_cu workgroups per CU over the launch, in groups of 8 strips x nblk column blocks (XCD dealing); never more
     // strips than 16-row groups of the capacity
-    int strips = r2_num_cus() * rows2_wgs_per_cu() / nblk;
+    int strips = r2_num_cus() * rows2_wgs_per_cu(nblk) / nblk;
     const int max_strips = (M_cap + 15) / 16;
     if (strips > max_strips) strips = max_strips;
     strips = (strips + 7) / 8 * 8;

@@ -74,7 +74,8 @@ def test_linear_family_matches_torch():
 
 @pytest.mark.parametrize("nn", [False, True])
 @pytest.mark.parametrize("R,cap,N,K,kind", [(8200, 8200, 256, 256, "tanh"), (9001, 9100, 128, 64, "relu"), (1, 9000, 256, 256, "plain"), (8500, 8500, 260, 96, "nobias"),
-                                            (10000, 30000, 256, 768, "plain"), (113, 8192, 256, 32, "accum"), (27613, 109120, 256, 256, "accum_relu")])
+                                            (10000, 30000, 256, 768, "plain"), (113, 8192, 256, 32, "accum"), (27613, 109120, 256, 256, "accum_relu"),
+                                            (9000, 9100, 256, 300, "plain"), (8200, 8200, 64, 20, "accum"), (8200, 8200, 256, 4, "relu")])
 def test_plain_row_products_two_workgroups_per_cu(R, cap, N, K, kind, nn, monkeypatch):
     """csrc/gemm_rows2.hpp (round 5: B fragments from global memory, two workgroups per CU) through the entry points that dispatch to it --
     lego_linear_fwd (NT: bias, tanh / ReLU) and lego_linear_bwd_data (NN: accumulate, ReLU' reference, column sums) -- against float64,

@@ -95,13 +95,14 @@ if __name__ == "__main__":
     print("LEGO_ROWS2 =", os.environ.get("LEGO_ROWS2", "(default 1)"))
     good = True
     for kw in [dict(R=8200, N=256, K=256, act=2), dict(R=9001, N=128, K=64, cap=9100, act=1), dict(R=1, N=256, K=256, cap=9000), dict(R=8500, N=260, K=96, ldo=264, bias=False),
-               dict(R=10000, N=768, K=256, cap=30000, ldx=260), dict(R=27613, N=256, K=256, cap=109120, act=2), dict(R=113, N=256, K=32, cap=8192)]:
+               dict(R=10000, N=768, K=256, cap=30000, ldx=260), dict(R=27613, N=256, K=256, cap=109120, act=2), dict(R=113, N=256, K=32, cap=8192),
+               dict(R=9000, N=256, K=300, cap=9100), dict(R=8200, N=64, K=20), dict(R=8200, N=256, K=4, act=1)]:
         good &= case(**kw)
-    for kw in [dict(R=27613, N=256, K=256, cap=109120, act=2), dict(R=30700, N=768, K=256, cap=123200), dict(R=30700, N=256, K=256, cap=123200),
+    for kw in [dict(R=27613, N=256, K=256, cap=109120, act=2), dict(R=4500, N=256, K=300, cap=105600), dict(R=30700, N=768, K=256, cap=123200), dict(R=30700, N=256, K=256, cap=123200),
                dict(R=29600, N=768, K=768), dict(R=29600, N=3072, K=768), dict(R=29600, N=768, K=3072)]:
         good &= case(timing=True, **kw)
     for kw in [dict(R=8200, N=256, K=256), dict(R=9001, N=64, K=128, cap=9100, relu=False), dict(R=1, N=256, K=256, cap=9000, accumulate=0, relu=False, colsum=False),
-               dict(R=8500, N=96, K=260, relu=False, colsum=False), dict(R=113, N=32, K=256, cap=8192)]:
+               dict(R=8500, N=96, K=260, relu=False, colsum=False), dict(R=113, N=32, K=256, cap=8192), dict(R=9000, N=300, K=256, cap=9100), dict(R=8200, N=12, K=64)]:
         good &= case_nn(**kw)
     for kw in [dict(R=27613, N=256, K=256, cap=109120), dict(R=30700, N=256, K=256, cap=123200, relu=False, colsum=False),
                dict(R=30700, N=768, K=256, cap=123200, accumulate=0, relu=False, colsum=False)]:
