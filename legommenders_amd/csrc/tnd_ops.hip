@@ -21,7 +21,7 @@ static int tnd_num_cus() {
 // 1.048 -> 1.020 ms; the 256 x 256 / 256 x 300 gradients of NAML are 15-20 % faster alone (45 -> 37 us) but the step is not (its
 // side-stream launches then hold every CU's registers and LDS while the main stream's next kernel waits): they keep the tile kernels;
 // 3072 x 768 (BERT FFN) is 6 % slower (the 64 x 64 wave tiles re-read the operands 48 x 12 times from L2).
-// LEGO_TND_WGS = workgroups aimed at (default 2 per CU), LEGO_TND_MIN_ROWS = smallest reduction it takes
+// LEGO_TND_WGS = workgroups aimed at (default 4 per CU), LEGO_TND_MIN_ROWS = smallest reduction it takes
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e != nullptr ? atoi(e) : dflt; }
 int tnd_mode() { static int v = -1; if (v < 0) v = env_int("LEGO_TND", 1); return v; }
 
@@ -39,7 +39,9 @@ bool tnd_ok(int M, int N, int K_cap, int lda, int ldb, int ldc) {
 int launch_tnd(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int M, int N, int K_cap, const int* k_dyn,
                const int* a_row_off, const int* b_row_off, hipStream_t st, const char* what) {
     static int wgs = -1;
-    if (wgs < 0) wgs = env_int("LEGO_TND_WGS", 2 * tnd_num_cus());
+    // four per CU: at the shapes the dispatch window lets in, 2 per CU is the WORST count (profiles/r05_tnd.txt: 768 x 256 over 30.7 k rows
+    // 106 / 125 / 104 us at 1 / 2 / 4 per CU, 768 x 768 425 / 288 / 266); NRMS step 0.990 -> 0.977-0.981 ms
+    if (wgs < 0) wgs = env_int("LEGO_TND_WGS", 4 * tnd_num_cus());
     const int tm = (M + TND_T - 1) / TND_T, tn = (N + TND_T - 1) / TND_T;
     int split = wgs / (tm * tn);
     const int max_s = (K_cap + 255) / 256;                  // at least 32 reduction rows per wave at capacity
