@@ -256,6 +256,7 @@ class TrainStep:
         self._hist_len = [torch.zeros(B, **i32) for _ in range(2)]
         self.cand, self.hist, self.hist_len = self._cand[0], self._hist[0], self._hist_len[0]
         self.prefetch = str(dev) != "cpu"
+        self._prefetch_at_go = os.environ.get("LEGO_PREFETCH_AT", "neck") == "go"
         if self.prefetch:
             self.engine.enable_plan_slots()
             self.pre = shared_stream(dev, "prefetch")
@@ -393,7 +394,8 @@ class TrainStep:
         _, loss = self.engine.forward(self.cand, self.hist, self.hist_len, training=True, planned=self.prefetch,
                                       fork_ev=go, neck_ev=neck)
         if self.prefetch:
-            self._prefetch(self.batch_idx + 1, neck)       # next batch: starts where this step's item tower ends
+            # next batch: starts where this step's item tower ends (LEGO_PREFETCH_AT=go, A/B: at the head of this step's forward pass instead)
+            self._prefetch(self.batch_idx + 1, go if self._prefetch_at_go else neck)
         self.engine.grad_hooks = self._exchange_hooks() if (last_of_cycle and self.overlap_exchange) else None
         self.engine.backward(self.fp.G)
         self.engine.grad_hooks = None
