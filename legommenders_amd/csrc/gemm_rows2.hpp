@@ -39,6 +39,7 @@ struct Rows2Args {
     const float* x; int ldx; unsigned x_bytes;              // A rows (x_bytes = M_cap * ldx * 4 < 2^31)
     const float* w; int ldw; unsigned w_bytes;              // B: [N][K] rows (NT), or -- B_MC -- [K][N] rows: the reduction index is the ROW (NN products,
     int M_cap; const int* M_dyn; int N, K;                  // data gradients: C = A . W with W as the forward pass holds it)
+    int min_strip;                                          // fewest rows a workgroup takes (live rows / this = strips in use)
 };
 
 template <int NF, bool B_MC, bool ACCUM, bool RELUREF>
@@ -219,7 +220,9 @@ __global__ __launch_bounds__(STRIP_THREADS) __attribute__((amdgpu_waves_per_eu(4
     // (strip, column block) dealing: the nblk blocks of a strip are 8 apart in blockIdx -- round-robin dispatch puts them on one XCD,
     // whose L2 then serves the strip's A rows to all of them
     const int nblk = (w.N + R2_BN - 1) / R2_BN;
-    const int G = max((int)gridDim.x / nblk, 1);
+    // strips: the grid's, but never shorter than min_strip rows -- a launch sized for a capacity with few live rows (the projection over the
+    // ~4.5 k distinct tokens of a batch: capacity 105 k) would otherwise stream the whole B panel through 2 x #CU workgroups of 16 rows each
+    const int G = max(min((int)gridDim.x / nblk, (M + w.min_strip - 1) / w.min_strip), 1);
     const int grp = blockIdx.x / (8 * nblk), in = blockIdx.x % (8 * nblk);
     const int strip = grp * 8 + (in & 7), blk = in >> 3;
     if (strip >= G) return;

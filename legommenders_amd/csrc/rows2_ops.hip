@@ -26,6 +26,11 @@ static int rows2_min_rows() {      // launches sized for fewer rows are latency-
     if (v < 0) { const char* e = getenv("LEGO_ROWS2_MIN_ROWS"); v = e != nullptr ? atoi(e) : 8192; }
     return v;
 }
+static int rows2_min_strip() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("LEGO_ROWS2_MIN_STRIP"); v = (e != nullptr && atoi(e) > 0) ? atoi(e) : 64; }     // 16 / 64 / 112: 17.6 / 16.5 / 23.8 us on the projection over 4.5 k of 105 k rows
+    return v;
+}
 static int rows2_max_n() {         // wider outputs: more column blocks re-read every A strip; measured slower than the row-strip kernels beyond 256
     static int v = -1;                // at two workgroups per CU (tools/rows2_check.py: N = 768 158 against 133 us; 116 at three per CU)
     if (v < 0) { const char* e = getenv("LEGO_ROWS2_MAX_N"); v = e != nullptr ? atoi(e) : 256; }
@@ -56,7 +61,7 @@ bool rows2_ok(const float* x, int ldx, const float* w, int ldw, int M_cap, int N
 int launch_rows2(const float* x, int ldx, const float* w, int ldw, int M_cap, const int* M_dyn, int N, int K, const EpiArgs& e, bool b_mc, bool accum,
                  bool reluref, hipStream_t st, const char* what) {
     Rows2Args a{x, ldx, (unsigned)((unsigned long long)M_cap * (unsigned long long)ldx * 4ull), w, ldw,
-                (unsigned)((unsigned long long)(b_mc ? K : N) * (unsigned long long)ldw * 4ull), M_cap, M_dyn, N, K};
+                (unsigned)((unsigned long long)(b_mc ? K : N) * (unsigned long long)ldw * 4ull), M_cap, M_dyn, N, K, rows2_min_strip()};
     const int nblk = (N + R2_BN - 1) / R2_BN;
     // strips: rows2_wgs_per_cu workgroups per CU over the launch, in groups of 8 strips x nblk column blocks (XCD dealing); never more
     // strips than 16-row groups of the capacity
