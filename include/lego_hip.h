@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LEGO_ABI_VERSION 7
+#define LEGO_ABI_VERSION 8
 #define LEGO_COUNTERS 8
 
 const char* lego_last_error(void);
@@ -110,14 +110,6 @@ int lego_expand_rows(const float* src, int ld_src, const int32_t* inv, int rows_
 int lego_qkv_expand_dropcorr(const float* qkvu, int ldq, const float* eu, int lde, const float* wt, int ldw, const float* bias /*nullable*/,
                              const int32_t* inv, const int32_t* rowinfo, const lego_dropout* drop /*nullable*/, int rows_cap,
                              const int32_t* rows_dyn, int D, int N, float* out, int ldo, void* stream);
-/* ... its data gradient's correction: deu[inv[r], c] -= g[r,:] . wt[c,:] for every coordinate c dropped in token row r (float atomics);
- * deu holds (sum over the key's rows of g) W on entry, and s is applied afterwards (lego_scale_mask_rows) */
-int lego_dropcorr_bwd(const float* g, int ldg, const float* wt, int ldw, const int32_t* inv, const int32_t* rowinfo,
-                      const lego_dropout* drop /*nullable*/, int rows_cap, const int32_t* rows_dyn, int D, int N, float* deu, int ldd,
-                      void* stream);
-/* x[r,:] = live_r ? scale * x[r,:] : 0 (live bit of rowinfo[r]) */
-int lego_scale_mask_rows(float* x, int ld, int rows_cap, const int32_t* rows_dyn, int width, const int32_t* rowinfo, float scale,
-                         void* stream);
 /* out[u,:] = sum over rows r with inv[r] == u of g[r,:] (u < U; perm = the rows grouped by inv): the per-token sums the
  * projection's weight gradient is formed from.  out[0:U] must be zero on entry: zero_first = 1 clears it here, 0 = the caller
  * has (lego_zero_rows, e.g. on another stream ahead of time). */
@@ -184,12 +176,14 @@ int lego_conv3_wino_unpack_add(float* du /*[S,4,Dout,Din]*/, int n_slabs, float*
 int lego_conv3_wino_fwd(const float* h, int ldh, const float* u, const float* bias, const int32_t* pair_info,
                         int P_cap, const int32_t* P_dyn, float* y, int ldy, int Dout, int Din,
                         const lego_dropout* drop, void* stream);
-int lego_conv3_wino_bwd_data(const float* gy, int ldg, const float* u, const float* ut /*nullable: reads ut instead of u*/,
+int lego_conv3_wino_bwd_data(const float* gy, int ldg, const float* u, const float* ut /*required (ABI 8): the transposed sets*/,
                              const int32_t* pair_info,
                              int P_cap, const int32_t* P_dyn, float* dh, int lddh, int Dout, int Din,
                              const lego_dropout* drop_in, float* colsum, void* stream);
+/* n_slabs = the S the caller sized du for (lego_conv3_wino_du_slabs at that time): a launch that would write another number of slabs
+ * -- the process-wide product mode changed in between -- is refused (ABI 8) */
 int lego_conv3_wino_bwd_weight(const float* gy, int ldg, const float* h, int ldh, const int32_t* pair_info,
-                               int P_cap, const int32_t* P_dyn, float* du /*[S,4,Dout,Din]*/, int Dout, int Din, void* stream);
+                               int P_cap, const int32_t* P_dyn, float* du /*[S,4,Dout,Din]*/, int n_slabs, int Dout, int Din, void* stream);
 int lego_conv3_fwd(const float* h, int ldh, const float* wt, const float* bias, const int32_t* rowinfo,
                    float* y, int ldy, int R_cap, const int32_t* R_dyn, int Dout, int Din,
                    const lego_dropout* drop, int mask_rows /*0: every row is live (ragged plan), skip the live-bit loads*/,
@@ -299,13 +293,6 @@ int lego_attn_fold_grads(const float* Wo, const float* bo, const float* Wl, cons
                          const float* bc, const float* Tp, const float* sp, float* T, float* s,
                          float* gWo, float* gbo, float* gWl, float* gbl, float* gW1, float* gb1,
                          int D, int A, void* stream);
-
-/* out_a[rows_a, N] += S_a[rows_a, K] . W[K, N] and out_b[rows_b, N] += S_b[rows_b, K] . W[K, N] (row-major, W with leading
- * dimension N, S with K) in ONE launch: a few rows through a weight matrix.  Engine use: the [SEP] / category gradients of
- * ConcatInputer's small tables (concat_inputer.py:96-114) from the row sums of d(qkv) that lego_nrms_special_grads produces when it
- * is run on d(qkv) instead of d(E): sum_r dE[r] = (sum_r dqkv[r]) . W_in. */
-int lego_small_rows_matmul_add(const float* S_a, int rows_a, float* out_a, int ld_a, const float* S_b, int rows_b, float* out_b,
-                               int ld_b, const float* W, int K, int N, void* stream);
 
 /* NRMS user head of a TRAINING step in one launch (engine route, folded attention block): user vector from the pooled attention
  * output (u = Wc p + bc: attention_operator.py:52-56 with the two affine layers folded), DotPredictor over the C candidates

@@ -22,7 +22,7 @@ U64 = ctypes.c_uint64
 U32 = ctypes.c_uint32
 
 
-ABI_VERSION = 7      # == LEGO_ABI_VERSION of include/lego_hip.h this binding was written against
+ABI_VERSION = 8      # == LEGO_ABI_VERSION of include/lego_hip.h this binding was written against
 
 
 class LegoDropout(ctypes.Structure):
@@ -39,7 +39,6 @@ SIGNATURES = {
     "lego_nrms_decode_keys": [P, I, P, I, P, P, P, P, P],
     "lego_nrms_special_grads": [P, I, P, P, P, I, I, P, P, I, I, P],
     "lego_mask_dropout_rows": [P, I, I, P, I, P, P, P, P],
-    "lego_small_rows_matmul_add": [P, I, P, I, P, I, P, I, P, I, I, P],
     "lego_nrms_user_head_train": [P, I, P, P, P, I, I, I, I, F, P, I, P, P, P, I, P, I, P, I, P, P],
     "lego_attn_fold_prepare": [P, P, P, P, P, P, P, P, P, P, I, I, P],
     "lego_attn_fold_grads": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P],
@@ -48,8 +47,6 @@ SIGNATURES = {
     "lego_sort_rows": [P, I, P, P, P, I64, P],
     "lego_expand_rows": [P, I, P, I, P, I, P, P, P, I, P, P, I, P, P, I, P],
     "lego_qkv_expand_dropcorr": [P, I, P, I, P, I, P, P, P, P, I, P, I, I, P, I, P],
-    "lego_dropcorr_bwd": [P, I, P, I, P, P, P, I, P, I, I, P, I, P],
-    "lego_scale_mask_rows": [P, I, I, P, I, P, F, P],
     "lego_segment_sum_rows": [P, I, I, P, P, I, P, P, P, I, I, P, I, P, P, P],
     "lego_zero_rows": [P, I, I, I, P, P],
     "lego_scatter_add_rows_range": [P, I, I, P, I, P, P, I, I, I, P],
@@ -65,7 +62,7 @@ SIGNATURES = {
     "lego_conv3_wino_unpack_add": [P, I, P, I, I, P],
     "lego_conv3_wino_fwd": [P, I, P, P, P, I, P, P, I, I, I, P, P],
     "lego_conv3_wino_bwd_data": [P, I, P, P, P, I, P, P, I, I, I, P, P, P],
-    "lego_conv3_wino_bwd_weight": [P, I, P, I, P, I, P, P, I, I, P],
+    "lego_conv3_wino_bwd_weight": [P, I, P, I, P, I, P, P, I, I, I, P],
     "lego_conv3_fwd": [P, I, P, P, P, P, I, I, P, I, I, P, I, P],
     "lego_conv3_bwd_data": [P, I, P, P, P, I, I, P, I, I, P, P, I, P],
     "lego_conv3_bwd_weight": [P, I, P, I, P, P, I, P, I, I, P],

@@ -16,9 +16,9 @@ tensors.  Published algorithm of the third-party package (transformers modeling_
 BertSelfOutput, BertIntermediate, BertOutput; pinned through the reference-generated fixtures tests/golden/bert_naml_*.npz and the
 test suite's CPU restatement of a BERT block).  Measured against the HF route: DESIGN.md section 5 (config 5 table).
 
-Where PyTorch-ROCm's hipBLASLt is used instead of the path's kernel: nowhere by default.  `tools/bert_shapes_bench.py` has the
-per-shape comparison (forward / data-gradient products: hipBLASLt 0-15 % faster at the FFN shapes; weight gradients: the path's
-TN kernel 1.6x faster); `LEGO_BERT_BLAS=1` routes the forward and data-gradient products of the FFN through torch (A/B switch).
+Where PyTorch-ROCm's hipBLASLt is used instead of the path's kernel: nowhere.  `tools/bert_shapes_bench.py` has the per-shape
+comparison (forward / data-gradient products: hipBLASLt 0-15 % faster at the FFN shapes; weight gradients: the path's TN kernel
+1.6x faster); the round-4 A/B hook that routed the FFN products through torch was removed in round 6.
 """
 from __future__ import annotations
 
@@ -39,7 +39,6 @@ LAYER_KEYS = ("attention.self.query.weight", "attention.self.query.bias", "atten
               "output.dense.weight", "output.dense.bias", "output.LayerNorm.weight", "output.LayerNorm.bias")
 EMBED_KEYS = ("position_embeddings.weight", "token_type_embeddings.weight", "LayerNorm.weight", "LayerNorm.bias")
 NL = len(LAYER_KEYS)
-USE_BLAS = os.environ.get("LEGO_BERT_BLAS", "0") == "1"
 
 
 def supported(transformer, L: int) -> Optional[str]:
@@ -114,9 +113,6 @@ def _lin_fwd(x, W, b, out, ldo, col=0, tag=None):
     M, Kd = x.shape
     N = W.shape[0]
     with _timed(tag, 2.0 * M * N * Kd):
-        if USE_BLAS and ldo == N and col == 0 and N * Kd >= 768 * 3072:
-            torch.addmm(b, x, W.t(), out=out)
-            return
         call("lego_linear_fwd", _ptr(x), Kd, _ptr(W), Kd, _ptr(b), _ptr(out, col), ldo, M, None, N, Kd, 0, None, None, None, None, _stream())
 
 
@@ -125,9 +121,6 @@ def _lin_bwd_data(g, ldg, col, W, dx, accumulate, tag=None):
     M = dx.shape[0]
     N, Kd = W.shape
     with _timed(tag, 2.0 * M * N * Kd):
-        if USE_BLAS and ldg == N and col == 0 and not accumulate and N * Kd >= 768 * 3072:
-            torch.mm(g, W, out=dx)
-            return
         call("lego_linear_bwd_data", _ptr(g, col), ldg, _ptr(W), Kd, _ptr(dx), Kd, M, None, N, Kd, 1 if accumulate else 0,
              None, 0, 1.0, None, None, None, None, None, _stream())
 

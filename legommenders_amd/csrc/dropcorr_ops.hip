@@ -14,8 +14,8 @@
 // would not beat the dense one: dW stays d(qkv)^T E over the rows (side stream).
 //
 //   lego_qkv_expand_dropcorr   q|k|v rows from the per-key product:  out_r = tok_r ? s (Q_k - corr_r) + b : Q_k + b
-//   lego_dropcorr_bwd          dEu[k][c] -= g_r . W[:, c]  for every dropped coordinate c of every token row r of key k
-//   lego_scale_mask_rows       x_r = live_r ? scale x_r : 0   (the per-key gradient rows that go on into the projection)
+// (Round 5 also built the data gradient's per-key form -- per-key sums of d(qkv), a product over the keys and a correction kernel whose
+// atomics queued on the Zipf head's rows: 620 us against 130 for the row form; removed in round 6, DESIGN.md section 11.4 has the record.)
 #include <stdlib.h>
 #include "../../include/lego_hip.h"
 #include "common.hpp"
@@ -188,79 +188,6 @@ __global__ __launch_bounds__(DC_THREADS) void qkv_expand_dropcorr_kernel(
     }
 }
 
-// dEu[inv[r]][c] -= sum_j g[r][cb + j] W^T[c][cb + j]  (j over this workgroup's 128-column slice) for the dropped coordinates c of the
-// token rows of a strip.  Lane = ONE dropped coordinate of the row (compacted list, up to 64 per turn); the row's slice of g sits
-// in LDS (broadcast reads), the W^T slice with a padded row stride (lanes on different rows c: the 16-lane groups of a
-// ds_read_b128 then spread over the banks)
-constexpr int DC_WLD = DC_CB + 4;
-__global__ __launch_bounds__(DC_THREADS) void dropcorr_bwd_kernel(
-    const float* __restrict__ g, int ldg, const float* __restrict__ wt, int ldw, const int* __restrict__ inv, const int* __restrict__ rowinfo,
-    const uint8_t* __restrict__ mask, int rows_cap, const int* __restrict__ rows_dyn, int D, int N, float* __restrict__ deu, int ldd, int strips) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const wl = smem;                                      // [D][DC_WLD]
-    float* const gl = smem + D * DC_WLD;                         // [waves][DC_CB]
-    int* const cl = reinterpret_cast<int*>(gl + DC_WAVES * DC_CB);   // [waves][256] compacted coordinates
-    const int rows = rows_dyn != nullptr ? min(rows_cap, *rows_dyn) : rows_cap;
-    const int nblk = (N + DC_CB - 1) / DC_CB;
-    const int blk = blockIdx.x % nblk, strip = blockIdx.x / nblk;
-    const int cb = blk * DC_CB;
-    const int per = (rows + strips - 1) / strips;
-    const int r0 = strip * per, r1 = min(rows, r0 + per);
-    if (r0 >= r1) return;
-    stage_wt(wt, ldw, D, cb, N, wl, DC_WLD);
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    float* const gw = gl + wave * DC_CB;
-    int* const cw = cl + wave * 256;
-    for (int r = r0 + wave; r < r1; r += DC_WAVES) {
-        if ((rowinfo[r] & RI_LIVE) == 0) continue;               // wave-uniform: [SEP] / category rows carry no Dropout
-        const int k = inv[r];
-        const uint32_t kw = keep_word(mask, r, D, lane);
-        // compacted list of the dropped coordinates (order: coordinate j of lane l -> all j = 0 first)
-        int n = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool d = ((kw >> (8 * j)) & 1u) == 0u;
-            const unsigned long long m = __ballot(d);
-            if (d) cw[n + __popcll(m & ((1ull << lane) - 1ull))] = 4 * lane + j;
-            n += __popcll(m);
-        }
-        {   // this wave's slice of the row's gradient: 128 floats = 2 per lane
-            const int col = cb + 2 * lane;
-            f32x2_t g2 = f32x2_t{0.f, 0.f};
-            if (col < N) g2 = *reinterpret_cast<const f32x2_t*>(g + (size_t)r * ldg + col);
-            *reinterpret_cast<f32x2_t*>(gw + 2 * lane) = g2;
-        }
-        // (the list and the gradient slice are written and read by this wave only: LDS operations of one wave complete in order)
-        for (int base = 0; base < n; base += 64) {
-            const bool on = base + lane < n;
-            const int c = on ? cw[base + lane] : 0;
-            const float* wr = wl + c * DC_WLD;
-            float dot = 0.f;
-#pragma unroll 8
-            for (int j = 0; j < DC_CB; j += 4) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + j);
-                const f32x4 gv = *reinterpret_cast<const f32x4*>(gw + j);
-                dot += wv[0] * gv[0] + wv[1] * gv[1] + wv[2] * gv[2] + wv[3] * gv[3];
-            }
-            if (on) atomicAdd(deu + (size_t)k * ldd + c, -dot);
-        }
-    }
-}
-
-__global__ void scale_mask_rows_kernel(float* x, int ld, int rows_cap, const int* __restrict__ rows_dyn, int width, const int* __restrict__ rowinfo,
-                                       float scale) {
-    const int rows = rows_dyn != nullptr ? min(rows_cap, *rows_dyn) : rows_cap;
-    const long long total = (long long)rows * (width / 4);
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const int r = (int)(e / (width / 4)), c = (int)(e % (width / 4)) * 4;
-        f32x4* p = reinterpret_cast<f32x4*>(x + (size_t)r * ld + c);
-        const bool live = (rowinfo[r] & RI_LIVE) != 0;
-        *p = live ? *p * scale : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-}
-
 static int dc_cus() {
     static int n = 0;
     if (n == 0) {
@@ -304,34 +231,3 @@ extern "C" int lego_qkv_expand_dropcorr(const float* qkvu, int ldq, const float*
     return check_launch("lego_qkv_expand_dropcorr");
 }
 
-extern "C" int lego_dropcorr_bwd(const float* g, int ldg, const float* wt, int ldw, const int32_t* inv, const int32_t* rowinfo,
-                                 const lego_dropout* drop, int rows_cap, const int32_t* rows_dyn, int D, int N, float* deu, int ldd, void* stream) {
-    LEGO_REQUIRE((D & 3) == 0 && D <= 256 && (N & 1) == 0 && (ldg & 1) == 0 && (ldw & 3) == 0,
-                 "lego_dropcorr_bwd: D=%d (multiple of 4, <= 256), N=%d and the row strides must be even / multiples of 4", D, N);
-    LEGO_REQUIRE(inv != nullptr && rowinfo != nullptr, "lego_dropcorr_bwd: inv and rowinfo are required");
-    if (rows_cap <= 0 || drop == nullptr || drop->p <= 0.f) return 0;          // nothing was dropped: no correction
-    LEGO_REQUIRE(drop->mask != nullptr, "lego_dropcorr_bwd: the dropout site needs its precomputed keep bits (lego_dropout_mask)");
-    const int nblk = (N + DC_CB - 1) / DC_CB;
-    int strips = dc_cus() / nblk;
-    if (strips < 1) strips = 1;
-    const size_t lds = ((size_t)D * DC_WLD + (size_t)DC_WAVES * DC_CB) * sizeof(float) + (size_t)DC_WAVES * 256 * sizeof(int);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dropcorr_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(((size_t)256 * DC_WLD + (size_t)DC_WAVES * DC_CB) * sizeof(float) + (size_t)DC_WAVES * 256 * sizeof(int)));
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(dropcorr_bwd_kernel, dim3(nblk * strips), dim3(DC_THREADS), lds, (hipStream_t)stream, g, ldg, wt, ldw, inv, rowinfo, drop->mask,
-                       rows_cap, rows_dyn, D, N, deu, ldd, strips);
-    return check_launch("lego_dropcorr_bwd");
-}
-
-extern "C" int lego_scale_mask_rows(float* x, int ld, int rows_cap, const int32_t* rows_dyn, int width, const int32_t* rowinfo, float scale,
-                                    void* stream) {
-    LEGO_REQUIRE((width & 3) == 0 && (ld & 3) == 0 && rowinfo != nullptr, "lego_scale_mask_rows: width=%d ld=%d must be multiples of 4, rowinfo is required", width, ld);
-    if (rows_cap <= 0) return 0;
-    const long long tot = (long long)rows_cap * (width / 4);
-    hipLaunchKernelGGL(scale_mask_rows_kernel, dim3((int)((tot + 255) / 256 < 2048 ? (tot + 255) / 256 : 2048)), dim3(256), 0, (hipStream_t)stream, x, ld,
-                       rows_cap, rows_dyn, width, rowinfo, scale);
-    return check_launch("lego_scale_mask_rows");
-}

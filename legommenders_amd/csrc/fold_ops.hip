@@ -144,20 +144,6 @@ extern "C" int lego_attn_fold_grads(const float* Wo, const float* bo, const floa
     return launch_level(M, st, "lego_attn_fold_grads");
 }
 
-// [SEP] / category gradients of ConcatInputer's small tables taken one product early (engine.py, NRMS GloVe variant): the row sums
-// S_sep[K3], S_cat[n_cat][K3] of d(qkv) at the [SEP] / category positions (lego_nrms_special_grads on d(qkv)) map through the
-// in-projection weight: g_sep += S_sep W_in, g_cat += S_cat W_in  -- one launch (the generic product entry point spent 36 us on each).
-extern "C" int lego_small_rows_matmul_add(const float* S_a, int rows_a, float* out_a, int ld_a, const float* S_b, int rows_b, float* out_b,
-                                          int ld_b, const float* W, int K, int N, void* stream) {
-    LEGO_REQUIRE(K > 0 && N > 0 && rows_a >= 0 && rows_b >= 0, "lego_small_rows_matmul_add: K=%d N=%d rows=%d,%d", K, N, rows_a, rows_b);
-    FoldLevel L{};
-    L.n_gemm = 0;
-    if (rows_a > 0) L.g[L.n_gemm++] = FoldGemm{S_a, K, 1, W, N, 1, out_a, ld_a, nullptr, nullptr, nullptr, rows_a, N, K, 0};
-    if (rows_b > 0) L.g[L.n_gemm++] = FoldGemm{S_b, K, 1, W, N, 1, out_b, ld_b, nullptr, nullptr, nullptr, rows_b, N, K, 0};
-    if (L.n_gemm == 0) return 0;
-    return launch_level(L, (hipStream_t)stream, "lego_small_rows_matmul_add");
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------
 // NRMS user "head" of a training step in one launch (fold level 2): the user vector from the pooled attention output, the dot
 // predictor, CrossEntropy(label 0) and their backward down to the pooled vector --

@@ -38,10 +38,9 @@ int launch_tnd(const float* a, int lda, const float* b, int ldb, float* c, int l
 
 
 }  // namespace lego
-#include "gemm_wino.hpp"
+#include "wino_common.hpp"
 #include "gemm_tn.hpp"
 #include "gemm_dma.hpp"
-#include "gemm_wino_dma.hpp"
 namespace lego {
 
 static Epi make_epi(float* C, int ldc) {
@@ -50,9 +49,7 @@ static Epi make_epi(float* C, int ldc) {
     e.drop = make_dropout(nullptr); e.drop_cols = 1;
     e.relu_ref = nullptr; e.ld_ref = 0; e.relu_scale = 1.f; e.colsum = nullptr;
     e.tap_stride = 0; e.row_off_dyn = nullptr; e.M = e.N = e.row_off = 0;
-    static int rows_form = -1;
-    if (rows_form < 0) { const char* v = getenv("LEGO_EPI_ROWS"); rows_form = (v != nullptr && v[0] >= '0' && v[0] <= '3') ? v[0] - '0' : 1; }
-    e.rows_form = rows_form;
+    e.rows_form = 1;
     return e;
 }
 static void set_drop(Epi& e, const lego_dropout* d, int cols) {
@@ -119,18 +116,10 @@ static int launch_strip(const GemmDims& d, const AL& a, const BL& b, const Epi& 
 }
 
 // the same split with LDS-DMA operand staging (gemm_dma.hpp): plain-row operands only
-static int dma_waves() {           // LEGO_DMA_WAVES=4: one wave per SIMD (4 x 4 column fragments, up to 512 registers); default 8
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("LEGO_DMA_WAVES"); v = (e != nullptr && e[0] == '4') ? 4 : 8; }
-    return v;
-}
-
 template <bool B_MC, class EK, class BL, int NW = 8>
 static int launch_dma_strip(const GemmDims& d, const KcRows& a, const BL& b, const Epi& e0, hipStream_t st, const char* what) {
     LEGO_REQUIRE(d.K >= 4 && d.K % 4 == 0 && a.ld % 4 == 0 && b.ld % 4 == 0,
                  "%s: the LDS-DMA row-strip kernel needs K %% 4 == 0 and 16-byte-aligned rows (K=%d, lda=%d, ldb=%d)", what, d.K, a.ld, b.ld);
-    if constexpr (NW == 8)
-        if (dma_waves() == 4) return launch_dma_strip<B_MC, EK, BL, 4>(d, a, b, e0, st, what);
     EK e;
     static_cast<EpiArgs&>(e) = e0;
 #ifdef LEGO_TUNING_HOOKS
@@ -152,46 +141,14 @@ static int launch_dma_strip(const GemmDims& d, const KcRows& a, const BL& b, con
     return check_launch(what);
 }
 
-static int dma_mode() {            // A/B switch (tuning): LEGO_DMA=0 keeps the register-staged row-strip kernel
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("LEGO_DMA"); v = (e != nullptr && e[0] == '0') ? 0 : 1; }
-    return v;
-}
-
-// small latency-bound products: every load of a 64 x 64 x K block in flight at once (gemm_oneshot.hpp)
-template <bool B_MC, class EK, class AL, class BL>
-static int launch_oneshot(const GemmDims& d, const AL& a, const BL& b, const Epi& e0, hipStream_t st, const char* what) {
-    EK e;
-    static_cast<EpiArgs&>(e) = e0;
-    auto k = oneshot_kernel<B_MC, AL, BL, EK>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)oneshot_lds_bytes<B_MC>(ONE_KMAX));
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(k, dim3((d.M + ONE_BM - 1) / ONE_BM, (d.N + ONE_BN - 1) / ONE_BN), dim3(ONE_THREADS),
-                       oneshot_lds_bytes<B_MC>(d.K < ONE_KMAX ? d.K : ONE_KMAX), st, d, a, b, e);
-    return check_launch(what);
-}
-
-static int light_mode() {          // A/B switch (tuning): LEGO_LIGHT=0 keeps the one-shot kernel for every small product
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("LEGO_LIGHT"); v = (e != nullptr && e[0] == '0') ? 0 : 1; }
-    return v;
-}
-
+// small latency-bound products (gemm_oneshot.hpp: light_kernel): one wave per 16 x 32 outputs, every load of the wave in flight at once
 template <bool B_MC, class EK, class AL, class BL>
 static int launch_light(const GemmDims& d, const AL& a, const BL& b, const Epi& e0, hipStream_t st, const char* what) {
     EK e;
     static_cast<EpiArgs&>(e) = e0;
     // k groups of 16 in flight per wave: 4 (84-92 VGPRs; a K = 256 product is four dependent round trips) against 2 (56-68 VGPRs, eight):
-    // NAML 0.6297 -> 0.6244 ms, NRMS 1.0363 -> 1.0328 ms (three alternating same-box runs each; 8 groups, 136 VGPRs: no further gain).
-    // LEGO_LIGHT_U=2 keeps the shallower form (A/B).
-    static int u = -1;
-    if (u < 0) { const char* v = getenv("LEGO_LIGHT_U"); u = (v != nullptr && v[0] == '2') ? 2 : 4; }
-    if (u == 2) hipLaunchKernelGGL((light_kernel<B_MC, AL, BL, EK, 2>), dim3((d.M + 15) / 16, (d.N + 31) / 32), dim3(64), 0, st, d, a, b, e);
-    else hipLaunchKernelGGL((light_kernel<B_MC, AL, BL, EK, 4>), dim3((d.M + 15) / 16, (d.N + 31) / 32), dim3(64), 0, st, d, a, b, e);
+    // NAML 0.6297 -> 0.6244 ms, NRMS 1.0363 -> 1.0328 ms (three alternating same-box runs each; 8 groups, 136 VGPRs: no further gain)
+    hipLaunchKernelGGL((light_kernel<B_MC, AL, BL, EK, 4>), dim3((d.M + 15) / 16, (d.N + 31) / 32), dim3(64), 0, st, d, a, b, e);
     return check_launch(what);
 }
 
@@ -239,14 +196,11 @@ static int launch_rows(const GemmDims& d, const AL& a, const BL& b, const Epi& e
         if (d.N > 64) return launch<C128x128s, false, B_MC, EK, true>(d, a, b, e, tm, (d.N + 127) / 128, 1, st, what);
         return launch<C128x64, false, B_MC, EK, true>(d, a, b, e, tm, (d.N + 63) / 64, 1, st, what);
     }
-    // LEGO_STRIP_MAXK (tuning): reductions at least this long skip the row-strip kernels and take the 128 x 128 tile kernel
-    static int strip_maxk = -1;
-    if (strip_maxk < 0) { const char* e = getenv("LEGO_STRIP_MAXK"); strip_maxk = e != nullptr ? atoi(e) : (1 << 30); }
-    if (d.M >= 32 * num_cus() && d.N <= 4 * STRIP_BN && d.K < strip_maxk) {
+    if (d.M >= 32 * num_cus() && d.N <= 4 * STRIP_BN) {
         if constexpr (std::is_same<AL, KcRows>::value && (std::is_same<BL, KcRows>::value || std::is_same<BL, McRows>::value))
             // the DMA staging moves 16-byte chunks clamped to K - 4 and zeroes tails at 4-element granularity: K % 4 == 0 and
             // 16-byte-aligned rows on both sides, else the register-staged strip kernel
-            if (dma_mode() && d.K >= 4 && d.K % 4 == 0 && a.ld % 4 == 0 && b.ld % 4 == 0 && (!B_MC || d.N % 4 == 0))
+            if (d.K >= 4 && d.K % 4 == 0 && a.ld % 4 == 0 && b.ld % 4 == 0 && (!B_MC || d.N % 4 == 0))
                 return launch_dma_strip<B_MC, EK>(d, a, b, e, st, what);
         return launch_strip<B_MC, EK>(d, a, b, e, st, what);
     }
@@ -254,8 +208,7 @@ static int launch_rows(const GemmDims& d, const AL& a, const BL& b, const Epi& e
         if (d.K <= 4 * ONE_KMAX && d.K % 4 == 0 &&
             ((d.M + ONE_BM - 1) / ONE_BM) * ((d.N + ONE_BN - 1) / ONE_BN) <= 3 * num_cus()) { // few rounds of whole-CU blocks by
                                                                                               // CAPACITY: the user side fills 40 %
-            if (light_mode()) return launch_light<B_MC, EK>(d, a, b, e, st, what);
-            return launch_oneshot<B_MC, EK>(d, a, b, e, st, what);
+            return launch_light<B_MC, EK>(d, a, b, e, st, what);
         }
     if (tm * ((d.N + 127) / 128) < 128) {         // few row tiles (user / category side): 64-row tiles fill more CUs
         if (d.N > 64) return launch<C64x128, false, B_MC, EK>(d, a, b, e, (d.M + 63) / 64, (d.N + 127) / 128, 1, st, what);
@@ -275,16 +228,13 @@ static int pick_split_small(int rows_cap, int M, int N, int small_target = 4096)
     const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
     // Outputs of several hundred tiles (BERT's 768 x 3072 FFN weights: 576) take ~2 300 workgroups --
     // 1024 / 576 floors to 1 and leaves 44 % of the workgroup slots empty; more, shorter workgroups also hide each other's load
-    // latency (LEGO_TN_SPLIT overrides: tuning)
-    static int forced = -1;
-    if (forced < 0) { const char* e = getenv("LEGO_TN_SPLIT"); forced = e != nullptr ? atoi(e) : 0; }
+    // latency
     // measured on [3072 x 768] over 29.6 k rows (tools/bert_shapes_bench.py): split 1 / 2 / 3 / 4 / 8 = 82 / 98 / 104 / 107 / 105 TFLOP/s
     // small outputs: ~4096 SHORT workgroups rather than ~1024 long ones.  Alone the launch is no faster (more atomics), but these products
     // run on the side stream next to the main chain's latency-bound kernels, which can only start on a CU when a workgroup retires:
     // NRMS step 1.035 -> 1.025 ms with the in-projection weight gradient (48 tiles) at 80-128 splits instead of 16, NAML unchanged
     // (tools/r04_tnsplit.sh, two alternating same-box runs)
     int s = tiles > 256 ? (2304 + tiles - 1) / tiles : small_target / tiles;
-    if (forced > 0) s = forced;
     const int max_s = (rows_cap + 127) / 128;       // at least 128 reduction rows per block
     if (s > max_s) s = max_s;
     if (s >= 16) s &= ~7;                           // a multiple of 8: the k splits can then be dealt to the 8 XCDs (gemm_tn.hpp)
@@ -480,49 +430,17 @@ extern "C" int lego_conv3_bwd_weight(const float* gy, int ldg, const float* h, i
 }
 
 
-// ---- Winograd F(2,3) form of the conv over row pairs (gemm_wino.hpp)
-static int launch_wino_dma(const WinoArgs& w, const Epi& e, hipStream_t st, const char* what) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)wino_dma_lds_bytes());
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(wino_dma_kernel, dim3(num_cus() / 16 * 16), dim3(STRIP_THREADS), wino_dma_lds_bytes(), st, w, e);
-    return check_launch(what);
-}
-
-// LEGO_WINO_DMA=1 selects the LDS-DMA form of the Winograd kernel (gemm_wino_dma.hpp).  It is exact (same differences to the
-// direct conv as wino_kernel) and measured SLOWER: 91.6 vs 78.9 us forward, 93.3 vs 81.3 us data gradient on 23 k rows
-// (tools/wino_check.py) -- two LDS reads + a packed add per A fragment, 256 VGPRs with 25 spills -- so the register-staged
-// kernel stays the default.
-static int wino_dma_mode() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("LEGO_WINO_DMA"); v = (e != nullptr && e[0] == '1') ? 1 : 0; }
-    return v;
-}
-
-// round 5: gemm_wino2.hpp (wino2_ops.hip) -- weight fragments straight from global memory, staggered wave halves, row-major epilogue
+// ---- Winograd F(2,3) form of the conv over row pairs (wino_common.hpp; kernel: gemm_wino2.hpp / wino2_ops.hip -- weight fragments
+// straight from global memory, branch-free A staging through buffer descriptors, row-major epilogue)
 namespace lego {
-bool wino2_ok(const WinoArgs& w, const EpiArgs& e);
+const char* wino2_why_not(const WinoArgs& w, const EpiArgs& e);
 int launch_wino2(const WinoArgs& w, const EpiArgs& e, hipStream_t st, const char* what);
 }
 
-template <bool B_MC>
 static int launch_wino(const WinoArgs& w, const Epi& e, hipStream_t st, const char* what) {
-    if constexpr (!B_MC) {
-        if (wino_dma_mode()) return launch_wino_dma(w, e, st, what);
-        if (wino2_ok(w, e)) return launch_wino2(w, e, st, what);
-    }
-    auto k = wino_kernel<B_MC>;
-    constexpr size_t lds = wino_lds_bytes<B_MC>();
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(k, dim3(num_cus() / 16 * 16), dim3(STRIP_THREADS), lds, st, w, e);   // (strip, half) dealing needs a multiple of 16
-    return check_launch(what);
+    const char* why = wino2_why_not(w, e);
+    LEGO_REQUIRE(why == nullptr, "%s: %s (the direct three-tap entry points lego_conv3_* take every shape)", what, why);
+    return launch_wino2(w, e, st, what);
 }
 
 extern "C" int lego_conv3_wino_fwd(const float* h, int ldh, const float* u, const float* bias, const int32_t* pair_info,
@@ -535,7 +453,7 @@ extern "C" int lego_conv3_wino_fwd(const float* h, int ldh, const float* u, cons
     Epi e = make_epi(y, ldy);
     e.bias = bias; e.act = 1;
     set_drop(e, drop, Dout);
-    return launch_wino<false>(w, e, (hipStream_t)stream, "lego_conv3_wino_fwd");
+    return launch_wino(w, e, (hipStream_t)stream, "lego_conv3_wino_fwd");
 }
 
 extern "C" int lego_conv3_wino_bwd_data(const float* gy, int ldg, const float* u, const float* ut, const int32_t* pair_info,
@@ -547,36 +465,27 @@ extern "C" int lego_conv3_wino_bwd_data(const float* gy, int ldg, const float* u
     Epi e = make_epi(dh, lddh);
     e.colsum = colsum;
     set_drop(e, drop_in, Din);
-    if (ut != nullptr) {         // transposed sets: the weight panel is K-contiguous like the forward's
-        WinoArgs w{gy, ldg, ut, Dout, Din, pair_info, P_cap, P_dyn, 1};
-        return launch_wino<false>(w, e, (hipStream_t)stream, "lego_conv3_wino_bwd_data");
-    }
-    WinoArgs w{gy, ldg, u, Dout, Din, pair_info, P_cap, P_dyn, 1};
-    return launch_wino<true>(w, e, (hipStream_t)stream, "lego_conv3_wino_bwd_data");
-}
-
-// LEGO_CONVW_64=<split> (tuning): the conv weight gradient on 64 x 64 tiles, four workgroups per CU, <split> slabs -- the
-// configuration that took the plain-row weight gradients from 63 to 100 TFLOP/s (more, shorter workgroups hide each other's loads).
-// MEASURED SLOWER for the pair operands (round 4, same box, bench.py --steps 200): 126-138 us against 111-114 us for the 128 x 128
-// one-workgroup-per-CU kernel (step 0.649-0.655 vs 0.631 ms) -- every workgroup re-reads and re-combines its pair rows, and 64-wide
-// tiles double that traffic (~900 MB of L2 reads per launch).  Off by default; kept as the record.
-static int convw64_split() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("LEGO_CONVW_64"); v = e != nullptr ? atoi(e) : 0; }
-    return v;
+    LEGO_REQUIRE(ut != nullptr, "lego_conv3_wino_bwd_data: needs the transposed weight sets `ut` (lego_conv3_wino_pack writes both)");
+    (void)u;
+    WinoArgs w{gy, ldg, ut, Dout, Din, pair_info, P_cap, P_dyn, 1};      // transposed sets: the weight panel is K-contiguous like the forward's
+    return launch_wino(w, e, (hipStream_t)stream, "lego_conv3_wino_bwd_data");
 }
 
 extern "C" int lego_conv3_wino_du_slabs(int Dout, int Din, int P_cap) {
     if (P_cap < TN_LONG) return 1;                  // short reductions accumulate with atomics into ONE cleared buffer
     if (product_mode() == 0 && tndp_slabs(Dout, Din, P_cap) > 0) return tndp_slabs(Dout, Din, P_cap);      // round 5: gemm_tnd.hpp
-    if (convw64_split() > 1) return convw64_split();
     return tn_split(Dout, Din, P_cap, 4);
 }
 
 extern "C" int lego_conv3_wino_bwd_weight(const float* gy, int ldg, const float* h, int ldh, const int32_t* pair_info,
-                                          int P_cap, const int32_t* P_dyn, float* du, int Dout, int Din, void* stream) {
+                                          int P_cap, const int32_t* P_dyn, float* du, int n_slabs, int Dout, int Din, void* stream) {
     CHECK4(ldg); CHECK4(ldh); CHECK4(Dout); CHECK4(Din);
     if (P_cap <= 0) return 0;
+    // the slab count is a function of (Dout, Din, P_cap) AND the process-wide product mode at call time: the caller states how many
+    // slabs `du` holds, and a launch that would write another number is refused instead of running past the buffer
+    const int want = lego_conv3_wino_du_slabs(Dout, Din, P_cap);
+    LEGO_REQUIRE(n_slabs == want, "lego_conv3_wino_bwd_weight: du holds %d slab(s), this launch writes %d (lego_conv3_wino_du_slabs; did the "
+                 "product mode change after the buffer was sized?)", n_slabs, want);
     // du[set][o][c] += sum_pairs dM_set[o] * A_set[c]: four TN products over the pair rows (gridDim.z = 4 * split)
     if (P_cap >= TN_LONG && product_mode() == 0 && tndp_slabs(Dout, Din, P_cap) > 0)
         return launch_tndp(gy, ldg, h, ldh, pair_info, P_cap, P_dyn, du, Dout, Din, (hipStream_t)stream, "lego_conv3_wino_bwd_weight");
@@ -584,16 +493,7 @@ extern "C" int lego_conv3_wino_bwd_weight(const float* gy, int ldg, const float*
     McPair b{h, ldh, Din, P_cap, pair_info, 0, 0};
     Epi e = make_epi(du, Din);
     e.tap_stride = (size_t)Dout * Din;
-    if (P_cap >= TN_LONG && convw64_split() > 1) {
-        const int split = convw64_split(), tm = (Dout + 63) / 64, tn = (Din + 63) / 64;
-        const int deal = split % 8 == 0;
-        TnDims d{Dout, Din, P_cap, P_dyn, split, 4, (size_t)4 * e.tap_stride, tm, tn, deal};
-        auto k = tn_kernel<McPair, McPair, true, 2, 2, 1>;
-        constexpr size_t lds = tn_lds_bytes(TN_BM_S, TN_BN_S, true);
-        hipLaunchKernelGGL(k, deal ? dim3(tm * tn * 4 * split) : dim3(tm, tn, 4 * split), dim3(TN_THREADS_S), lds, (hipStream_t)stream, d, a, b, e);
-        return check_launch("lego_conv3_wino_bwd_weight");
-    }
-    if (lego_conv3_wino_du_slabs(Dout, Din, P_cap) > 1)      // long reduction: one slab per k split, plain stores
+    if (want > 1)                                   // long reduction: one slab per k split, plain stores
         return launch_tn_long<true>(Dout, Din, P_cap, P_dyn, a, b, e, 4, (hipStream_t)stream, "lego_conv3_wino_bwd_weight");
     return launch_tn(Dout, Din, P_cap, P_dyn, a, b, e, 4, (hipStream_t)stream, "lego_conv3_wino_bwd_weight");
 }
@@ -627,7 +527,6 @@ extern "C" int lego_debug_gemm_nt(int variant, const float* x, const float* W, c
         case 8: return launch<TileCfg<128, 128, 2, 4, true>, false, false, EpiPlain>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, 1, st, "dbg8");
         case 9: return launch_strip<false, EpiPlain>(d, a, b, e, st, "dbg9");
         case 10: return launch_dma_strip<false, EpiPlain>(d, a, b, e, st, "dbg10");
-        case 13: return launch_dma_strip<false, EpiPlain, KcRows, 4>(d, a, b, e, st, "dbg13");
         case 20: return launch<TileCfg<128, 128, 2, 4, true>, false, false, EpiPlain, true>(d, a, b, e, (M + 127) / 128, (N + 127) / 128, 1, st, "dbg20");
         case 21: return launch<TileCfg<256, 128, 4, 2>, false, false, EpiPlain, true>(d, a, b, e, (M + 255) / 256, (N + 127) / 128, 1, st, "dbg21");
         case 22: return launch<TileCfg<128, 256, 2, 4>, false, false, EpiPlain, true>(d, a, b, e, (M + 127) / 128, (N + 255) / 256, 1, st, "dbg22");

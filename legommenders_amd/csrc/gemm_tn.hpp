@@ -13,7 +13,7 @@
 // Partial tiles either go out as fp32 atomics (ATOMIC) or as plain stores into a slab [split][M][N] that one combine launch
 // folds later (the conv's unpack kernel, lego_combine_slabs for the Linear weights).
 #pragma once
-#include "gemm_wino.hpp"
+#include "wino_common.hpp"
 
 namespace lego {
 

@@ -18,7 +18,7 @@
 //   * the workgroups of one k split are dealt to one XCD, so the rows they share are fetched into ONE L2.
 #pragma once
 #include "gemm_epi.hpp"
-#include "gemm_wino.hpp"      // PI_* bits of a pair_info word
+#include "wino_common.hpp"      // PI_* bits of a pair_info word
 
 namespace lego {
 

@@ -20,7 +20,7 @@
 // launcher (gemm_ops.hip: launch_wino) keeps wino_kernel<false> for everything else.  LEGO_WINO2=0 selects the old kernel (A/B).
 #pragma once
 #include "gemm_epi.hpp"
-#include "gemm_wino.hpp"
+#include "wino_common.hpp"
 
 namespace lego {
 

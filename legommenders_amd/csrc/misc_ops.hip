@@ -544,7 +544,7 @@ __device__ __forceinline__ void atomic_add_row(float* out_row, int col0, int wid
 // VEC = columns per lane: 4 (a wave covers 256 columns of a row with one 16-byte load per lane) or 1 (64 columns, a dword per lane).
 // Round 5: VEC = 1 is the default -- the launch has R / 32 waves per column slice, and with 256-column slices that is ~840 waves for a
 // NAML batch (3 per CU: every wave waits out its two batches of 16 dependent-free row loads with nothing beside it); four times the
-// slices = four times the waves for the same loads, groups and atomics per column (LEGO_SEGSUM_VEC=4: the round-3 form).
+// slices = four times the waves for the same loads, groups and atomics per column (the VEC = 4 form stays for the tuning tools).
 template <int VEC>
 __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float* __restrict__ g, int ld_g, int width, const int* __restrict__ perm,
                                                                const int* __restrict__ inv, const int* __restrict__ sorted_keys,
@@ -1812,13 +1812,10 @@ extern "C" int lego_segment_sum_rows(const float* g, int ld_g, int width, const 
         const long long tot = (long long)U_cap * (width / 4);
         hipLaunchKernelGGL(zero_rows_kernel, dim3((int)((tot + 255) / 256 < 2048 ? (tot + 255) / 256 : 2048)), dim3(256), 0, ST, out, ld_out, width, U_cap, U_dyn);
     }
-    static int vec = -1;
-    if (vec < 0) { const char* v = getenv("LEGO_SEGSUM_VEC"); vec = (v != nullptr && v[0] == '4') ? 4 : 1; }
-    const dim3 gx((R_cap + 4 * kSegRows - 1) / (4 * kSegRows), (width + 64 * vec - 1) / (64 * vec));
+    const dim3 gx((R_cap + 4 * kSegRows - 1) / (4 * kSegRows), (width + 63) / 64);
     const uint8_t* km = dropping ? dr.mask : (const uint8_t*)nullptr;
     const float ks = dropping ? 1.f / (1.f - dr.p) : 1.f;
-    if (vec == 4) hipLaunchKernelGGL(segment_sum_rows_kernel<4>, gx, dim3(256), 0, ST, g, ld_g, width, perm, inv, sorted_keys, R_cap, R_dyn, out, ld_out, km, ks, rowinfo);
-    else hipLaunchKernelGGL(segment_sum_rows_kernel<1>, gx, dim3(256), 0, ST, g, ld_g, width, perm, inv, sorted_keys, R_cap, R_dyn, out, ld_out, km, ks, rowinfo);
+    hipLaunchKernelGGL(segment_sum_rows_kernel<1>, gx, dim3(256), 0, ST, g, ld_g, width, perm, inv, sorted_keys, R_cap, R_dyn, out, ld_out, km, ks, rowinfo);
     return check_launch("lego_segment_sum_rows");
 }
 
@@ -1950,9 +1947,7 @@ extern "C" int lego_additive_pool_fwd(const float* t, int ldt, const float* x, i
                  "lego_additive_pool_fwd: D=%d A=%d must be multiples of 4 and <= %d", D, A, 256 * kMaxChunks);
     LEGO_REQUIRE((ldt & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0, "lego_additive_pool_fwd: strides must be multiples of 4");
     if (n_cap <= 0) return 0;
-    static int fast = -1;                            // LEGO_POOL_FAST=0: the row-by-row kernels (A/B)
-    if (fast < 0) { const char* v = getenv("LEGO_POOL_FAST"); fast = (v != nullptr && v[0] == '0') ? 0 : 1; }
-    if (fast && D <= 256 && A <= 256)
+    if (D <= 256 && A <= 256)                        // (wider rows: the row-by-row kernels)
         hipLaunchKernelGGL(additive_pool_fwd_fast_kernel, dim3(n_cap), dim3(256), 0, ST, t, ldt, x, ldx, w2, seg_off, rowinfo,
                            extra_off_dyn, n_cap, n_dyn, D, A, out, ldo, wrow);
     else
@@ -1971,9 +1966,7 @@ extern "C" int lego_additive_pool_bwd(float* t_dpre, int ldt, const float* x, in
     const int cap = 1024;
     int blocks = n_cap;
     if (blocks > cap) blocks = cap;
-    static int fast = -1;
-    if (fast < 0) { const char* v = getenv("LEGO_POOL_FAST"); fast = (v != nullptr && v[0] == '0') ? 0 : 1; }
-    if (fast && D <= 256 && A <= 256 && (ldt & 3) == 0 && (ldx & 3) == 0 && (lddx & 3) == 0 && (ldgo & 3) == 0)
+    if (D <= 256 && A <= 256 && (ldt & 3) == 0 && (ldx & 3) == 0 && (lddx & 3) == 0 && (ldgo & 3) == 0)
         hipLaunchKernelGGL(additive_pool_bwd_fast_kernel, dim3(blocks), dim3(256), 0, ST, t_dpre, ldt, x, ldx, w2, seg_off, extra_off_dyn,
                            n_cap, n_dyn, D, A, gout, ldgo, wrow, dx, lddx, gw2, gb1, scratch);
     else

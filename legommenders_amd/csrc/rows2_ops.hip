@@ -15,37 +15,16 @@ static int r2_num_cus() {
     return n;
 }
 
-// LEGO_ROWS2: 0 = the row-strip kernels of rounds 2-4 for every plain-row product, 1 = rows2_kernel where it applies (default)
-static int rows2_mode() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("LEGO_ROWS2"); v = (e != nullptr && e[0] == '0') ? 0 : 1; }
-    return v;
-}
-static int rows2_min_rows() {      // launches sized for fewer rows are latency-bound: the single-wave-tile kernels serve them
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("LEGO_ROWS2_MIN_ROWS"); v = e != nullptr ? atoi(e) : 8192; }
-    return v;
-}
-static int rows2_min_strip() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("LEGO_ROWS2_MIN_STRIP"); v = (e != nullptr && atoi(e) > 0) ? atoi(e) : 64; }     // 16 / 64 / 112: 17.6 / 16.5 / 23.8 us on the projection over 4.5 k of 105 k rows
-    return v;
-}
-static int rows2_max_n() {         // wider outputs: more column blocks re-read every A strip; measured slower than the row-strip kernels beyond 256
-    static int v = -1;                // at two workgroups per CU (tools/rows2_check.py: N = 768 158 against 133 us; 116 at three per CU)
-    if (v < 0) { const char* e = getenv("LEGO_ROWS2_MAX_N"); v = e != nullptr ? atoi(e) : 256; }
-    return v;
-}
-static int rows2_wgs_per_cu(int nblk) {    // workgroups per CU over the launch: 2 (= resident) for one or two column blocks, 3 for more (tools/rows2_check.py:
-    static int v = -1;                       // N = 768 at 2 / 3 / 4 / 6 per CU = 158 / 116 / 132 / 120 us)
-    if (v < 0) { const char* e = getenv("LEGO_ROWS2_WGS"); v = (e != nullptr && atoi(e) > 0) ? atoi(e) : 0; }
-    return v > 0 ? v : (nblk <= 2 ? 2 : 3);
-}
+// Dispatch window (measured, tools/rows2_check.py / profiles/r05_rows2.txt): launches sized for >= 8 192 rows (fewer are latency-bound: the
+// single-wave-tile kernels serve them); outputs of <= 256 columns (wider ones re-read every A strip once per column block: N = 768 takes 158 us
+// against 133 for the row-strip kernel at two workgroups per CU); strips of >= 64 rows (16 / 64 / 112: 17.6 / 16.5 / 23.8 us on the projection over
+// 4.5 k live of 105 k capacity rows); two workgroups per CU for one or two column blocks, three for more
+constexpr int R2_MIN_ROWS = 8192, R2_MAX_N = 256, R2_MIN_STRIP = 64;
+static int rows2_wgs_per_cu(int nblk) { return nblk <= 2 ? 2 : 3; }
 
 // x [M, K] rows (no row offset), w [N, K] rows; e: C, bias, act, [accumulate is the template kind], relu_ref, colsum
 bool rows2_ok(const float* x, int ldx, const float* w, int ldw, int M_cap, int N, int K, const EpiArgs& e, bool b_mc, bool accum, bool reluref) {
-    if (rows2_mode() == 0 || M_cap < rows2_min_rows()) return false;
-    if (N > rows2_max_n()) return false;
+    if (M_cap < R2_MIN_ROWS || N > R2_MAX_N) return false;
     if ((K & 3) != 0 || K < 4 || (N & 3) != 0 || (ldx & 3) != 0 || (ldw & 3) != 0 || (e.ldc & 3) != 0) return false;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(e.C)) & 15) return false;
     if (e.bias != nullptr && (reinterpret_cast<uintptr_t>(e.bias) & 15)) return false;
@@ -61,7 +40,7 @@ bool rows2_ok(const float* x, int ldx, const float* w, int ldw, int M_cap, int N
 int launch_rows2(const float* x, int ldx, const float* w, int ldw, int M_cap, const int* M_dyn, int N, int K, const EpiArgs& e, bool b_mc, bool accum,
                  bool reluref, hipStream_t st, const char* what) {
     Rows2Args a{x, ldx, (unsigned)((unsigned long long)M_cap * (unsigned long long)ldx * 4ull), w, ldw,
-                (unsigned)((unsigned long long)(b_mc ? K : N) * (unsigned long long)ldw * 4ull), M_cap, M_dyn, N, K, rows2_min_strip()};
+                (unsigned)((unsigned long long)(b_mc ? K : N) * (unsigned long long)ldw * 4ull), M_cap, M_dyn, N, K, R2_MIN_STRIP};
     const int nblk = (N + R2_BN - 1) / R2_BN;
     // strips: rows2_wgs_per_cu workgroups per CU over the launch, in groups of 8 strips x nblk column blocks (XCD dealing); never more
     // strips than 16-row groups of the capacity

@@ -15,22 +15,15 @@ static int tnd_num_cus() {
     return n;
 }
 
-// LEGO_TND: 0 = the tile kernels of gemm_tn.hpp everywhere, 1 (default) = tnd_kernel for plain-row weight gradients whose OUTPUT has
-// LEGO_TND_MIN_NK <= M N <= LEGO_TND_MAX_NK elements (defaults 128 K .. 1 M).  Measured (tools/tnd_check.py, profiles/r05_tnd.txt):
-// 768 x 256 over 30.7 k rows (NRMS in-projection) 135 -> 106-125 us, 768 x 768 over 29.6 k (BERT) 318 -> 265-288 us, NRMS step
+// tnd_kernel takes plain-row weight gradients whose OUTPUT has 128 K .. 1 M elements over >= 2 048 rows.  Measured (tools/tnd_check.py,
+// profiles/r05_tnd.txt): 768 x 256 over 30.7 k rows (NRMS in-projection) 135 -> 106-125 us, 768 x 768 over 29.6 k (BERT) 318 -> 265-288 us, NRMS step
 // 1.048 -> 1.020 ms; the 256 x 256 / 256 x 300 gradients of NAML are 15-20 % faster alone (45 -> 37 us) but the step is not (its
 // side-stream launches then hold every CU's registers and LDS while the main stream's next kernel waits): they keep the tile kernels;
 // 3072 x 768 (BERT FFN) is 6 % slower (the 64 x 64 wave tiles re-read the operands 48 x 12 times from L2).
-// LEGO_TND_WGS = workgroups aimed at (default 4 per CU), LEGO_TND_MIN_ROWS = smallest reduction it takes
-static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e != nullptr ? atoi(e) : dflt; }
-int tnd_mode() { static int v = -1; if (v < 0) v = env_int("LEGO_TND", 1); return v; }
+constexpr int TND_MIN_ROWS = 2048, TND_MIN_NK = 1 << 17, TND_MAX_NK = 1 << 20;
 
 bool tnd_ok(int M, int N, int K_cap, int lda, int ldb, int ldc) {
-    static int min_rows = -1, max_nk = -1, min_nk = -1;
-    if (min_rows < 0) min_rows = env_int("LEGO_TND_MIN_ROWS", 2048);
-    if (max_nk < 0) max_nk = env_int("LEGO_TND_MAX_NK", 1 << 20);
-    if (min_nk < 0) min_nk = env_int("LEGO_TND_MIN_NK", 1 << 17);
-    if (tnd_mode() == 0 || K_cap < min_rows || M < 4 || N < 4 || (long long)M * N > max_nk || (long long)M * N < min_nk) return false;
+    if (K_cap < TND_MIN_ROWS || M < 4 || N < 4 || (long long)M * N > TND_MAX_NK || (long long)M * N < TND_MIN_NK) return false;
     if ((lda & 3) || (ldb & 3) || (M & 3) || (N & 3)) return false;
     const unsigned long long lim = 0x7FFF0000ull;          // 32-bit byte offsets, with room for the ring's reads past the range
     return ((unsigned long long)K_cap + 64) * (unsigned long long)lda * 4ull < lim && ((unsigned long long)K_cap + 64) * (unsigned long long)ldb * 4ull < lim;
@@ -38,10 +31,9 @@ bool tnd_ok(int M, int N, int K_cap, int lda, int ldb, int ldc) {
 
 int launch_tnd(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int M, int N, int K_cap, const int* k_dyn,
                const int* a_row_off, const int* b_row_off, hipStream_t st, const char* what) {
-    static int wgs = -1;
     // four per CU: at the shapes the dispatch window lets in, 2 per CU is the WORST count (profiles/r05_tnd.txt: 768 x 256 over 30.7 k rows
     // 106 / 125 / 104 us at 1 / 2 / 4 per CU, 768 x 768 425 / 288 / 266); NRMS step 0.990 -> 0.977-0.981 ms
-    if (wgs < 0) wgs = env_int("LEGO_TND_WGS", 4 * tnd_num_cus());
+    const int wgs = 4 * tnd_num_cus();
     const int tm = (M + TND_T - 1) / TND_T, tn = (N + TND_T - 1) / TND_T;
     int split = wgs / (tm * tn);
     const int max_s = (K_cap + 255) / 256;                  // at least 32 reduction rows per wave at capacity
@@ -59,17 +51,15 @@ int launch_tnd(const float* a, int lda, const float* b, int ldb, float* c, int l
 }
 
 
-// ---- the Winograd conv's weight gradient (tndp_kernel).  LEGO_TNDP: 0 = tn_kernel<McPair> (rounds 2-4), 1 = tndp_kernel (default)
-int tndp_mode() { static int v = -1; if (v < 0) v = env_int("LEGO_TNDP", 1); return v; }
+// ---- the Winograd conv's weight gradient (tndp_kernel)
 
 // slabs the kernel writes for (Dout, Din, P_cap); 0 = not its case (the caller keeps the tile kernel).  Decided from these three
 // alone: lego_conv3_wino_du_slabs sizes the slab buffer before the launch sees the row strides.
 int tndp_slabs(int Dout, int Din, int P_cap) {
-    if (tndp_mode() == 0 || P_cap < 8192 || Dout % TNDP_TM != 0 || Din % TNDP_TN != 0) return 0;
+    if (P_cap < 8192 || Dout % TNDP_TM != 0 || Din % TNDP_TN != 0) return 0;
     const unsigned long long widest = (unsigned long long)(Dout > Din ? Dout : Din);
     if (2ull * (unsigned long long)P_cap * widest * 4ull * 4ull >= 0x7FFF0000ull) return 0;     // 31-bit row offsets, strides up to 4 x the width
-    static int wgs = -1;
-    if (wgs < 0) wgs = env_int("LEGO_TNDP_WGS", tnd_num_cus());
+    const int wgs = tnd_num_cus();
     const int tiles = (Dout / TNDP_TM) * (Din / TNDP_TN);
     int split = wgs / tiles;
     const int max_s = P_cap / 1024 > 0 ? P_cap / 1024 : 1;                  // at least 128 pairs per wave at capacity

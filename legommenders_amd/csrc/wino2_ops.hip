@@ -16,12 +16,6 @@ static int w2_num_cus() {
     return n;
 }
 
-// LEGO_WINO2: 0 = wino_kernel<false> (rounds 1-4), 1 = wino2_kernel (default)
-int wino2_mode() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("LEGO_WINO2"); v = (e != nullptr && e[0] == '0') ? 0 : 1; }
-    return v;
-}
 #ifdef LEGO_TUNING_HOOKS
 static int wino2_abl() {        // LEGO_WINO2_ABL=<bits>: the ablation variants of gemm_wino2.hpp (timing only, wrong results)
     static int v = -1;
@@ -30,14 +24,16 @@ static int wino2_abl() {        // LEGO_WINO2_ABL=<bits>: the ablation variants 
 }
 #endif
 
-bool wino2_ok(const WinoArgs& w, const EpiArgs& e) {
-    if (wino2_mode() == 0) return false;
-    if (w.C % BK != 0 || (w.N & 3) != 0 || (w.ldx & 3) != 0 || (e.ldc & 3) != 0) return false;
-    if ((reinterpret_cast<uintptr_t>(w.x) | reinterpret_cast<uintptr_t>(w.u) | reinterpret_cast<uintptr_t>(e.C)) & 15) return false;
-    if (e.bias != nullptr && (reinterpret_cast<uintptr_t>(e.bias) & 15)) return false;
-    if (e.drop.p > 0.f && (e.drop.mask == nullptr || (e.drop_cols & 3) != 0 || (reinterpret_cast<uintptr_t>(e.drop.mask) & 3))) return false;
-    if (2ull * (unsigned long long)w.P_cap * (unsigned long long)w.ldx * 4ull >= 0x7FFFFFF0ull) return false;   // row offsets are 31-bit
-    return e.act != 2;
+// nullptr when the kernel takes the launch, else the reason it cannot (the entry points report it: there is no second Winograd kernel)
+const char* wino2_why_not(const WinoArgs& w, const EpiArgs& e) {
+    if (w.C % BK != 0 || (w.N & 3) != 0 || (w.ldx & 3) != 0 || (e.ldc & 3) != 0) return "channel counts / row strides must be multiples of 32 / 4";
+    if ((reinterpret_cast<uintptr_t>(w.x) | reinterpret_cast<uintptr_t>(w.u) | reinterpret_cast<uintptr_t>(e.C)) & 15) return "operands must be 16-byte aligned";
+    if (e.bias != nullptr && (reinterpret_cast<uintptr_t>(e.bias) & 15)) return "the bias must be 16-byte aligned";
+    if (e.drop.p > 0.f && (e.drop.mask == nullptr || (e.drop_cols & 3) != 0 || (reinterpret_cast<uintptr_t>(e.drop.mask) & 3)))
+        return "a dropout site needs its keep bits drawn ahead of time (lego_dropout_mask)";
+    if (2ull * (unsigned long long)w.P_cap * (unsigned long long)w.ldx * 4ull >= 0x7FFFFFF0ull) return "the input exceeds 2 GB (31-bit row offsets)";
+    if (e.act == 2) return "tanh epilogue not built";
+    return nullptr;
 }
 
 int launch_wino2(const WinoArgs& w0, const EpiArgs& e, hipStream_t st, const char* what) {

@@ -109,7 +109,6 @@ class _Base:
         self.P = params
         # switches read once per engine (an os.environ look-up per launch site and step is host time the step does not have)
         self._serial = os.environ.get("LEGO_SERIAL") == "1"      # profiling aid (tools/prof_*.sh): every launch of a step on ONE stream
-        self._one_wait = os.environ.get("LEGO_ONE_WAIT", "0") == "1"
         self.tb = tables
         self.B, self.C, self.S, self.T = B, C, S, tables.T
         self.dev = tables.title_tok.device
@@ -305,10 +304,8 @@ class NamlEngine(_Base):
         # span waves -- a Zipf head holds a fifth of the rows -- are added with 256-B-contiguous float atomics onto rows cleared
         # ahead of time on the side stream), then the product over the distinct tokens: 18 + 21 us against 55 for the product over
         # the token rows.  (First version: 16 rows per wave, 16-B-strided atomics, a counting sort with an atomic cursor: 46 + 25 us
-        # and 2 x 64 us of serialised int atomics on the prefetch stream -- slower than not de-duplicating.)  LEGO_DEDUP_BWD=0: off
-        self.dedup_bwd = self.dedup and os.environ.get("LEGO_DEDUP_BWD", "1") != "0"
-        self.proj_side = os.environ.get("LEGO_PROJ_SIDE", "0") == "1"
-        self.unpack_side = os.environ.get("LEGO_UNPACK_SIDE", "0") == "1"
+        # and 2 x 64 us of serialised int atomics on the prefetch stream -- slower than not de-duplicating.)
+        self.dedup_bwd = self.dedup
         V = P["embedding_vocab_table.glove.embedding.weight"].shape[0]
         self.V = V
         self.Uc = min(self.Rc, V) if self.dedup else 0
@@ -347,8 +344,6 @@ class NamlEngine(_Base):
         self.wino_dw = os.environ.get("LEGO_WINO", "1") != "0" and D <= 256 and self.Rc > 0
         self._built_mode = _lib.product_mode()       # (forward() refuses a step in the other mode: the conv entry points are chosen here)
         self.wino = self.wino_dw and self._built_mode == _lib.EXACT_F32
-        if os.environ.get("LEGO_SPLIT_WINO_DW", "1") == "0":
-            self.wino_dw = self.wino
         self.Pc = self.NIc * ((self.T + 1) // 2)
         self.pair_info = torch.zeros(max(self.Pc, 1), **i32)
         self.mask_proj = torch.zeros(((self.Rc + 3) // 4) * D + 1, dtype=torch.uint8, device=self.dev)
@@ -396,7 +391,16 @@ class NamlEngine(_Base):
         if not training or p <= 0.0:
             return None
         d = LegoDropout(p, self.seed, site + 16 * self.step, None)
-        if self._mask_step == self.step and site in (SITE_PROJ, SITE_CONV):
+        if site in (SITE_PROJ, SITE_CONV):
+            if self._mask_step != self.step and self.Rc > 0:
+                # a training pass whose keep bits were not drawn with the plan (an un-planned forward): drawn here, on the current
+                # stream -- the Winograd kernels and the expansion read keep bits, they do not run Philox (round 6)
+                st = _stream()
+                for p_, site_, buf in ((self.p_proj, SITE_PROJ, self.mask_proj), (self.p_conv, SITE_CONV, self.mask_conv)):
+                    if p_ > 0.0:
+                        call("lego_dropout_mask", ctypes.byref(LegoDropout(p_, self.seed, site_ + 16 * self.step, None)), self.Rc, self.cnt(0),
+                             self.D, _ptr(buf), st)
+                self._mask_step = self.step
             d.mask = (self.mask_proj if site == SITE_PROJ else self.mask_conv).data_ptr()
         return ctypes.byref(d)
 
@@ -536,8 +540,7 @@ class NamlEngine(_Base):
             self.kk(sb, None, "lego_conv3_wino_pack", _ptr(P["item_op.cnn.weight"]), _ptr(self.wino_u), _ptr(self.wino_ut), D, D)
         else:
             self.kk(sb, None, "lego_conv3_pack", _ptr(P["item_op.cnn.weight"]), _ptr(self.wt), D, D)
-        one_wait = self._one_wait                    # A/B: the conv waits ONCE, for the whole side chain (measured 1 % slower)
-        if sb is not m and not one_wait:
+        if sb is not m:
             ev[8].record(sb)
         if zero_loss:
             with torch.cuda.stream(sb):
@@ -567,7 +570,7 @@ class NamlEngine(_Base):
             # the side chain is three short kernels (packed conv weights, category rows, category Linear: the category ids come
             # with the plan) and ends while the projection still runs: ONE wait here covers the conv's weights and the category
             # rows of Y -- every cross-stream wait costs the main stream 6-14 us of idle even when already signalled
-            m.wait_event(ev[1] if one_wait else ev[8])
+            m.wait_event(ev[8])
         # k3: conv + relu + mask + dropout (cnn_operator.py:54-57)
         if self.wino:
             self.kk(m, "conv3_fwd", "lego_conv3_wino_fwd", _ptr(self.H), D, _ptr(self.wino_u), _ptr(P["item_op.cnn.bias"]),
@@ -578,7 +581,7 @@ class NamlEngine(_Base):
                     _ptr(self.Y), D, self.Rc, self.cnt(0), D, D, self.drop(self.p_conv, SITE_CONV, training), 0)
         if neck_ev is not None:
             neck_ev.record(m)                        # the next batch's prefetch chain starts here (see forward)
-        if sb is not m and not one_wait:
+        if sb is not m:
             m.wait_event(ev[1])                      # category rows of Y
         # k5: additive attention pool over [title tokens..., category] (attention.py:31-38)
         self._additive_fwd(m, "item_op.", _ptr(self.Y), self.Ryc, self.cnt(2), self.Tt, A, self.seg_off, self.cnt(0),
@@ -663,21 +666,12 @@ class NamlEngine(_Base):
             self.kk(m, "conv3_bwd_data", "lego_conv3_bwd_data", _ptr(self.dY), D, _ptr(self.wt), _ptr(self.rowinfo), _ptr(self.dH), D,
                     self.Rc, self.cnt(0), D, D, self.drop(self.p_proj, SITE_PROJ, training),
                     _ptr(G["embedding_vocab_table.glove.linear.bias"]), 0)
-        # A/B (LEGO_PROJ_SIDE=1): the projection's weight-gradient tail (segment sums + product over the distinct tokens) on the
-        # side stream beside the conv weight gradient instead of behind it on the main stream
-        pst = m
-        if self.proj_side:
-            self._fork(ev[7], m, sb)
-            pst = sb
+        pst = m      # (the projection's weight-gradient tail beside the conv weight gradient on the side stream: 0.578 -> 0.601 ms)
         # ---- conv weight gradient after the data gradient on the main stream (a third stream measured 1-1.5 % slower)
         if self.wino_dw:
             self.kk(m, "conv3_bwd_weight", "lego_conv3_wino_bwd_weight", _ptr(self.dY), D, _ptr(self.H), D,
-                    _ptr(self.pair_info), self.Pc, self.cnt(5), _ptr(self.wino_du), D, D)
-            ust = m
-            if self.unpack_side:                     # A/B (LEGO_UNPACK_SIDE=1): the slabs' unpack beside the projection's tail, not in front of it
-                self._fork(ev[8], m, sb)
-                ust = sb
-            self.kk(ust, None, "lego_conv3_wino_unpack_add", _ptr(self.wino_du), self.wino_slabs, _ptr(G["item_op.cnn.weight"]), D, D)
+                    _ptr(self.pair_info), self.Pc, self.cnt(5), _ptr(self.wino_du), self.wino_slabs, D, D)
+            self.kk(m, None, "lego_conv3_wino_unpack_add", _ptr(self.wino_du), self.wino_slabs, _ptr(G["item_op.cnn.weight"]), D, D)
         else:
             self.kk(m, "conv3_bwd_weight", "lego_conv3_bwd_weight", _ptr(self.dY), D, _ptr(self.H), D, _ptr(self.rowinfo),
                     _ptr(self.dwt), self.Rc, self.cnt(0), D, D)
@@ -835,10 +829,8 @@ class NrmsEngine(_Base):
         # embeddings E are still expanded -- on the side stream, for the backward pass only.  Needs the site's keep bits ahead of time
         # (TrainStep draws them with the plan); a step without them, or LEGO_NRMS_DROPCORR=0, runs the in-projection row by row.
         self.dropcorr = self.dedup and glove and D <= 256 and os.environ.get("LEGO_NRMS_DROPCORR", "1") != "0"
-        # the backward pass of that form (per-key sums of d(qkv), a product over the keys, lego_dropcorr_bwd) is opt-in: measured, its three
-        # launches cost more than the row-by-row data gradient they replace, so by default only the FORWARD
-        # in-projection runs per key and the backward pass is the row form over the same key space
-        self.dropcorr_bwd = self.dropcorr and os.environ.get("LEGO_NRMS_DROPCORR_BWD", "0") == "1"
+        # (only the FORWARD in-projection runs per key; the backward pass is the row form over the same key space -- its per-key form
+        # measured 620 us against 130, DESIGN.md section 11.4, and was removed in round 6)
         if self.dropcorr:
             n_cat = P["embedding_vocab_table.category.weight"].shape[0]
             self.Vk = self.V + 1 + n_cat
@@ -889,7 +881,7 @@ class NrmsEngine(_Base):
 
     def prefetch_masks(self, stream, slot):
         """TrainStep, after plan_on: the projection site's keep bits of the coming training step (engine.step) into the slot"""
-        if self.dedup and self.glove and self.p_proj > 0.0 and os.environ.get("LEGO_NRMS_MASK_AHEAD", "1") != "0":      # 0: in-kernel draws + a mask pass over dE
+        if self.dedup and self.glove and self.p_proj > 0.0:
             b = self._slots[slot]
             call("lego_dropout_mask", ctypes.byref(LegoDropout(self.p_proj, self.seed, SITE_PROJ + 16 * self.step, None)), self.Rc,
                  _ptr(b["counters"], 0), self.D, _ptr(b["mask_proj"]), stream_handle(stream))
@@ -971,8 +963,9 @@ class NrmsEngine(_Base):
 
     # how the attention core's backward gets the softmax: recomputed from Q, K and one log-sum-exp per (row, head) (no [rows, heads, L]
     # tensor: 64 MB less HBM traffic per step at the bench shape) or read back from probabilities the forward pass saved.  Same-box
-    # A/B in DESIGN.md section 4; LEGO_MHSA_RECOMPUTE picks
-    mhsa_recompute = os.environ.get("LEGO_MHSA_RECOMPUTE", "0") == "1"
+    # A/B in DESIGN.md section 4: the saved probabilities are faster (the kernel is issue-bound, not HBM-bound); set this attribute before
+    # building an engine to trade 122 MB of workspace for the recomputing form (the plug-in route always recomputes)
+    mhsa_recompute = False
 
     def _att_ws(self, rows, Lmax, n_seg):
         D, A, H = self.D, self.A, self.heads
@@ -1063,8 +1056,8 @@ class NrmsEngine(_Base):
     _fold_ev = None
 
     # user side: a few hundred (user, head) pairs, a fifth of them longer than 32 clicks -- ONE launch of the two-wave (<= 64 rows)
-    # instantiation for all of them instead of a short-segment and a long-segment launch (LEGO_MHSA_ALL_LONG; A/B: LEGO_NRMS_USER_ONE=0)
-    user_one = os.environ.get("LEGO_NRMS_USER_ONE", "1") != "0"
+    # instantiation for all of them instead of a short-segment and a long-segment launch (LEGO_MHSA_ALL_LONG)
+    user_one = True
 
     def _part(self, pre, ws):
         """(part, long_list, long_count) arguments of lego_mhsa_core_*"""
@@ -1120,7 +1113,7 @@ class NrmsEngine(_Base):
         m = current_stream()
         return m, (m if self._serial else self._sw)
 
-    def _att_bwd(self, pre, ws, G, x_ptr, dx_ptr, rows_dyn, seg_off, n_cap, n_dyn, gout, site, training, st, ev, dx_epi=None, per_key=False):
+    def _att_bwd(self, pre, ws, G, x_ptr, dx_ptr, rows_dyn, seg_off, n_cap, n_dyn, gout, site, training, st, ev, per_key=False):
         """data-gradient chain on the current stream `st`; weight gradients in two groups on the side stream, each behind
         ONE event (`ev[0]`, `ev[1]`) recorded where its inputs are final (the workspace is not overwritten before the
         next forward, which the caller orders after the side stream)"""
@@ -1137,29 +1130,6 @@ class NrmsEngine(_Base):
                 self.drop(self.p_att, site, training), rows, _ptr(ws["d_qkv"]), 3 * D,
                 _ptr(G[pre + "multi_head_attention.in_proj_bias"]))      # bias gradient = column sums of d_qkv, fused
         self.kk(m, "mhsa_core_bwd_" + pre[:4], *core, *self._part(pre, ws))
-        if per_key == "dropcorr":
-            # data gradient per key: dEu = (sum over the key's rows of d(qkv)) W_in, minus the dropped coordinates' share row by row;
-            # weight gradient: the dense product over the rows, d(qkv)^T E, on the side stream (E: expanded there in the forward pass)
-            W_in = P[pre + "multi_head_attention.in_proj_weight"]
-            self.kk(m, "qkv_bwd_segsum", "lego_segment_sum_rows", _ptr(ws["d_qkv"]), 3 * D, 3 * D, _ptr(self.perm), _ptr(self.inv), rows,
-                    _ptr(self.keys_sorted), rows_dyn, _ptr(self.dQKVu), 3 * D, self.Uc, self.cnt(6), 1, None, None)
-            if sw is not m:
-                ev[1].record(m)                      # (d_qkv is final since the attention core)
-
-            def side2d():
-                if sw is not m:
-                    sw.wait_event(ev[1])
-                call("lego_linear_bwd_weight", _ptr(ws["d_qkv"]), 3 * D, _ptr(self.E), D,
-                     _ptr(G[pre + "multi_head_attention.in_proj_weight"]), D, rows, rows_dyn, 3 * D, D, None, None, sp)
-            if self.fold == 2:
-                self._deferred.append(side2d)
-            else:
-                side2d()
-            self.kk(m, "qkv_bwd_data", "lego_linear_bwd_data", _ptr(self.dQKVu), 3 * D, _ptr(W_in), D, dx_ptr, D, self.Uc, self.cnt(6), 3 * D, D, 0,
-                    None, 0, 1.0, None, None, None, None, None)
-            self.kk(m, "qkv_bwd_dropcorr", "lego_dropcorr_bwd", _ptr(ws["d_qkv"]), 3 * D, _ptr(self.WinT), 3 * D, _ptr(self.inv), _ptr(self.tokinfo),
-                    self._dc_drop, rows, rows_dyn, D, 3 * D, dx_ptr, D)
-            return
         if per_key:
             # d(qkv) summed per distinct key, then both products of the in-projection's backward over the ~4.5 k keys instead of the
             # ~31 k sequence rows: dW_in = dQKVu^T Eu (side stream), dEu = dQKVu W_in (x_ptr = Eu, dx_ptr = dEu)
@@ -1194,11 +1164,9 @@ class NrmsEngine(_Base):
             self._deferred.append(side2)
         else:
             side2()
-        # dx = d_qkv W_in; `dx_epi` = (rowinfo, dropout, colsum): the backward of the GloVe projection's mask + Dropout and its bias
-        # gradient in this product's epilogue (NRMS item side)
-        ri, dr, cs = dx_epi if dx_epi is not None else (None, None, None)
+        # dx = d_qkv W_in
         call("lego_linear_bwd_data", _ptr(ws["d_qkv"]), 3 * D, _ptr(P[pre + "multi_head_attention.in_proj_weight"]), D,
-             dx_ptr, D, rows, rows_dyn, 3 * D, D, 0, None, 0, 1.0, ri, dr, cs, None, None, st)
+             dx_ptr, D, rows, rows_dyn, 3 * D, D, 0, None, 0, 1.0, None, None, None, None, None, st)
 
     _deferred = ()
 
@@ -1367,17 +1335,16 @@ class NrmsEngine(_Base):
         self._long_lists(self.__dict__, _stream())
 
     _folds_fresh = False
-    # GloVe variant: mask + Dropout backward and the projection bias gradient in the epilogue of dx = d_qkv W_in, [SEP] / category
-    # gradients from row sums of d(qkv).  Correct (test_nrms_folded_linear_equals_unfolded runs both forms) and 31 us shorter on the
-    # main stream, but the three extra side-stream launches land behind the in-projection weight gradient, where the side stream is
-    # already the longer one: 1.240 against 1.212 ms per step.  Off until the side stream has room.
-    fused_mask = os.environ.get("LEGO_NRMS_FUSED_MASK") == "1"
-
     def _forward_items(self, training, planned=False):
         P, D = self.P, self.D
         st = _stream()
         self._prepare_folds()
         self._folds_fresh = True
+        if self._dc_e_pending:                       # a per-key forward pass with no backward behind it left its row expansion (E, on the side
+            m_, sw_ = self._side()                   # stream, reading Eu) un-joined: EVERY branch below rewrites E or Eu
+            if sw_ is not m_:
+                m_.wait_event(self._sev[9])
+            self._dc_e_pending = False
         if not (planned and getattr(self, "_slots", None) is not None):      # else: done with the plan (plan_on)
             self._decode_gather(self.__dict__, current_stream())
         self._dc_active = False
@@ -1389,9 +1356,6 @@ class NrmsEngine(_Base):
             if dp is not None:                       # W_in^T for the two correction kernels (768 KB, once per step)
                 with torch.cuda.stream(m):
                     self.WinT.copy_(P["item_op.multi_head_attention.in_proj_weight"].t())
-            if self._dc_e_pending and sw is not m:   # a forward pass with no backward behind it left its row expansion un-joined: it reads Eu
-                m.wait_event(self._sev[9])
-            self._dc_e_pending = False
             # Hu = projection of the distinct TOKEN keys ([SEP] / category keys: zero rows of Xu, masked next) ...
             call("lego_linear_fwd", _ptr(self.Xu), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
                  _ptr(P["embedding_vocab_table.glove.linear.bias"]), _ptr(self.Hu), D, self.Uc, self.cnt(6), D, E0, 0,
@@ -1497,34 +1461,6 @@ class NrmsEngine(_Base):
         self._deferred = []
         g_spec, g_cat = G["embedding_vocab_table.__cat_inputer_special_ids.weight"], G["embedding_vocab_table.category.weight"]
         n_cat = g_cat.shape[0]
-        epi = None
-        fused = self.glove and self.fused_mask
-        if fused:
-            # the data gradient of the in-projection lands in dE already masked + dropout-scaled, with the projection's bias gradient as
-            # its column sums (one epilogue instead of two more passes over dE: 20 + 18-26 us of the main stream's tail)
-            epi = (_ptr(self.tokinfo), self.drop(self.p_proj, SITE_PROJ, training), _ptr(G["embedding_vocab_table.glove.linear.bias"]))
-        if self.dropcorr_bwd and self._dc_active:
-            E0 = self.E0
-            self._att_bwd("item_op.", self.item_ws, G, _ptr(self.Eu), _ptr(self.dHu), self.cnt(0), self.seg_off, self.NIc,
-                          self.cnt(1), self.d_items, SITE_ITEM_ATT, training, st, sev[2:4], per_key="dropcorr")
-            # dHu = d(Eu): the [SEP] / category keys' rows are those tables' gradients (one key per table row) ...
-            call("lego_scatter_add_rows_range", _ptr(g_spec), D, D, _ptr(self.idx_spec_u), self.Uc, self.cnt(6), _ptr(self.dHu), D, 0, 3, st)
-            call("lego_scatter_add_rows_range", _ptr(g_cat), D, D, _ptr(self.idx_cat_u), self.Uc, self.cnt(6), _ptr(self.dHu), D, 0, n_cat, st)
-            # ... the token keys' rows, times the Dropout's 1 / (1 - p), go on into the projection: bias = column sums, weight = dHu^T Xu
-            dp = self._dc_drop
-            call("lego_scale_mask_rows", _ptr(self.dHu), D, self.Uc, self.cnt(6), D, _ptr(self.tokinfo_u),
-                 1.0 / (1.0 - self.p_proj) if dp is not None else 1.0, st)
-            call("lego_colsum", _ptr(self.dHu), D, self.Uc, self.cnt(6), None, D, _ptr(G["embedding_vocab_table.glove.linear.bias"]), st)
-            self.kk(m, "proj_bwd_weight", "lego_linear_bwd_weight", _ptr(self.dHu), D, _ptr(self.Xu), E0,
-                    _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Uc, self.cnt(6), D, E0, None, None)
-            for side in self._deferred:
-                side()
-            self._deferred = ()
-            if sw is not m:
-                sev[4].record(sw)
-                m.wait_event(sev[4])
-            self.step = step_save
-            return
         if self.qkv_dedup:
             self._att_bwd("item_op.", self.item_ws, G, _ptr(self.Eu), _ptr(self.dHu), self.cnt(0), self.seg_off, self.NIc,
                           self.cnt(1), self.d_items, SITE_ITEM_ATT, training, st, sev[2:4], per_key=True)
@@ -1539,28 +1475,10 @@ class NrmsEngine(_Base):
             self.step = step_save
             return
         self._att_bwd("item_op.", self.item_ws, G, _ptr(self.E), _ptr(self.dE), self.cnt(0), self.seg_off, self.NIc,
-                      self.cnt(1), self.d_items, SITE_ITEM_ATT, training, st, sev[2:4], dx_epi=epi)
+                      self.cnt(1), self.d_items, SITE_ITEM_ATT, training, st, sev[2:4])
         # embedding tables: the three summed look-ups of ConcatInputer.get_embeddings.  [SEP] (id 2 of the special table) and the
         # category row come from fixed places of every item's sequence (lego_nrms_special_grads)
-        if fused:
-            # ... whose gradient rows the mask has just zeroed in dE: take them one product earlier.  sum_r dE[r] over a set of rows =
-            # (sum_r d_qkv[r]) W_in, so the kernel sums the [SEP] / category ROWS OF d_qkv (3 rows per item) and two tiny products map
-            # the sums through W_in -- on the side stream, behind the in-projection weight gradient
-            ws, W_in = self.item_ws, P["item_op.multi_head_attention.in_proj_weight"]
-            if "S_sep" not in ws:
-                ws["S_sep"], ws["S_cat"] = self._f(3 * D), self._f(n_cat, 3 * D)
-            _, sw_ = self._side()
-
-            def side_special():
-                spp = stream_handle(sw_)
-                with torch.cuda.stream(sw_):
-                    torch._foreach_zero_([ws["S_sep"], ws["S_cat"]])
-                call("lego_nrms_special_grads", _ptr(self.seg_off), self.NIc, self.cnt(1), _ptr(self.idx_cat), _ptr(ws["d_qkv"]), 3 * D, 3 * D,
-                     _ptr(ws["S_sep"]), _ptr(ws["S_cat"]), 3 * D, n_cat, spp)
-                call("lego_small_rows_matmul_add", _ptr(ws["S_sep"]), 1, _ptr(g_spec, 2 * D), D, _ptr(ws["S_cat"]), n_cat, _ptr(g_cat), D,
-                     _ptr(W_in), 3 * D, D, spp)
-            self._deferred.append(side_special)
-        elif n_cat > 32:                             # category tables beyond the segment kernel's 32-row LDS image: two generic
+        if n_cat > 32:                               # category tables beyond the segment kernel's 32-row LDS image: two generic
             # scatters over the sequence rows (the segment kernel replaced them and hard-failed above 32 rows)
             call("lego_scatter_add_rows", _ptr(g_cat), D, D, n_cat, _ptr(self.idx_cat), self.Rc, self.cnt(0), _ptr(self.dE), D, st)
             call("lego_scatter_add_rows", _ptr(g_spec), D, D, 3, _ptr(self.idx_spec), self.Rc, self.cnt(0), _ptr(self.dE), D, st)
@@ -1572,8 +1490,8 @@ class NrmsEngine(_Base):
             gb = _ptr(G["embedding_vocab_table.glove.linear.bias"])
             dp = self.drop(self.p_proj, SITE_PROJ, training)
             # with the keep bits at hand (or nothing to drop) the per-token sums mask and rescale dE as they read it
-            in_sums = self.dedup and not fused and (dp is None or self._mask_step == self.step)
-            if not fused and not in_sums:            # the three-pass form (kept as the cross-check of the fused epilogue)
+            in_sums = self.dedup and (dp is None or self._mask_step == self.step)
+            if not in_sums:                          # the three-pass form (keep bits not drawn with the plan)
                 call("lego_mask_dropout_rows", _ptr(self.dE), D, self.Rc, self.cnt(0), D, _ptr(self.tokinfo),
                      dp, None if self.dedup else gb, st)
             if self.dedup:                           # per-token sums of the masked dE, then the product over the distinct tokens
@@ -1581,8 +1499,7 @@ class NrmsEngine(_Base):
                      self.cnt(0), _ptr(self.dHu), D, self.Uc, self.cnt(6), 0 if self._dhu_zeroed else 1, dp if in_sums else None,
                      _ptr(self.tokinfo) if in_sums else None, st)
                 self._dhu_consumed()
-                if not fused:                        # the bias gradient = column sums of the masked dE = column sums of the per-token sums
-                    call("lego_colsum", _ptr(self.dHu), D, self.Uc, self.cnt(6), None, D, gb, st)
+                call("lego_colsum", _ptr(self.dHu), D, self.Uc, self.cnt(6), None, D, gb, st)      # bias gradient = column sums of the per-token sums
                 call("lego_linear_bwd_weight", _ptr(self.dHu), D, _ptr(self.Xu), E0,
                      _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Uc, self.cnt(6), D, E0, None, None, st)
             else:

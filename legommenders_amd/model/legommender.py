@@ -216,9 +216,9 @@ class Legommender(nn.Module):
         else:
             hist = batch[self.cm.history_col]
             if isinstance(hist, torch.Tensor):                       # id-only batch: the sample the resampler's user inputer would have
-                m = batch[self.cm.mask_col].to(Env.device)           # built (resampler.py:222-226) -- ids, pads UNSET, the clicks mask
-                hist = {"input_ids": {self.cm.history_col: torch.where(m > 0, hist.to(Env.device).long(), torch.full_like(m, Env.UNSET).long())},
-                        "attention_mask": m}
+                m = batch[self.cm.mask_col].to(Env.device).long()    # built (resampler.py:222-226) -- ids, pads UNSET, the clicks mask
+                ids = hist.to(Env.device).long()                     # (the pad value is built on the id tensor: a bool / uint8 mask cannot hold -1)
+                hist = {"input_ids": {self.cm.history_col: ids.masked_fill(m <= 0, Env.UNSET)}, "attention_mask": m}
             clicks = self.user_op.inputer.get_embeddings(hist)
         return self.user_op(clicks, mask=batch[self.cm.mask_col].to(Env.device))
 
@@ -256,8 +256,8 @@ class Legommender(nn.Module):
     # On an id-only batch the candidates and the live history slots are the same kind of thing -- item ids -- so ONE item-operator call
     # encodes both (round 4): for the BERT news encoder that is one 30 k-row pass through the blocks instead of a 24 k-row and a 6 k-row
     # one (the products lose efficiency below ~10 k rows, and every launch is paid once).  Values are those of the two-call form
-    # (`LEGO_ONE_ITEM_CALL=0`); only the dropout streams are numbered differently.
-    one_item_call = os.environ.get("LEGO_ONE_ITEM_CALL", "1") != "0"
+    # (class attribute `one_item_call = False`); only the dropout streams are numbered differently.
+    one_item_call = True
 
     def _one_call_ok(self, batch):
         col, hcol = self.cm.item_col, self.cm.history_col

@@ -296,8 +296,8 @@ class BertOperator(LMOperator, abc.ABC):
     # positions that are pads in ALL of its items: masked keys never enter a softmax and the pool after the blocks skips masked
     # positions, so the live outputs are the same numbers (up to the GEMM library's summation order for another row count).
     # `Legommender.get_item_content` sorts the items of a batch by live length before paging, so a page of 64 items is cut to its
-    # own longest sequence: 18.5 instead of 31 positions on average.  LEGO_BERT_TRIM=0: the full length, as the reference.
-    trim_pads = os.environ.get("LEGO_BERT_TRIM", "1") != "0"
+    # own longest sequence: 18.5 instead of 31 positions on average.  `trim_pads = False`: the full length, as the reference.
+    trim_pads = True
 
     @staticmethod
     def _trim(states, mask):

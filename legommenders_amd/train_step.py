@@ -256,7 +256,6 @@ class TrainStep:
         self._hist_len = [torch.zeros(B, **i32) for _ in range(2)]
         self.cand, self.hist, self.hist_len = self._cand[0], self._hist[0], self._hist_len[0]
         self.prefetch = str(dev) != "cpu"
-        self._prefetch_at_go = os.environ.get("LEGO_PREFETCH_AT", "neck") == "go"
         if self.prefetch:
             self.engine.enable_plan_slots()
             self.pre = shared_stream(dev, "prefetch")
@@ -274,7 +273,7 @@ class TrainStep:
         self.accumulate, self._acc, self.batch_idx = max(1, int(accumulate)), 0, 0
         self.pg, self.world = process_group, world_size
         self.force_allreduce = force_allreduce
-        self.overlap_exchange = os.environ.get("LEGO_OVERLAP_EXCHANGE", "1") != "0"
+        self.overlap_exchange = True               # tests set it to False to exchange the whole buffer after the backward pass
         self.counter_sum = torch.zeros(8, dtype=torch.int64, device=dev)
         self._grad_clean = True                    # FlatParams allocates a zeroed gradient buffer
 
@@ -394,8 +393,8 @@ class TrainStep:
         _, loss = self.engine.forward(self.cand, self.hist, self.hist_len, training=True, planned=self.prefetch,
                                       fork_ev=go, neck_ev=neck)
         if self.prefetch:
-            # next batch: starts where this step's item tower ends (LEGO_PREFETCH_AT=go, A/B: at the head of this step's forward pass instead)
-            self._prefetch(self.batch_idx + 1, go if self._prefetch_at_go else neck)
+            # next batch: starts where this step's item tower ends (at the head of this step's forward pass instead: no faster)
+            self._prefetch(self.batch_idx + 1, neck)
         self.engine.grad_hooks = self._exchange_hooks() if (last_of_cycle and self.overlap_exchange) else None
         self.engine.backward(self.fp.G)
         self.engine.grad_hooks = None

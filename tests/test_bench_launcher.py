@@ -41,6 +41,27 @@ def test_world_size_mismatch_fails_loudly():
     assert r.returncode != 0 and "{" not in r.stdout
 
 
+def test_no_fraction_of_a_peak_above_one_and_per_key_pricing():
+    """the per-key in-projection launch was priced with the ROW count (frac 2.2 of the matrix peak).  The pricing
+    table takes the distinct-key count for such an engine, and the line lists every `*frac*` entry above 1 (none is acceptable)."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class Eng:
+        qkv_dedup, dropcorr = False, True
+    assert bench.per_key_of(Eng) and not bench.per_key_of(object())
+    rows, keys, D = 30800.0, 4600.0, 256
+    assert bench.nrms_flops(rows, D, 300, per_key=keys)["qkv_fwd_item"] == 2.0 * keys * D * 3 * D
+    assert bench.nrms_flops(rows, D, 300)["qkv_fwd_item"] == 2.0 * rows * D * 3 * D
+    line = {"roofline": {"frac": 0.86}, "kernels": {"a": {"frac_of_f32_mfma_peak": 2.19, "in_region": {"frac_of_f32_mfma_peak": 0.4}}},
+            "secondary": [{"x": {"frac_of_hbm_peak": 1.01}}]}
+    assert bench.fracs_over_one(line) == ["kernels.a.frac_of_f32_mfma_peak=2.19", "secondary[0].x.frac_of_hbm_peak=1.01"]
+    assert bench.fracs_over_one({"conv3_fwd": {"frac_of_f32_mfma_peak": 1.016, "mfma_issue_frac": 0.677}}) == []      # Winograd: direct-conv pricing
+    assert bench.fracs_over_one({"conv3_fwd": {"frac_of_f32_mfma_peak": 1.6, "mfma_issue_frac": 1.07}}) != []
+    st = bench.step_roofline("nrms", {}, 0.98e-3, {"rows": rows, "uniq": keys, "glove": True, "per_key": True}, D, 300, ())
+    assert 0.0 < st["issued_frac"] < st["frac"] < 1.0
+
+
 import pytest  # noqa: E402
 
 
@@ -62,3 +83,5 @@ def test_the_drivers_command_prints_one_line_with_the_contract_fields():
     assert roof["bound"] in ("mfma", "hbm") and roof["unit"] in ("TFLOP/s", "GB/s") and roof["peak"] > 0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and "traffic" in roof
     assert "cpu_baseline" in j and j["cpu_baseline"] is None          # skipped by the flag; the key stays
+    assert j["fracs_over_one"] == [], j["fracs_over_one"]
+    assert j["value_without_prewarm"] > 0 and j["without_prewarm"]["steps"] == 6

@@ -514,11 +514,12 @@ def test_fused_user_tower_matches_unfused():
     _grads_close(g_fused, G, "fused")
 
 
-@pytest.mark.parametrize("env", [{"LEGO_SERIAL": "1"}, {"LEGO_WINO": "0"}, {"LEGO_SERIAL": "1", "LEGO_WINO": "0"}, {"LEGO_DEDUP": "0"},
-                                 {"LEGO_DMA": "0"}, {"LEGO_EPI_ROWS": "0"}, {"LEGO_WINO_DMA": "1"}, {"LEGO_DEDUP_BWD": "0"}])
+@pytest.mark.parametrize("env", [{"LEGO_SERIAL": "1"}, {"LEGO_WINO": "0"}, {"LEGO_SERIAL": "1", "LEGO_WINO": "0"}, {"LEGO_DEDUP": "0"}])
 def test_switches_keep_the_result(env, monkeypatch):
-    """the two environment switches the product still reads (tools/README.md): single-stream launch order for profiling and
-    the direct three-tap conv instead of the Winograd form -- same logits, loss and gradients as the reference fixture"""
+    """the NAML engine's environment switches (tools/README.md lists every switch the product reads): single-stream launch order for
+    profiling, the direct three-tap conv instead of the Winograd form, the row-by-row projection instead of the de-duplicated one -- same
+    logits, loss and gradients as the reference fixture.  (The NRMS engine's three -- LEGO_NRMS_DEDUP, LEGO_NRMS_QKV_DEDUP,
+    LEGO_NRMS_DROPCORR -- are held by test_nrms_projection_once_per_distinct_token and the per-key trajectory tests; the BERT operator's by tests/test_bert_operator.py.)"""
     from legommenders_amd.engine import ItemTables, NamlEngine
     dev = _dev()
     for k, v in env.items():
@@ -705,19 +706,19 @@ def test_winograd_conv_matches_direct_and_torch(D, n_items):
     d0 = torch.zeros(R, D, device=dev); d1 = torch.zeros(R, D, device=dev)
     c0 = torch.zeros(D, device=dev); c1 = torch.zeros(D, device=dev)
     call("lego_conv3_bwd_data", P(gyd), D, P(wt), P(rowinfo), P(d0), D, R, P(cnt, 0), D, D, None, P(c0), 0, None)
-    call("lego_conv3_wino_bwd_data", P(gyd), D, P(u), None, P(pair), Pcap, P(cnt, 5), P(d1), D, D, D, None, P(c1), None)
-    d2 = torch.zeros(R, D, device=dev); c2 = torch.zeros(D, device=dev)       # same product from the transposed weight sets
-    call("lego_conv3_wino_bwd_data", P(gyd), D, P(u), P(ut), P(pair), Pcap, P(cnt, 5), P(d2), D, D, D, None, P(c2), None)
+    call("lego_conv3_wino_bwd_data", P(gyd), D, P(u), P(ut), P(pair), Pcap, P(cnt, 5), P(d1), D, D, D, None, P(c1), None)
     torch.cuda.synchronize()
     assert torch.equal(ut, u.transpose(1, 2).contiguous())
-    _close(d2.cpu(), d0.cpu(), rtol=2e-5, what="wino bwd_data (transposed sets) vs direct")
-    _close(c2.cpu(), c0.cpu(), rtol=2e-5, what="wino bwd_data (transposed sets) column sums")
+    with pytest.raises(_lib.LegoHipError, match="transposed"):            # ABI 8: the data gradient reads the transposed sets only
+        call("lego_conv3_wino_bwd_data", P(gyd), D, P(u), None, P(pair), Pcap, P(cnt, 5), P(d1), D, D, D, None, P(c1), None)
     S = _lib.lib().lego_conv3_wino_du_slabs(D, D, Pcap)      # 1 for short reductions (atomics), one slab per k split otherwise
     dwt = torch.zeros(3, D, D, device=dev); du = torch.full((S, 4, D, D), float("nan") if S > 1 else 0.0, device=dev)
     gw0 = torch.zeros(D, D, 3, device=dev); gw1 = torch.zeros(D, D, 3, device=dev)
     call("lego_conv3_bwd_weight", P(gyd), D, P(hd), D, P(rowinfo), P(dwt), R, P(cnt, 0), D, D, None)
     call("lego_conv3_unpack_add", P(dwt), P(gw0), D, D, None)
-    call("lego_conv3_wino_bwd_weight", P(gyd), D, P(hd), D, P(pair), Pcap, P(cnt, 5), P(du), D, D, None)
+    with pytest.raises(_lib.LegoHipError, match="slab"):                  # ABI 8: a slab count that is not the launch's is refused
+        call("lego_conv3_wino_bwd_weight", P(gyd), D, P(hd), D, P(pair), Pcap, P(cnt, 5), P(du), S + 1, D, D, None)
+    call("lego_conv3_wino_bwd_weight", P(gyd), D, P(hd), D, P(pair), Pcap, P(cnt, 5), P(du), S, D, D, None)
     call("lego_conv3_wino_unpack_add", P(du), S, P(gw1), D, D, None)
     torch.cuda.synchronize()
     assert S > 1 or float(du.abs().max()) == 0.0             # a single accumulator is handed back clean; slabs are overwritten
@@ -884,7 +885,7 @@ def test_grouped_metrics_kernel_at_evaluation_size_and_edges():
         PM.calculate_device(torch.tensor([0.3], device=dev), np.array([1]), np.array([0]), ["Precision@5"])
 
 
-@pytest.mark.parametrize("kind", ["naml", "nrms"])
+@pytest.mark.parametrize("kind", ["naml", "nrms", "nrms_glove"])
 def test_headline_size_oracle_and_properties(kind):
     """BASELINE.json configs 2 / 3 at their full batch shape (D=256, B=64, C=5, S=50, 65 238 items; the token vocabulary is
     cut to 50 k rows to bound host memory): the engine against the oracle directly, then the size-independent properties
@@ -903,6 +904,12 @@ def test_headline_size_oracle_and_properties(kind):
         P = init_naml_params(D=D, V=V, n_cat=w["n_cat"], glove=glove_like(V, 300, seed=2024, device=dev))
         mk = lambda b: E.NamlEngine(Pd, tb, b, C, S, p_proj=0.0, p_conv=0.0)
         okw = {}
+    elif kind == "nrms_glove":
+        # config 3 as bench.py times it: frozen GloVe + Linear, the in-projection per DISTINCT key (engine.NrmsEngine.dropcorr; with
+        # p = 0 the correction term is empty -- test_headline_size_per_key_in_projection_with_dropout below runs it with Dropout on)
+        P = init_nrms_params(D=D, V=V, n_cat=w["n_cat"], heads=8, glove=glove_like(V, 300, seed=2024, device="cpu"))
+        mk = lambda b: E.NrmsEngine(Pd, tb, b, C, S, heads=8, glove=True, p_proj=0.0, p_att=0.0)
+        okw = dict(heads=8, glove=True)
     else:
         P = init_nrms_params(D=D, V=V, n_cat=w["n_cat"], heads=8, glove=None)
         mk = lambda b: E.NrmsEngine(Pd, tb, b, C, S, heads=8, glove=False, p_proj=0.0, p_att=0.0)
@@ -930,9 +937,13 @@ def test_headline_size_oracle_and_properties(kind):
         return scores.clone(), float(loss), G
 
     eng = mk(B)
+    if kind == "nrms_glove":
+        assert eng.dropcorr, "the per-key in-projection is the route under test"
     scores, loss, G = run(eng, cand, hist, hl)
+    if kind == "nrms_glove":
+        assert eng._dc_active
     tables = {k: w[k].astype(np.int64) for k in ("title_tok", "title_len", "cat")}
-    lg, ls, g = O.loss_and_grads(kind, {k: v.cpu().numpy() for k, v in P.items()}, tables, cand, hist, hl, **okw)
+    lg, ls, g = O.loss_and_grads(kind.split("_")[0], {k: v.cpu().numpy() for k, v in P.items()}, tables, cand, hist, hl, **okw)
     assert float(np.abs(scores.cpu().numpy() - lg).max()) < 2e-4 and abs(loss - ls) < 2e-5
     _grads_close(G, g, f"{kind} headline size")
     Gn = {k: v.cpu().numpy() for k, v in G.items()}
@@ -962,6 +973,41 @@ def test_headline_size_oracle_and_properties(kind):
         _close(s5.cpu(), scores.cpu().numpy()[sl], rtol=2e-6, atol=2e-6, what="half-batch logits")
         acc = G5 if acc is None else {k: acc[k] + G5[k] for k in acc}
     _grads_close({k: v * 0.5 for k, v in acc.items()}, Gn, "two half batches")
+
+
+def test_headline_size_per_key_in_projection_with_dropout(monkeypatch):
+    """BASELINE config 3 at its full shape (D=256, B=64, C=5, S=50, 65 238 items, GloVe projection) WITH Dropout: TrainStep (plan slots,
+    keep bits drawn with the plan, Adam) through the per-key in-projection + sparse Dropout correction (engine default,
+    csrc/dropcorr_ops.hip) against the row-by-row in-projection (LEGO_NRMS_DROPCORR=0) on the same seeds and Philox streams -- the two
+    forms compute the same function of the same keep bits (embedding_hub.py:95-96 + attention_operator.py:49-55), so the per-step losses
+    and the parameters after 12 steps agree to fp32 summation order.  (Every slot is used six times: a re-used slot carries nothing over.)"""
+    from legommenders_amd.synthetic import glove_like, init_nrms_params, make_world
+    from legommenders_amd.train_step import DeviceData, TrainStep
+    dev = _dev()
+    D, B, V = 256, 64, 50000
+    w = make_world(seed=2023, n_users=4000, n_rows=4000, V=V)
+    assert w["n_items"] == 65238
+    glove = glove_like(V, 300, seed=2024, device=dev)
+    traj, final = {}, {}
+    for form in ("0", "1"):
+        monkeypatch.setenv("LEGO_NRMS_DROPCORR", form)
+        P = init_nrms_params(D=D, V=V, n_cat=w["n_cat"], heads=8, glove=glove, seed=6)
+        ts = TrainStep("nrms", P, DeviceData(w, dev, seed=5), B, K=4, seed=5, glove=True, dropout=True, lr=1e-3, total_steps=0, tail="drop")
+        assert ts.engine.dropcorr == (form == "1")
+        losses = [ts.step().clone() for _ in range(12)]
+        torch.cuda.synchronize()
+        assert ts.engine._dc_active == (form == "1")
+        traj[form] = np.array([float(x) for x in losses])
+        final[form] = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in ts.fp.P.items() if k in ts.fp.offsets}
+        del ts
+    d = np.abs(traj["1"] - traj["0"])
+    assert d.max() < 2e-5, (int(d.argmax()), float(d.max()), traj["0"][:6], traj["1"][:6])
+    assert np.all(np.isfinite(traj["1"]))         # (the MIND-shaped world is label-free: the loss stays near ln 5)
+    # Adam's first steps are sign-like (|update| ~ lr whatever the gradient's size), so parameters are compared against the distance
+    # travelled: 12 steps of lr = 1e-3 move an element by up to 1.2e-2
+    for k, a in final["0"].items():
+        diff = float(np.abs(final["1"][k] - a).max())
+        assert diff <= 6e-4, (k, diff)
 
 
 def test_eval_caches_through_the_collective_path():
@@ -1338,16 +1384,13 @@ def test_nrms_projection_once_per_distinct_token(planned, glove, monkeypatch):
     # forms: row by row / per distinct token (projection, table gradient) / -- trainable table only -- the in-projection per distinct KEY
     # (GloVe, round 5: "1", "2" = the in-projection per distinct key WITH the sparse Dropout correction -- csrc/dropcorr_ops.hip -- which the
     # planned form takes; the un-planned form has no keep bits ahead of time and falls back to the row-by-row product in the key space)
-    # "3" = "2" plus the per-key backward pass (opt-in, LEGO_NRMS_DROPCORR_BWD=1)
-    forms = [("0", "0"), ("1", "0")] + ([("1", "2"), ("1", "3")] if glove else [("1", "1")])
+    forms = [("0", "0"), ("1", "0")] + ([("1", "2")] if glove else [("1", "1")])
     for dedup, per_key in forms:
         monkeypatch.setenv("LEGO_NRMS_DEDUP", dedup)
         monkeypatch.setenv("LEGO_NRMS_QKV_DEDUP", "1" if per_key == "1" else "0")
-        monkeypatch.setenv("LEGO_NRMS_DROPCORR", "1" if per_key in ("2", "3") else "0")
-        monkeypatch.setenv("LEGO_NRMS_DROPCORR_BWD", "1" if per_key == "3" else "0")
+        monkeypatch.setenv("LEGO_NRMS_DROPCORR", "1" if per_key == "2" else "0")
         eng = E.NrmsEngine(Pd, tb, B, C, S, heads=8, glove=glove, seed=77)
-        assert eng.dedup == (dedup == "1") and eng.qkv_dedup == (per_key == "1") and eng.dropcorr == (per_key in ("2", "3"))
-        assert eng.dropcorr_bwd == (per_key == "3")
+        assert eng.dedup == (dedup == "1") and eng.qkv_dedup == (per_key == "1") and eng.dropcorr == (per_key == "2")
         G = eng.grads_like()
         if planned:
             eng.enable_plan_slots()
@@ -1358,7 +1401,7 @@ def test_nrms_projection_once_per_distinct_token(planned, glove, monkeypatch):
                 eng.prefetch_masks(torch.cuda.current_stream(), i % 2)     # keep bits with the plan: expansion and per-token sums read them
                 eng.use_slot(i % 2)
             scores, loss = eng.forward(*ids, training=True, planned=planned)
-            assert eng._dc_active == (per_key in ("2", "3") and planned)
+            assert eng._dc_active == (per_key == "2" and planned)
             eng.backward(G)
             res.append((scores.clone(), float(loss)))
         torch.cuda.synchronize()
@@ -1408,8 +1451,7 @@ def test_nrms_training_trajectory_per_key_in_projection(monkeypatch):
 def test_in_projection_per_key_with_dropout_correction(D, R, U, p):
     """csrc/dropcorr_ops.hip against the dense row-by-row form it replaces (embedding_hub.py:95-96 + attention_operator.py:49-55):
     q|k|v rows  E_r W^T + b  with  E_r = keep_r . Eu[k] / (1 - p)  for token rows and  Eu[k]  for the others, from the per-key product
-    Eu W^T and the sparse correction; and the data gradient's correction  dEu[k][c] -= g_r . W[:, c]  over the dropped coordinates --
-    same keep bits (lego_dropout_mask), float64 references; plus the plain expansion (no Dropout) and the row scaling / masking"""
+    Eu W^T and the sparse correction -- same keep bits (lego_dropout_mask), float64 references; plus the plain expansion (no Dropout)"""
     import ctypes
     from legommenders_amd._lib import call, LegoDropout
     dev = _dev()
@@ -1447,24 +1489,6 @@ def test_in_projection_per_key_with_dropout_correction(D, R, U, p):
     out2 = torch.zeros(R, N, device=dev)
     call("lego_qkv_expand_dropcorr", P(QKVu_d), N, P(Eu_d), D, None, N, P(b_d), P(inv_d), P(ri_d), None, R, P(cnt), D, N, P(out2), N, None)
     _close(out2.cpu(), (Eu[inv.long()].double() @ W.double().T + b.double()).float(), rtol=3e-5, what="q|k|v rows, plain expansion")
-    # backward correction
-    g = torch.randn(R, N, generator=g_)
-    deu0 = torch.randn(U, D, generator=g_)
-    deu = deu0.clone().to(dev)
-    call("lego_dropcorr_bwd", P(g.to(dev)), N, P(WT_d), N, P(inv_d), P(ri_d), dr, R, P(cnt), D, N, P(deu), D, None)
-    gw = g.double() @ W.double()                                                            # [R, D]: g_r . W[:, c]
-    corr = torch.zeros(U, D, dtype=torch.float64).index_add_(0, inv.long(), gw * ((~keep) & live[:, None]))
-    _close(deu.cpu(), (deu0.double() - corr).float(), rtol=3e-5, what="data-gradient correction")
-    # together: dEu = s * (sum_r g_r W - corr) equals the dense form  sum_r s keep_r . (g_r W)  for the token rows
-    dense = torch.zeros(U, D, dtype=torch.float64).index_add_(0, inv.long(), gw * keep * live[:, None] * scale)
-    sums = torch.zeros(U, N, dtype=torch.float64).index_add_(0, inv.long(), g.double() * live[:, None])
-    deu2 = (sums @ W.double()).float().to(dev)
-    call("lego_dropcorr_bwd", P(g.to(dev)), N, P(WT_d), N, P(inv_d), P(ri_d), dr, R, P(cnt), D, N, P(deu2), D, None)
-    ulive = torch.zeros(U, dtype=torch.int32)
-    ulive[::2] = 4
-    call("lego_scale_mask_rows", P(deu2), D, U, None, D, P(ulive.to(dev)), scale, None)
-    want = dense.float() * (ulive[:, None] != 0)
-    _close(deu2.cpu(), want, rtol=5e-5, what="per-key data gradient = dense form")
 
 
 @pytest.mark.parametrize("D,A", [(256, 256), (96, 40), (32, 0)])
