@@ -669,7 +669,9 @@ def main():
             for name, tf, st, wu in (("tune_from_0", 0, 6, 6), ("tune_from_9_cached_layer", 9, 10, 2)):
                 r = bert_naml_bench.run(batch=B, steps=st, warmup=wu, layers=12, hidden=D, tune_from=tf)
                 bsec[name] = {"steps": st, "warmup": wu, "ms_per_step": round(r["s_per_step"] * 1e3, 2), "value": r["impressions_per_s"],
-                              "timing": r["timing"], "step_ms": r["step_ms"], "ms_per_step_mean": round(r["s_per_step_mean"] * 1e3, 2),
+                              "timing": r["timing"], "step_ms": r["step_ms"], "step_ms_max_over_min": r["step_ms_max_over_min"], "live_rows_per_step": r["live_rows_per_step"],
+                              "us_per_live_row": r["us_per_live_row"], "us_per_live_row_max_over_min": r["us_per_live_row_max_over_min"],
+                              "workspace_arena": r["workspace_arena"], "torch_allocator": r["torch_allocator"], "ms_per_step_mean": round(r["s_per_step_mean"] * 1e3, 2),
                               "unit": "impressions/s", "bert_blocks_run": r["bert_layers_run"], "trainable_params": r["trainable_params"],
                               "layer_cache_s": r["layer_cache_s"], "layer_cache_GB": r["layer_cache_GB"], "final_loss": round(r["loss"], 4),
                               "item_page_size_yaml": r["item_page_size"], "item_page_effective": r["effective_item_page"],
@@ -679,7 +681,7 @@ def main():
             sec["bert_naml_base"] = dict(bsec, workload=f"MIND-small-shaped BERT-NAML (BASELINE config 5): BertConfig() defaults "
                                          f"(768 x 12 blocks x 12 heads, random init), item_page_size 64 in the yaml (raised to one call per batch side: same values, "
                                          f"fuller launches; only the LIVE history slots are encoded), hidden={D} bs={B}, "
-                                         f"5 000-item world, full plug-in train step (device sampler ids, fwd, bwd, torch Adam), fp32")
+                                         f"5 000-item world, full plug-in train step (PluginStep: device sampler ids, fwd, bwd, one lego_adam_step over the flat buffers), fp32")
         # OPT-IN product mode (include/lego_hip.h: lego_set_product_mode; never the headline): split-bf16 operands (bf16 x 3, fp32
         # accumulate) for the large dense products.  Same workloads, same seeds, engines rebuilt in that mode (NAML takes the direct
         # conv: the Winograd kernels have no split form); logits within ~1e-6 of the oracle, gradients 2e-3 (tests/test_split_bf16.py)

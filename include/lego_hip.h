@@ -393,6 +393,16 @@ int lego_dropout_add_layernorm_bwd(const float* dout, int lddo, const float* y, 
                                    int rows, int width, void* stream);
 /* g = z Phi(z) (erf form) over n contiguous floats; dz = dg (Phi(z) + z phi(z)), dz may alias dg */
 int lego_gelu_fwd(const float* z, float* g, int64_t n, void* stream);
+/* (ABI 8) BertIntermediate / BertOutput.dense of the BERT news encoder (reference model/operators/bert_operator.py:16 ->
+ * transformers modeling_bert.py BertIntermediate.forward, BertOutput.forward) with the GELU inside the product's epilogue:
+ *   lego_linear_gelu_fwd       z[M,N] = x[M,K] W[N,K]^T + bias  (kept for the backward pass),  g[M,N] = gelu(z)
+ *   lego_linear_bwd_data_gelu  dz[M,K] = (dy[M,N] W[N,K]) * gelu'(z[M,K])
+ * -- the same numbers as lego_linear_fwd + lego_gelu_fwd and lego_linear_bwd_data + lego_gelu_bwd (one rounding sequence), without the
+ * second pass over the [M, 3072] tensors. */
+int lego_linear_gelu_fwd(const float* x, int ldx, const float* W, int ldw, const float* bias /*nullable*/, float* z, int ldz, float* g, int ldg,
+                         int M, int N, int K, void* stream);
+int lego_linear_bwd_data_gelu(const float* dy, int ldy, const float* W, int ldw, const float* z, int ldz, float* dz, int lddz,
+                              int M, int N, int K, void* stream);
 int lego_gelu_bwd(const float* dg, const float* z, float* dz, int64_t n, void* stream);
 
 /* small utilities used by the host side */

@@ -90,6 +90,8 @@ SIGNATURES = {
     "lego_dropout_add_layernorm_bwd": [P, I, P, I, P, I, P, P, P, P, P, P, I, P, I, P, P, P, I, I, P],
     "lego_gelu_fwd": [P, P, I64, P],
     "lego_gelu_bwd": [P, P, P, I64, P],
+    "lego_linear_gelu_fwd": [P, I, P, I, P, P, I, P, I, I, I, I, P],
+    "lego_linear_bwd_data_gelu": [P, I, P, I, P, I, P, I, I, I, I, P],
     "lego_grouped_metrics": [P, P, P, I, P, I, P, P],
 }
 

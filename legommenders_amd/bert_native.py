@@ -31,6 +31,7 @@ import torch
 from . import functional as F_hip
 from . import kernels as K
 from ._lib import LegoDropout, call
+from .arena import arena_of
 from .kernels import _ptr, _stream
 
 LAYER_KEYS = ("attention.self.query.weight", "attention.self.query.bias", "attention.self.key.weight", "attention.self.key.bias",
@@ -39,6 +40,26 @@ LAYER_KEYS = ("attention.self.query.weight", "attention.self.query.bias", "atten
               "output.dense.weight", "output.dense.bias", "output.LayerNorm.weight", "output.LayerNorm.bias")
 EMBED_KEYS = ("position_embeddings.weight", "token_type_embeddings.weight", "LayerNorm.weight", "LayerNorm.bias")
 NL = len(LAYER_KEYS)
+# PluginStep (plugin_step.py) keeps every trainable parameter's gradient as a view of ONE flat buffer that its Adam launch reads and clears.
+# With DIRECT_GRADS on, the backward pass below accumulates each parameter gradient straight into `param.grad` when that is such a pre-set
+# fp32 tensor and hands autograd `None` for it: no per-step gradient buffer, no AccumulateGrad pass over 79 M elements.  Off (the default
+# outside PluginStep): gradients are returned to autograd as usual.
+DIRECT_GRADS = False
+ROWS_SEEN = None        # a list: the live-row count of every forward pass is appended (tools/bert_naml_bench.py: step time per row)
+
+
+def _stacked(ts):
+    """ONE [sum of rows, ...] view over tensors that lie back to back in one storage (PluginStep's flat buffers put q, k, v so), else None"""
+    t0 = ts[0]
+    if any(t is None for t in ts):
+        return None
+    base, off = t0.untyped_storage().data_ptr(), t0.storage_offset()
+    for t in ts:
+        if (not t.is_contiguous() or t.dtype != t0.dtype or t.untyped_storage().data_ptr() != base or t.storage_offset() != off
+                or t.shape[1:] != t0.shape[1:]):
+            return None
+        off += t.numel()
+    return torch.as_strided(t0, (sum(t.shape[0] for t in ts),) + tuple(t0.shape[1:]), t0.stride())
 
 
 def supported(transformer, L: int) -> Optional[str]:
@@ -133,6 +154,33 @@ def _lin_bwd_weight(g, ldg, col, x, gW, tag=None):
         call("lego_linear_bwd_weight", _ptr(g, col), ldg, _ptr(x), Kd, _ptr(gW), Kd, M, None, N, Kd, None, None, _stream())
 
 
+FUSED_GELU = True       # the GELU inside the two feed-forward products' epilogues (False: lego_gelu_fwd / _bwd as passes of their own -- the cross-check)
+
+
+def _ffn1_fwd(a, W1, b1, z, g):
+    """z = a W1^T + b1 (kept for GELU'), g = gelu(z)"""
+    M, Kd = a.shape
+    N = W1.shape[0]
+    if FUSED_GELU:
+        with _timed("ffn1_fwd", 2.0 * M * N * Kd):
+            call("lego_linear_gelu_fwd", _ptr(a), Kd, _ptr(W1), Kd, _ptr(b1), _ptr(z), N, _ptr(g), N, M, N, Kd, _stream())
+        return
+    _lin_fwd(a, W1, b1, z, N, tag="ffn1_fwd")
+    call("lego_gelu_fwd", _ptr(z), _ptr(g), z.numel(), _stream())
+
+
+def _ffn2_bwd_data(d_fo, W2, z, dz):
+    """dz = (d_fo W2) . gelu'(z)"""
+    M, N = d_fo.shape
+    Kd = W2.shape[1]
+    if FUSED_GELU:
+        with _timed("ffn2_bwd_data", 2.0 * M * N * Kd):
+            call("lego_linear_bwd_data_gelu", _ptr(d_fo), N, _ptr(W2), Kd, _ptr(z), Kd, _ptr(dz), Kd, M, N, Kd, _stream())
+        return
+    _lin_bwd_data(d_fo, N, 0, W2, dz, False, tag="ffn2_bwd_data")
+    call("lego_gelu_bwd", _ptr(dz), _ptr(z), _ptr(dz), dz.numel(), _stream())
+
+
 def _colsum(g, ldg, col, N, out):
     call("lego_colsum", _ptr(g, col), ldg, g.shape[0], None, None, N, _ptr(out), _stream())
 
@@ -150,7 +198,9 @@ def _ln_bwd(dout, y, resid, gamma, mean, rstd, pre, post, dy, dresid, dgamma, db
 
 
 class _Blocks(torch.autograd.Function):
-    """hidden states of the live rows through (optionally the embedding stage and) the kept blocks; dense in, dense out"""
+    """hidden states of the live rows through (optionally the embedding stage and) the kept blocks; dense in, dense out.
+    Every tensor of the pass that does not leave it -- saved activations, LayerNorm statistics, backward temporaries -- is a view of the
+    device's workspace arena (arena.py): a steady-state training step allocates nothing here."""
 
     @staticmethod
     def forward(ctx, x, mask, heads, eps, p_hidden, p_attn, training, embed, *params):
@@ -167,16 +217,21 @@ class _Blocks(torch.autograd.Function):
         ctx.params = params
         out = torch.zeros(n * L, H, **f)
         if R == 0:
-            ctx.layers = []
+            ctx.layers, ctx.frame = [], None
             return out.view(n, L, H)
-        xc = K.gather_rows(x.view(n * L, H), idx)
+        if ROWS_SEEN is not None:
+            ROWS_SEEN.append(R)
+        A = arena_of(dev)
+        ctx.frame = frame = A.push()
+        xc = K.gather_rows(x.view(n * L, H), idx, out=A.take(R, H))
         saved = {}
         if embed:
             pos_w, type_w, g0, b0 = params[:4]
             pos = idx.long() % L                      # BertEmbeddings.position_ids: the row's place in its padded sequence (any mask)
-            resid0 = (pos_w.detach()[pos] + type_w.detach()[0]).contiguous()       # position + token-type rows (token_type_ids = 0)
-            h = torch.empty(R, H, **f)
-            mean0, rstd0 = torch.empty(R, **f), torch.empty(R, **f)
+            resid0 = torch.index_select(pos_w.detach(), 0, pos, out=A.take(R, H))          # position + token-type rows (token_type_ids = 0)
+            resid0 += type_w.detach()[0]
+            h = A.take(R, H)
+            mean0, rstd0 = A.take(R), A.take(R)
             post, post_rng = _drop(p_hidden, training)
             _ln_fwd(xc, resid0, g0.detach(), b0.detach(), eps, None, post, h, mean0, rstd0)
             saved["embed"] = (xc, resid0, mean0, rstd0, post_rng, pos)
@@ -186,37 +241,44 @@ class _Blocks(torch.autograd.Function):
         I = lp[10].shape[0] if n_layers else 0
         for l in range(n_layers):
             Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2 = (t.detach() for t in lp[l * NL:(l + 1) * NL])
-            # q, k, v as ONE product against the stacked [3H, H] weight (a 7 MB copy per block and step: the three 768-wide launches
-            # cost 1.02 ms at 29.6 k rows, the 2304-wide one 0.95; the data gradient 1.04 -> 0.88 ms: tools/bert_shapes_bench.py)
-            Wqkv, bqkv = torch.cat((Wq, Wk, Wv), 0), torch.cat((bq, bk, bv), 0)
-            qkv = torch.empty(R, 3 * H, **f)
+            # q, k, v as ONE product against the stacked [3H, H] weight (the three 768-wide launches cost 1.02 ms at 29.6 k rows, the
+            # 2304-wide one 0.95; the data gradient 1.04 -> 0.88 ms: tools/bert_shapes_bench.py).  PluginStep lays the three tensors out
+            # back to back in its flat parameter buffer: the stacked weight is then a VIEW; else a 7 MB copy into the arena
+            Wqkv, bqkv = _stacked((Wq, Wk, Wv)), _stacked((bq, bk, bv))
+            if Wqkv is None:
+                Wqkv = torch.cat((Wq, Wk, Wv), 0, out=A.take(3 * H, H))
+            if bqkv is None:
+                bqkv = torch.cat((bq, bk, bv), 0, out=A.take(3 * H))
+            qkv = A.take(R, 3 * H)
             _lin_fwd(h, Wqkv, bqkv, qkv, 3 * H, tag="qkv_fwd")
-            ctxv = torch.empty(R, H, **f)
-            probs = torch.empty(R, heads, L, **f)
+            ctxv = A.take(R, H)
+            probs = A.take(R, heads, L)
             adrop, arng = _drop(p_attn, training)
             with _timed("mhsa_core_fwd", 4.0 * R * L * H / 2):            # ~L/2 live keys per row on average: nominal
                 call("lego_mhsa_core_fwd", _ptr(qkv), 3 * H, _ptr(seg_off), n, None, H, heads, _ptr(ctxv), H, None, _ptr(probs), L,
                      adrop, R, 0, None, None, _stream())
-            ao = torch.empty(R, H, **f)
+            ao = A.take(R, H)
             _lin_fwd(ctxv, Wo, bo, ao, H, tag="attn_out_fwd")
-            a = torch.empty(R, H, **f)
-            mean1, rstd1 = torch.empty(R, **f), torch.empty(R, **f)
+            a = A.take(R, H)
+            mean1, rstd1 = A.take(R), A.take(R)
             pre1, rng1 = _drop(p_hidden, training)
             _ln_fwd(ao, h, g1, be1, eps, pre1, None, a, mean1, rstd1)
-            z = torch.empty(R, I, **f)
-            _lin_fwd(a, W1, b1, z, I, tag="ffn1_fwd")
-            g = torch.empty(R, I, **f)
-            call("lego_gelu_fwd", _ptr(z), _ptr(g), R * I, _stream())
-            fo = torch.empty(R, H, **f)
+            z = A.take(R, I)
+            g = A.take(R, I)
+            _ffn1_fwd(a, W1, b1, z, g)
+            fo = A.take(R, H)
             _lin_fwd(g, W2, b2, fo, H, tag="ffn2_fwd")
-            hn = torch.empty(R, H, **f)
-            mean2, rstd2 = torch.empty(R, **f), torch.empty(R, **f)
+            hn = A.take(R, H)
+            mean2, rstd2 = A.take(R), A.take(R)
             pre2, rng2 = _drop(p_hidden, training)
             _ln_fwd(fo, a, g2, be2, eps, pre2, None, hn, mean2, rstd2)
             layers.append((h, qkv, probs, arng, ctxv, ao, a, mean1, rstd1, rng1, z, g, fo, mean2, rstd2, rng2, Wqkv))
             h = hn
         ctx.layers, ctx.saved = layers, saved
         out.index_copy_(0, idx.long(), h)
+        if not any(ctx.needs_input_grad):            # no backward pass will come (evaluation): the workspace is free again
+            ctx.layers, ctx.saved, ctx.frame = [], {}, None
+            frame.release()
         return out.view(n, L, H)
 
     @staticmethod
@@ -231,48 +293,60 @@ class _Blocks(torch.autograd.Function):
         dx_dense = torch.zeros(n * L, H, **f) if need[0] else None
         if R == 0:
             return (dx_dense.view(n, L, H) if need[0] else None,) + (None,) * (n_fixed - 1) + tuple(grads)
+        frame = ctx.frame
+        if frame is None or not frame.alive:
+            raise RuntimeError("the BERT blocks' workspace frame is closed: a second backward pass through the same forward (retain_graph) is not supported")
+        A = arena_of(dev)
         off = len(EMBED_KEYS) if embed else 0
         lp = params[off:]
 
         def want(i):                                 # gradient of params[i] wanted?
             return need[n_fixed + i]
 
-        # every wanted gradient is a view of ONE zero-filled buffer (one fill launch per backward instead of one per tensor; the
-        # products and the LayerNorm column sums accumulate into it)
-        sizes = [(p.numel() + 3) // 4 * 4 if need[n_fixed + i] else 0 for i, p in enumerate(params)]
-        flat = torch.zeros(sum(sizes), **f)
+        def direct(i):                               # ... and accumulated straight into params[i].grad (PluginStep's flat gradient buffer)?
+            gr = params[i].grad
+            return DIRECT_GRADS and gr is not None and gr.dtype == torch.float32 and gr.is_contiguous() and gr.shape == params[i].shape
+
+        # every wanted gradient that is RETURNED is a view of ONE zero-filled buffer (one fill launch per backward instead of one per tensor;
+        # the products and the LayerNorm column sums accumulate into it).  It leaves this pass (autograd may keep it as `.grad`): torch memory
+        sizes = [(p.numel() + 3) // 4 * 4 if (need[n_fixed + i] and not direct(i)) else 0 for i, p in enumerate(params)]
+        flat = torch.zeros(sum(sizes), **f) if sum(sizes) else None
         offs, o = [], 0
         for sz in sizes:
             offs.append(o)
             o += sz
+        is_direct = [False] * len(params)
 
         def gbuf(i):
+            if direct(i):
+                is_direct[i] = True
+                return params[i].grad
             grads[i] = flat[offs[i]:offs[i] + params[i].numel()].view(params[i].shape)
             return grads[i]
-        dh = K.gather_rows(gout.detach().float().contiguous().view(n * L, H), ctx.idx)
+        I = lp[10].shape[0] if n_layers else 0
+        dh = K.gather_rows(gout.detach().float().contiguous().view(n * L, H), ctx.idx, out=A.take(R, H))
+        # backward temporaries, ONE set for all blocks (each is dead before the next block writes it)
+        d_fo, d_a, d_ao = A.take(R, H), A.take(R, H), A.take(R, H)
+        dg = A.take(R, I) if n_layers else None
+        d_qkv = A.take(R, 3 * H) if n_layers else None
         for l in reversed(range(n_layers)):
             (h, qkv, probs, arng, ctxv, ao, a, mean1, rstd1, rng1, z, g, fo, mean2, rstd2, rng2, Wqkv) = ctx.layers[l]
             base = off + l * NL
             Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2 = (t.detach() for t in lp[l * NL:(l + 1) * NL])
-            I = W1.shape[0]
             # ---- BertOutput: hn = LN(drop(fo) + a)
-            d_fo, d_a = torch.empty(R, H, **f), torch.empty(R, H, **f)
             _ln_bwd(dh, fo, a, g2, mean2, rstd2, _redrop(rng2), None, d_fo, d_a,
                     gbuf(base + 14) if want(base + 14) else None, gbuf(base + 15) if want(base + 15) else None,
                     gbuf(base + 13) if want(base + 13) else None)                         # ... and b2's gradient = colsum(d_fo), same pass
             if want(base + 12):
                 _lin_bwd_weight(d_fo, H, 0, g, gbuf(base + 12), tag="ffn2_bwd_weight")
-            dg = torch.empty(R, I, **f)
-            _lin_bwd_data(d_fo, H, 0, W2, dg, False, tag="ffn2_bwd_data")
-            call("lego_gelu_bwd", _ptr(dg), _ptr(z), _ptr(dg), R * I, _stream())          # dz in place
+            _ffn2_bwd_data(d_fo, W2, z, dg)                                               # dz = (d_fo W2) . gelu'(z)
             if want(base + 10):
                 _lin_bwd_weight(dg, I, 0, a, gbuf(base + 10), tag="ffn1_bwd_weight")
             if want(base + 11):
                 _colsum(dg, I, 0, I, gbuf(base + 11))
             _lin_bwd_data(dg, I, 0, W1, d_a, True, tag="ffn1_bwd_data")                                        # d_a += dz W1
-            del dg
-            # ---- BertSelfOutput: a = LN(drop(ao) + h)
-            d_ao, d_h = torch.empty(R, H, **f), torch.empty(R, H, **f)
+            # ---- BertSelfOutput: a = LN(drop(ao) + h)      (d_h takes dh's place: dh was consumed by the LayerNorm pass above)
+            d_h = dh
             _ln_bwd(d_a, ao, h, g1, mean1, rstd1, _redrop(rng1), None, d_ao, d_h,
                     gbuf(base + 8) if want(base + 8) else None, gbuf(base + 9) if want(base + 9) else None,
                     gbuf(base + 7) if want(base + 7) else None)                           # bo's gradient = colsum(d_ao)
@@ -281,42 +355,54 @@ class _Blocks(torch.autograd.Function):
             d_ctx = d_a                                                                   # reuse: d_a is consumed
             _lin_bwd_data(d_ao, H, 0, Wo, d_ctx, False, tag="attn_out_bwd_data")
             # ---- attention core: d(qkv) and, fused, the three bias gradients (column sums of d(qkv))
-            d_qkv = d_qkv_buf = torch.empty(R, 3 * H, **f)
             any_b = want(base + 1) or want(base + 3) or want(base + 5)
-            bsum = torch.zeros(3 * H, **f) if any_b else None
+            all_b = want(base + 1) and want(base + 3) and want(base + 5)
+            bsum = _stacked(tuple(params[base + 1 + 2 * c].grad for c in range(3))) if (all_b and all(direct(base + 1 + 2 * c) for c in range(3))) else None
+            b_direct = bsum is not None
+            if any_b and not b_direct:
+                bsum = torch.zeros(3 * H, **f)
             with _timed("mhsa_core_bwd", 8.0 * R * L * H / 2):
                 call("lego_mhsa_core_bwd", _ptr(qkv), 3 * H, _ptr(ctx.seg_off), n, None, H, heads, _ptr(d_ctx), H, None, _ptr(probs), L,
                      _redrop(arng), R, _ptr(d_qkv), 3 * H, _ptr(bsum), 0, None, None, _stream())
             if want(base) and want(base + 2) and want(base + 4):          # the three weight gradients as one [3H, H] product
-                gWqkv = torch.zeros(3 * H, H, **f)
+                gWqkv = _stacked(tuple(params[base + 2 * c].grad for c in range(3))) if all(direct(base + 2 * c) for c in range(3)) else None
+                if gWqkv is not None:
+                    for c in range(3):
+                        is_direct[base + 2 * c] = True
+                else:
+                    gWqkv = torch.zeros(3 * H, H, **f)
+                    for c in range(3):
+                        grads[base + 2 * c] = gWqkv[c * H:(c + 1) * H]
                 _lin_bwd_weight(d_qkv, 3 * H, 0, h, gWqkv, tag="qkv_bwd_weight")
-                for c in range(3):
-                    grads[base + 2 * c] = gWqkv[c * H:(c + 1) * H]
             else:
                 for c in range(3):
                     if want(base + 2 * c):
                         _lin_bwd_weight(d_qkv, 3 * H, c * H, h, gbuf(base + 2 * c))
             for c in range(3):
                 if want(base + 2 * c + 1):
-                    grads[base + 2 * c + 1] = bsum[c * H:(c + 1) * H]
+                    if b_direct:
+                        is_direct[base + 2 * c + 1] = True
+                    else:
+                        grads[base + 2 * c + 1] = bsum[c * H:(c + 1) * H]
             _lin_bwd_data(d_qkv, 3 * H, 0, Wqkv, d_h, True, tag="qkv_bwd_data")               # d_h += d(qkv) Wqkv
-            del d_qkv_buf
             dh = d_h
         if embed:
             xc, resid0, mean0, rstd0, post_rng, pos = ctx.saved["embed"]
             pos_w, type_w, g0, b0 = params[:4]
-            d_xc = torch.empty(R, H, **f) if need[0] else None
-            d_res = torch.empty(R, H, **f) if (want(0) or want(1)) else None
+            d_xc = A.take(R, H) if need[0] else None
+            d_res = A.take(R, H) if (want(0) or want(1)) else None
             _ln_bwd(dh, xc, resid0, g0.detach(), mean0, rstd0, None, _redrop(post_rng), d_xc, d_res,
                     gbuf(2) if want(2) else None, gbuf(3) if want(3) else None)
             if want(0):
                 gbuf(0).index_add_(0, pos, d_res)
             if want(1):
-                gbuf(1)[0] = d_res.sum(0)
+                gbuf(1)[0] += d_res.sum(0)
             dh = d_xc
         if need[0]:
             dx_dense.index_copy_(0, ctx.idx.long(), dh)
-        return (dx_dense.view(n, L, H) if need[0] else None,) + (None,) * (n_fixed - 1) + tuple(grads)
+        ctx.layers, ctx.saved = [], {}
+        frame.release()                              # (everything above is enqueued on this stream: the next pass may overwrite the workspace)
+        return (dx_dense.view(n, L, H) if need[0] else None,) + (None,) * (n_fixed - 1) + tuple(None if is_direct[i] else g_ for i, g_ in enumerate(grads))
 
 
 def encoder_forward(transformer, x, mask, embed: bool):

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__
         const f32x4 v = reinterpret_cast<const f32x4*>(z)[i];
         f32x4 o;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = 0.5f * v[k] * (1.f + erff(v[k] * 0.70710678118654752440f));
+        for (int k = 0; k < 4; ++k) o[k] = gelu_exact(v[k]);
         reinterpret_cast<f32x4*>(g)[i] = o;
     }
 }
@@ -204,11 +204,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* dg, const fl
         const f32x4 v = reinterpret_cast<const f32x4*>(z)[i], go = reinterpret_cast<const f32x4*>(dg)[i];
         f32x4 o;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float cdf = 0.5f * (1.f + erff(v[k] * 0.70710678118654752440f));
-            const float pdf = 0.39894228040143267794f * __expf(-0.5f * v[k] * v[k]);
-            o[k] = go[k] * (cdf + v[k] * pdf);
-        }
+        for (int k = 0; k < 4; ++k) o[k] = go[k] * gelu_exact_grad(v[k]);
         reinterpret_cast<f32x4*>(dz)[i] = o;
     }
 }

@@ -96,6 +96,15 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.f - 2.f * __frcp_rn(t + 1.f);
 }
 
+// exact GELU (torch.nn.functional.gelu, approximate='none'; BertConfig.hidden_act = "gelu"): g = z Phi(z), g' = Phi(z) + z phi(z).
+// One definition for the stand-alone kernels (bert_ops.hip) and the fused product epilogues (gemm_epi.hpp): the two forms agree bit for bit.
+__device__ __forceinline__ float gelu_exact(float z) { return 0.5f * z * (1.f + erff(z * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_exact_grad(float z) {
+    const float cdf = 0.5f * (1.f + erff(z * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * z * z);
+    return cdf + z * pdf;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

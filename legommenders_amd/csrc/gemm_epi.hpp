@@ -12,7 +12,10 @@ namespace lego {
 struct EpiArgs {
     float* C; int ldc;
     const float* bias;        // [N] or null
-    int act;                  // 0 none, 1 relu, 2 tanh
+    int act;                  // 0 none, 1 relu, 2 tanh; tile-kernel epilogue (`run`) only: 3 = exact GELU with the pre-activation kept in C2
+                              // (BertIntermediate: z = x W1^T + b1 -> C2, gelu(z) -> C), 4 = the reference IS a GELU pre-activation:
+                              // x * gelu'(ref) instead of the ReLU rule (data gradient of BertOutput.dense through the GELU)
+    float* C2; int ldc2;      // act == 3: where the pre-activation goes
     const int* rowinfo;       // live-bit source (indexed by absolute row), kind ROWINFO
     Dropout drop;             // p == 0: off
     int drop_cols;            // column count of the dropout counter space
@@ -68,13 +71,18 @@ struct EpiT : EpiArgs {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         float x = acc[a][b][4 * g + i] + bcol[b];
+                        const bool in = r0 + i < M && col[b] < N;
                         if (act == 1) x = fmaxf(x, 0.f);
                         else if (act == 2) x = fast_tanh(x);
+                        else if (act == 3) {
+                            if (in) C2[(size_t)ra[i] * ldc2 + col[b]] = x;
+                            x = gelu_exact(x);
+                        }
                         if (ROWINFO && !live[i]) x = 0.f;
                         x *= ds[i];
                         if (ACCUM) x += old[b][i];
-                        if (RELUREF) x = ref[b][i] > 0.f ? x * relu_scale : 0.f;
-                        if (r0 + i < M && col[b] < N) {
+                        if (RELUREF) x = act == 4 ? x * gelu_exact_grad(ref[b][i]) : (ref[b][i] > 0.f ? x * relu_scale : 0.f);
+                        if (in) {
                             float* dst = C + (size_t)ra[i] * ldc + col[b];
                             if (ATOMIC) atomicAdd(dst, x); else *dst = x;
                             csum[b] += x;

@@ -45,7 +45,7 @@ namespace lego {
 
 static Epi make_epi(float* C, int ldc) {
     Epi e;
-    e.C = C; e.ldc = ldc; e.bias = nullptr; e.act = 0; e.rowinfo = nullptr;
+    e.C = C; e.ldc = ldc; e.bias = nullptr; e.act = 0; e.rowinfo = nullptr; e.C2 = nullptr; e.ldc2 = 0;
     e.drop = make_dropout(nullptr); e.drop_cols = 1;
     e.relu_ref = nullptr; e.ld_ref = 0; e.relu_scale = 1.f; e.colsum = nullptr;
     e.tap_stride = 0; e.row_off_dyn = nullptr; e.M = e.N = e.row_off = 0;
@@ -86,6 +86,7 @@ using EpiLive = EpiT<true, false, false, false>;
 using EpiAccum = EpiT<false, true, false, false>;
 using EpiAccumRelu = EpiT<false, true, true, false>;
 using EpiAtomic = EpiT<false, false, false, true>;
+using EpiRef = EpiT<false, false, true, false>;       // a reference tensor without accumulation (GELU' in the FFN data gradient)
 
 static int num_cus() {
     static int n = 0;
@@ -367,6 +368,45 @@ extern "C" int lego_linear_bwd_data(const float* g, int ldg, const float* W, int
     }
     if (accumulate) return launch_rows<true, EpiAccum>(d, a, b, e, st, "lego_linear_bwd_data");
     return launch_rows<true, EpiPlain>(d, a, b, e, st, "lego_linear_bwd_data");
+}
+
+// ---- BERT feed-forward with the GELU in the product epilogues (config 5; modeling_bert.py BertIntermediate / BertOutput).  The tile kernel's
+// epilogue only (act 3 / 4 of gemm_epi.hpp): these products have N = 3072 outputs and run on 128 x 128 tiles whatever the row count.
+extern "C" int lego_linear_gelu_fwd(const float* x, int ldx, const float* W, int ldw, const float* bias, float* z, int ldz, float* g, int ldg,
+                                    int M, int N, int K, void* stream) {
+    CHECK4(ldx); CHECK4(ldw); CHECK4(K);
+    LEGO_REQUIRE(z != nullptr && g != nullptr, "lego_linear_gelu_fwd: both outputs (pre-activation z, gelu(z)) are required");
+    if (M <= 0) return 0;
+    GemmDims d{M, N, K, nullptr, nullptr, 1};
+    KcRows a{x, ldx, M, K, nullptr};
+    KcRows b{W, ldw, N, K, nullptr};
+    Epi e = make_epi(g, ldg);
+    e.bias = bias; e.act = 3; e.C2 = z; e.ldc2 = ldz;
+    const int tm = (M + 127) / 128;
+    if (product_mode() == 1 && M >= SPLIT_MIN_ROWS) {
+        if (N >= 512) return launch<C128x256s, false, false, EpiPlain, true>(d, a, b, e, tm, (N + 255) / 256, 1, (hipStream_t)stream, "lego_linear_gelu_fwd");
+        return launch<C128x128s, false, false, EpiPlain, true>(d, a, b, e, tm, (N + 127) / 128, 1, (hipStream_t)stream, "lego_linear_gelu_fwd");
+    }
+    return launch<C128x128, false, false, EpiPlain>(d, a, b, e, tm, (N + 127) / 128, 1, (hipStream_t)stream, "lego_linear_gelu_fwd");
+}
+
+/* dz[M,K] = (dy[M,N] . W[N,K]) * gelu'(z[M,K]) */
+extern "C" int lego_linear_bwd_data_gelu(const float* dy, int ldy, const float* W, int ldw, const float* z, int ldz, float* dz, int lddz,
+                                         int M, int N, int K, void* stream) {
+    CHECK4(ldy); CHECK4(ldw); CHECK4(N); CHECK4(K);
+    LEGO_REQUIRE(z != nullptr, "lego_linear_bwd_data_gelu: the forward's pre-activation z is required");
+    if (M <= 0) return 0;
+    GemmDims d{M, /*N=*/K, /*K=*/N, nullptr, nullptr, 1};
+    KcRows a{dy, ldy, M, N, nullptr};
+    McRows b{W, ldw, K, N, nullptr};
+    Epi e = make_epi(dz, lddz);
+    e.relu_ref = z; e.ld_ref = ldz; e.act = 4;
+    const int tm = (M + 127) / 128;
+    if (product_mode() == 1 && M >= SPLIT_MIN_ROWS) {
+        if (K >= 512) return launch<C128x256s, false, true, EpiRef, true>(d, a, b, e, tm, (K + 255) / 256, 1, (hipStream_t)stream, "lego_linear_bwd_data_gelu");
+        return launch<C128x128s, false, true, EpiRef, true>(d, a, b, e, tm, (K + 127) / 128, 1, (hipStream_t)stream, "lego_linear_bwd_data_gelu");
+    }
+    return launch<C128x128, false, true, EpiRef>(d, a, b, e, tm, (K + 127) / 128, 1, (hipStream_t)stream, "lego_linear_bwd_data_gelu");
 }
 
 extern "C" int lego_linear_bwd_weight(const float* g, int ldg, const float* x, int ldx, float* dW, int lddw,

@@ -16,6 +16,11 @@
 // -- 4.3 KB per wave, so occupancy is set by registers (3-4 waves per SIMD), not by the 23 KB per wave of staged Q / K / V /
 // dOut tiles the previous version held (6 waves per CU: 134 + 69 us per NRMS step for the item side; this one: see DESIGN).
 // Segments of 33..64 rows run as 2 x 2 tiles in a second instantiation on a small grid (launched only when Lmax > 32).
+// Round 6: segments of <= 16 rows (a third of the news items: titles of 5..13 tokens + [SEP] category [SEP]) take a 16 x 16 tile on
+// v_mfma_f32_16x16x4_f32 inside the same launch (wave-uniform branch per pair): a quarter of the matrix-pipe cycles and a quarter of the
+// per-lane softmax / mask / store work of the 32 x 32 tile, which is 75 % padding for them -- the kernel is issue-bound.
+// The layout idea is the same at both sizes: `Tile<T>` below holds what differs (lane split, accumulator registers, the instruction).
+// The dropout keep bit of (query row, head, key j) is the same at every tile size (keep_bits), so which tile a segment takes is invisible.
 // Round 4: two ways to hand the softmax to the backward pass.  `probs`: the forward saves the (sign-tagged) probabilities, the backward
 // reads them -- the engine's default, measured faster (backward 63 against 80 us).  `lse`: the forward keeps one float
 // per (row, head) -- the log-sum-exp of the row's scaled scores -- and the backward recomputes S^T = K Q^T (hd/2 MFMAs per tile, operands
@@ -29,14 +34,36 @@ namespace lego {
 
 constexpr int kMaxL = 64;
 
-__device__ __forceinline__ int acc_row(int v, int lh) { return (v & 3) + 8 * (v >> 2) + 4 * lh; }   // row of accumulator register v
+// What differs between the two tile sizes.  T = 32: v_mfma_f32_32x32x2_f32, lane = (li = lane % 32, lh = lane / 32 in 0..1), 16 accumulator
+// registers, register v of lane (li, lh) = C[row (v & 3) + 8 (v >> 2) + 4 lh][column li].  T = 16: v_mfma_f32_16x16x4_f32, lane = (li = lane % 16,
+// lh = lane / 16 in 0..3), 4 registers, register v = C[row v + 4 lh][column li].  In both, the A / B operand of lane (li, lh) is element
+// [li][k = lh] / [k = lh][li] of a K = KL step, so a "row per lane" operand is the lane's HD / KL contiguous values of row li, and an accumulator
+// register doubles as the A operand of the next product with its row index as that product's reduction index.
+template <int T> struct Tile;
+template <> struct Tile<32> {
+    static constexpr int KL = 2, NV = 16, SH = 5;
+    typedef f32x16 acc_t;
+    static __device__ __forceinline__ int row0(int v) { return (v & 3) + 8 * (v >> 2); }
+    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ float sum(float x) { return x + __shfl_xor(x, 32, 64); }
+    static __device__ __forceinline__ float max(float x) { return fmaxf(x, __shfl_xor(x, 32, 64)); }
+};
+template <> struct Tile<16> {
+    static constexpr int KL = 4, NV = 4, SH = 4;
+    typedef f32x4 acc_t;
+    static __device__ __forceinline__ int row0(int v) { return v; }
+    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ float sum(float x) { x += __shfl_xor(x, 16, 64); return x + __shfl_xor(x, 32, 64); }
+    static __device__ __forceinline__ float max(float x) { x = fmaxf(x, __shfl_xor(x, 16, 64)); return fmaxf(x, __shfl_xor(x, 32, 64)); }
+};
+template <int T> __device__ __forceinline__ int acc_row(int v, int lh) { return Tile<T>::row0(v) + 4 * lh; }   // row of accumulator register v
 
 // Round 4: every operand access of a (segment, head) goes through a BUFFER descriptor with the hardware range check (guide T8 /
 // T20) instead of per-lane clamps (loads) and per-store branches.  A `View` is one matrix seen from row 0 of the segment at the
 // head's first column, valid up to the end of the matrix's row L - 1; an access to a row past the segment is out of range: loads
 // return 0 (every product such a row enters meets an exact zero or lands in an entry that is masked or never stored), stores are
-// dropped.  The wave-uniform part of an address (which of the 16 rows an accumulator register indexes, which third of a qkv row)
-// goes into the descriptor's base and record count -- scalar ALU work -- so the 16 loads / stores of a "column per lane" tile share
+// dropped.  The wave-uniform part of an address (which of the rows an accumulator register indexes, which third of a qkv row)
+// goes into the descriptor's base and record count -- scalar ALU work -- so the loads / stores of a "column per lane" tile share
 // ONE per-lane byte offset.  (Before: 16 clamped 32-bit offsets per matrix pitch and a branch per store kept ~70 VGPRs alive from
 // the top of the kernel to its last store; the backward with the score recomputation did not fit three waves per SIMD.)
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -45,77 +72,79 @@ __device__ __forceinline__ View make_view(const float* p, int ld, int L, int col
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t view_rsrc(const View& v, int off_floats) {          // off_floats: wave-uniform
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(v.p + off_floats), 0, max(v.bytes - off_floats * 4, 0), 0x00020000);
 }
-__device__ __forceinline__ int acc_row0(int s) { return (s & 3) + 8 * (s >> 2); }                     // acc_row(s, lh) - 4 * lh
-// "row per lane" operand: columns [col0 + lh * HD/2, col0 + (lh + 1) * HD/2) of row `row` (zeros past the segment)
-template <int HD>
-__device__ __forceinline__ void load_row(const View& v, int col0, int row, int lh, float (&r)[HD / 2]) {
+// "row per lane" operand: columns [col0 + lh * HD/KL, col0 + (lh + 1) * HD/KL) of row `row` (zeros past the segment)
+template <int HD, int T>
+__device__ __forceinline__ void load_row(const View& v, int col0, int row, int lh, float (&r)[HD / Tile<T>::KL]) {
+    constexpr int HH = HD / Tile<T>::KL;
+    static_assert(HH % 4 == 0, "a lane's share of a head-dim row is loaded in 16-byte pieces");
     const __amdgpu_buffer_rsrc_t rs = view_rsrc(v, col0);
-    const int off = (row * v.ld + lh * (HD / 2)) * 4;
+    const int off = (row * v.ld + lh * HH) * 4;
 #pragma unroll
-    for (int t = 0; t < HD / 8; ++t) {
+    for (int t = 0; t < HH / 4; ++t) {
         // (bit_cast of the WHOLE vector: hipcc 7.2 lowers __builtin_bit_cast(float, v.y) on a vector-element lvalue to a read of element 0)
         const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16 * t, 0, 0));
         r[4 * t] = f.x; r[4 * t + 1] = f.y; r[4 * t + 2] = f.z; r[4 * t + 3] = f.w;
     }
 }
-// "column per lane" operand: column col0 + min(ct * 32 + li, HD - 1) of rows tile * 32 + acc_row(s, lh), s = 0..15
-template <int HD>
-__device__ __forceinline__ void load_cols(const View& v, int col0, int tile, int li, int lh, float (&r)[(HD + 31) / 32][16]) {
+// "column per lane" operand: column col0 + min(ct * T + li, HD - 1) of rows tile * T + acc_row(s, lh), s = 0..NV-1
+template <int HD, int T>
+__device__ __forceinline__ void load_cols(const View& v, int col0, int tile, int li, int lh, float (&r)[(HD + T - 1) / T][Tile<T>::NV]) {
 #pragma unroll
-    for (int ct = 0; ct < (HD + 31) / 32; ++ct) {
-        const int c = min(ct * 32 + li, HD - 1);                 // lanes past the head dim compute a duplicate column that is never stored
-        const int off = ((tile * 32 + 4 * lh) * v.ld + c) * 4;
+    for (int ct = 0; ct < (HD + T - 1) / T; ++ct) {
+        const int c = min(ct * T + li, HD - 1);                  // lanes past the head dim compute a duplicate column that is never stored
+        const int off = ((tile * T + 4 * lh) * v.ld + c) * 4;
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
-            r[ct][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(view_rsrc(v, col0 + acc_row0(s) * v.ld), off, 0, 0));
+        for (int s = 0; s < Tile<T>::NV; ++s)
+            r[ct][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(view_rsrc(v, col0 + Tile<T>::row0(s) * v.ld), off, 0, 0));
     }
 }
 // acc += A B^T over the head dim, both operands "row per lane"
-template <int HD>
-__device__ __forceinline__ void rows_mfma(const float (&a)[HD / 2], const float (&b)[HD / 2], f32x16& acc) {
+template <int HD, int T>
+__device__ __forceinline__ void rows_mfma(const float (&a)[HD / Tile<T>::KL], const float (&b)[HD / Tile<T>::KL], typename Tile<T>::acc_t& acc) {
 #pragma unroll
-    for (int s = 0; s < HD / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+    for (int s = 0; s < HD / Tile<T>::KL; ++s) acc = Tile<T>::mfma(a[s], b[s], acc);
 }
-// out[m][c] += sum over the 32 rows of a tile: coef(register s of this lane) * rows[acc_row(s, lh)][c]
-template <int HD>
-__device__ __forceinline__ void regs_mfma(const f32x16& coef, const float (&cols)[(HD + 31) / 32][16], f32x16 (&out)[(HD + 31) / 32]) {
+// out[m][c] += sum over the T rows of a tile: coef(register s of this lane) * rows[acc_row(s, lh)][c]
+template <int HD, int T>
+__device__ __forceinline__ void regs_mfma(const typename Tile<T>::acc_t& coef, const float (&cols)[(HD + T - 1) / T][Tile<T>::NV],
+                                          typename Tile<T>::acc_t (&out)[(HD + T - 1) / T]) {
 #pragma unroll
-    for (int ct = 0; ct < (HD + 31) / 32; ++ct)
+    for (int ct = 0; ct < (HD + T - 1) / T; ++ct)
 #pragma unroll
-        for (int s = 0; s < 16; ++s) out[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(coef[s], cols[ct][s], out[ct], 0, 0, 0);
+        for (int s = 0; s < Tile<T>::NV; ++s) out[ct] = Tile<T>::mfma(coef[s], cols[ct][s], out[ct]);
 }
-template <int CT>
-__device__ __forceinline__ void zero(f32x16 (&t)[CT]) {
+template <int T, int CT>
+__device__ __forceinline__ void zero(typename Tile<T>::acc_t (&t)[CT]) {
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) t[ct][v] = 0.f;
+        for (int v = 0; v < Tile<T>::NV; ++v) t[ct][v] = 0.f;
 }
-// out[tile * 32 + acc_row(v, lh)][col0 + ct * 32 + li] = t * scale; rows past the segment and columns past the head are dropped by the
+// out[tile * T + acc_row(v, lh)][col0 + ct * T + li] = t * scale; rows past the segment and columns past the head are dropped by the
 // range check (their offset is out of range)
-template <int HD>
-__device__ __forceinline__ void store_cols(const f32x16 (&t)[(HD + 31) / 32], float scale, const View& o, int col0, int tile, int li, int lh) {
+template <int HD, int T>
+__device__ __forceinline__ void store_cols(const typename Tile<T>::acc_t (&t)[(HD + T - 1) / T], float scale, const View& o, int col0, int tile, int li, int lh) {
 #pragma unroll
-    for (int ct = 0; ct < (HD + 31) / 32; ++ct) {
-        const int c = ct * 32 + li;
-        const int off = c < HD ? ((tile * 32 + 4 * lh) * o.ld + c) * 4 : 0x7FFFFFF0;
+    for (int ct = 0; ct < (HD + T - 1) / T; ++ct) {
+        const int c = ct * T + li;
+        const int off = c < HD ? ((tile * T + 4 * lh) * o.ld + c) * 4 : 0x7FFFFFF0;
 #pragma unroll
-        for (int v = 0; v < 16; ++v)
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t[ct][v] * scale), view_rsrc(o, col0 + acc_row0(v) * o.ld), off, 0, 0);
+        for (int v = 0; v < Tile<T>::NV; ++v)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t[ct][v] * scale), view_rsrc(o, col0 + Tile<T>::row0(v) * o.ld), off, 0, 0);
     }
 }
 
-// colsum[c] += scale * sum over the 32 rows of an accumulator tile (rows past the segment hold exact zeros): the bias gradient of
+// colsum[c] += scale * sum over the T rows of an accumulator tile (rows past the segment hold exact zeros): the bias gradient of
 // the in-projection, folded into the kernel that produces d(qkv) instead of a separate pass over [rows, 3D]
-template <int HD>
-__device__ __forceinline__ void col_add(const f32x16 (&t)[(HD + 31) / 32], float scale, float* dst, int li, int lh) {
+template <int HD, int T>
+__device__ __forceinline__ void col_add(const typename Tile<T>::acc_t (&t)[(HD + T - 1) / T], float scale, float* dst, int li, int lh) {
 #pragma unroll
-    for (int ct = 0; ct < (HD + 31) / 32; ++ct) {
+    for (int ct = 0; ct < (HD + T - 1) / T; ++ct) {
         float s = 0.f;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) s += t[ct][v];
-        s += __shfl_xor(s, 32, 64);
-        const int c = ct * 32 + li;
+        for (int v = 0; v < Tile<T>::NV; ++v) s += t[ct][v];
+        s = Tile<T>::sum(s);
+        const int c = ct * T + li;
         if (lh == 0 && c < HD) atomicAdd(dst + c, s * scale);
     }
 }

@@ -475,3 +475,123 @@ def test_native_blocks_with_holes_in_the_mask(embed):
         assert g is not None, k
         d = float((g.cpu().double() - p.grad).abs().max())
         assert d <= 2e-5 * max(1.0, float(p.grad.abs().max())), (k, d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(1003, 3072, 768), (37, 128, 64), (260, 512, 256)])
+def test_feed_forward_products_with_the_gelu_in_their_epilogues(M, N, K):
+    """lego_linear_gelu_fwd / lego_linear_bwd_data_gelu (BertIntermediate / BertOutput.dense, transformers modeling_bert.py) against
+    float64, and against the product + stand-alone GELU pass they replace (the same rounding sequence)"""
+    from legommenders_amd._lib import call
+    from legommenders_amd.kernels import _ptr, _stream
+    dev = torch.device("cuda:0")
+    g_ = torch.Generator().manual_seed(M + N)
+    x, W, b = torch.randn(M, K, generator=g_), torch.randn(N, K, generator=g_) * 0.05, torch.randn(N, generator=g_)
+    xd, Wd, bd = x.to(dev), W.to(dev), b.to(dev)
+    z, g = torch.full((M, N), 7.0, device=dev), torch.full((M, N), 7.0, device=dev)
+    call("lego_linear_gelu_fwd", _ptr(xd), K, _ptr(Wd), K, _ptr(bd), _ptr(z), N, _ptr(g), N, M, N, K, _stream())
+    zr = x.double() @ W.double().T + b.double()
+    gr = torch.nn.functional.gelu(zr)
+    assert float((z.cpu().double() - zr).abs().max()) < 2e-5 * max(1.0, float(zr.abs().max()))
+    assert float((g.cpu().double() - gr).abs().max()) < 2e-5 * max(1.0, float(gr.abs().max()))
+    z2, g2 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    call("lego_linear_fwd", _ptr(xd), K, _ptr(Wd), K, _ptr(bd), _ptr(z2), N, M, None, N, K, 0, None, None, None, None, _stream())
+    call("lego_gelu_fwd", _ptr(z2), _ptr(g2), M * N, _stream())
+    assert float((g - g2).abs().max()) <= 1e-6 * max(1.0, float(g2.abs().max()))
+    # backward: dz = (dy W2) * gelu'(z) with W2 [Nout = K here, N]: dy [M, K], W2 [K, N], z [M, N]
+    dy, W2 = torch.randn(M, K, generator=g_), torch.randn(K, N, generator=g_) * 0.05
+    dyd, W2d = dy.to(dev), W2.to(dev)                # (named: a temporary passed as a raw pointer may be freed and reused before the launch)
+    dz = torch.full((M, N), 7.0, device=dev)
+    call("lego_linear_bwd_data_gelu", _ptr(dyd), K, _ptr(W2d), N, _ptr(z), N, _ptr(dz), N, M, K, N, _stream())
+    zz = z.cpu().double().requires_grad_(True)
+    torch.nn.functional.gelu(zz).backward(dy.double() @ W2.double())
+    assert float((dz.cpu().double() - zz.grad).abs().max()) < 3e-5 * max(1.0, float(zz.grad.abs().max()))
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_blocks_take_their_workspace_from_the_arena_and_adam_runs_on_flat_buffers(tmp_path, monkeypatch):
+    """config 5's training step (plugin_step.PluginStep) on a small BERT: (a) after the first steps no step allocates -- the blocks'
+    saved activations and temporaries are views of the workspace arena (arena.py), whose chunk count stays put over ragged batches, and
+    the q / k / v weights, biases and their gradients are views of the step's flat buffers (no torch.cat, no gradient copies);
+    (b) the parameters follow torch.optim.Adam + the HF linear schedule on the same gradients (base_lego.py:175-223): same model stepped
+    by PluginStep and by autograd + torch.optim.Adam from the same initial state, dropout off -- equal to fp32 rounding after 6 steps;
+    (c) the optimizer / scheduler state round-trips through torch's formats."""
+    from legommenders_amd import bert_native
+    from legommenders_amd.arena import arena_of
+    from legommenders_amd.engine import ItemTables
+    from legommenders_amd.loader.class_hub import ClassHub
+    from legommenders_amd.loader.env import Env
+    from legommenders_amd.model.legommender import Legommender
+    from legommenders_amd.plugin_step import PluginStep
+    from legommenders_amd.train_step import DeviceData
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("LEGO_LAYER_CACHE_SAVE", "0")
+    dev = torch.device("cuda:0")
+    Env.set_device(dev)
+    meta, P, G, tables, batch, logits, loss = load_model_fixture("bert_naml_small")
+    n_users = tables["user_hist"].shape[0]
+    rs = np.random.RandomState(0)
+    world = dict(title_tok=tables["title_tok"], title_len=tables["title_len"], cat=tables["cat"], user_hist=tables["user_hist"],
+                 user_hist_len=tables["user_hist_len"], neg_list=np.zeros((n_users, 4), dtype=np.int64), neg_len=np.zeros(n_users, dtype=np.int64),
+                 row_user=rs.randint(0, n_users, size=400), row_item=rs.randint(0, tables["title_tok"].shape[0], size=400))
+
+    def build():                                     # (the fixture's configuration carries no Dropout: the two optimisers see the same gradients)
+        lc = _lego_config(meta, tables, P, ClassHub.operators(), ClassHub.predictors(), {"tune_from": 0})
+        lc.build_components()
+        lc.register_inputer_vocabs()
+        torch.manual_seed(1)
+        model = Legommender(lc).to(dev)
+        model.load_state_dict({k: torch.tensor(v) for k, v in P.items()}, strict=False)
+        model.attach_item_table(ItemTables(tables["title_tok"], tables["title_len"], tables["cat"], dev))
+        return model
+    B = 8
+    # (a) + (c): ragged batches
+    model = build()
+    ps = PluginStep(model, DeviceData(world, dev, seed=3), B, K=4, lr=1e-3, seed=3, total_steps=40, warmup=2, tail="drop")
+    layer0 = model.item_op.transformer.encoder.layer[0].attention.self
+    assert bert_native._stacked((layer0.query.weight, layer0.key.weight, layer0.value.weight)) is not None
+    assert bert_native._stacked((layer0.query.bias.grad, layer0.key.bias.grad, layer0.value.bias.grad)) is not None
+    ar = arena_of(dev)
+    for _ in range(6):
+        ps.step()
+    torch.cuda.synchronize()
+    before, dev_allocs = ar.allocations, torch.cuda.memory_stats().get("num_device_alloc", 0)
+    assert len(ar.chunks) == 1 and not ar.frames
+    losses = [float(ps.step()) for _ in range(6)]
+    torch.cuda.synchronize()
+    assert ar.allocations == before and not ar.frames, (ar.allocations, before)
+    assert torch.cuda.memory_stats().get("num_device_alloc", 0) <= dev_allocs + 1      # (torch's small pool may take one more segment)
+    assert all(np.isfinite(losses)) and float(ps.gflat.abs().max()) == 0.0             # Adam cleared what it consumed
+    sd, sc = ps.optimizer_state(), ps.scheduler_state()
+    ref_opt = torch.optim.Adam([{"params": g["params"], "lr": g["initial_lr"]} for g in ps.opt.param_groups])
+    ref_opt.load_state_dict(sd)                                                          # torch accepts it ...
+    ps.load_optimizer_state(ref_opt.state_dict())                                        # ... and its own format loads back
+    assert ps.step_idx == 12 and sc["last_epoch"] == 12
+    # (b): PluginStep against autograd + torch.optim.Adam on twin models and the same sampled batches
+    m1, m2 = build(), build()
+    ps1 = PluginStep(m1, DeviceData(world, dev, seed=4), B, K=4, lr=1e-3, seed=4, total_steps=20, warmup=1, tail="drop")
+    d2 = DeviceData(world, dev, seed=4)
+    ps2 = PluginStep(m2, d2, B, K=4, lr=1e-3, seed=4, total_steps=20, warmup=1, tail="drop")     # (used for its sampler only)
+    params2 = [p for p in m2.parameters() if p.requires_grad]
+    for p in params2:
+        p.grad = None
+    opt2 = torch.optim.Adam(params2, lr=1e-3)
+    sched2 = torch.optim.lr_scheduler.LambdaLR(opt2, ps2.factor)
+    cm = m2.cm
+    for _ in range(6):
+        l1 = ps1.step()
+        nb = ps2.sample_batch()
+        ps2.batch_idx += 1
+        b2 = {cm.item_col: ps2.cand[:nb].long(), cm.history_col: ps2.hist[:nb].long(), cm.mask_col: (ps2.ar < ps2.hist_len[:nb, None]).long()}
+        Env.train(); m2.train()
+        opt2.zero_grad(set_to_none=True)
+        l2 = m2(batch=b2)
+        l2.backward()
+        opt2.step(); sched2.step()
+        assert abs(float(l1) - float(l2)) < 5e-5, (float(l1), float(l2))
+    sd1, sd2 = m1.state_dict(), m2.state_dict()
+    for k in sd1:
+        if sd1[k].dtype == torch.float32:
+            d = float((sd1[k] - sd2[k]).abs().max())
+            assert d <= 3e-4, (k, d)          # 6 sign-like Adam steps of lr 1e-3 move an element by up to 6e-3

@@ -1,5 +1,6 @@
 """Throughput of the BERT-NAML plug-in route (BERT-base news encoder, item_hidden = 768) on one
-MI355X: `Legommender.forward` + backward + torch Adam on a MIND-small-shaped synthetic world, random-init BERT-base
+MI355X: the product's own training step (`plugin_step.PluginStep`: device sampler, `Legommender.forward`, backward, the flat-buffer Adam launch)
+on a MIND-small-shaped synthetic world, random-init BERT-base
 (no pretrained weights offline; tune_from = 0 -> 11 of the 12 blocks run, as in the reference).
 
     python tools/bert_naml_bench.py [--batch 64] [--steps 5] [--layers 12] [--hidden 256] [--tune_from 9]
@@ -60,45 +61,39 @@ def run(batch=64, steps=5, warmup=2, layers=12, hidden=256, tune_from=0, n_items
     model.attach_item_table(ItemTables(w["title_tok"], w["title_len"], w["cat"], dev))
     torch.cuda.synchronize()
     t_cache = time.perf_counter() - t_cache
-    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
-    B, S = a.batch, 50
-    rs = np.random.RandomState(0)
-    Env.train(); model.train()
-
-    def step():
-        users = rs.randint(0, user_v.size, size=B)
-        cand = rs.randint(0, n_items, size=(B, 5))
-        hist = w["user_hist"][users]
-        hl = w["user_hist_len"][users]
-        ids = {"item_id": torch.tensor(cand), "history": torch.tensor(hist),
-               "__clicks_mask__": (torch.arange(S)[None] < torch.tensor(hl)[:, None]).long()}
-        opt.zero_grad(set_to_none=True)
-        loss = model(batch=ids)
-        loss.backward()
-        opt.step()
-        return loss
+    from legommenders_amd.arena import arena_of
+    from legommenders_amd.plugin_step import PluginStep
+    from legommenders_amd.train_step import DeviceData
+    B = a.batch
+    ps = PluginStep(model, DeviceData(w, dev, seed=2023), B, K=4, lr=1e-4, seed=2023, tail="drop")
+    step = ps.step
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
     # one device sync per step (a step is ~125 ms: the sync costs nothing): un-synchronised, the host runs several steps ahead, each step's
     # ~15 GB of saved activations is requested before the previous step's are back in the caching allocator, and the timed steps pay for
     # fresh hipMalloc segments -- 165-213 ms per step inside bench.py's process against 122-128 ms for the same steps taken one at a time
-    step_ms = []
+    step_ms, step_rows = [], []
+    from legommenders_amd import bert_native
     for _ in range(a.steps):
+        bert_native.ROWS_SEEN = []
         t1 = time.perf_counter()
         loss = step()
         torch.cuda.synchronize()
         step_ms.append(round((time.perf_counter() - t1) * 1e3, 1))
+        step_rows.append(int(sum(bert_native.ROWS_SEEN)))
+    bert_native.ROWS_SEEN = None
+    us_per_row = [round(m * 1e3 / max(1, r), 3) for m, r in zip(step_ms, step_rows)]
     # the MEDIAN step: a step whose ragged batch is larger than any before it makes the caching allocator fetch new segments (hipMalloc:
     # 120 -> 290-360 ms for that step, seen for two of five steps in bench.py's process); the mean and the list are kept beside it
     dt = sorted(step_ms)[len(step_ms) // 2] / 1e3
+    ar = arena_of(dev)
     if os.environ.get("LEGO_BERT_STEP_TIMES") == "1":
         print("bert_naml_bench step times (ms):", step_ms, "allocated GB", round(torch.cuda.memory_allocated() / 2**30, 2),
               "reserved GB", round(torch.cuda.memory_reserved() / 2**30, 2), file=sys.stderr, flush=True)
     n_par = sum(p.numel() for p in model.parameters() if p.requires_grad)
     # per-product table of the native blocks: two more steps with every product launch bracketed by HIP events (outside the timing above)
     kernels = None
-    from legommenders_amd import bert_native
     if getattr(model.item_op, "native", False) and model.item_op._native_ok(32):
         bert_native.TIMERS = {}
         for _ in range(2):
@@ -118,6 +113,12 @@ def run(batch=64, steps=5, warmup=2, layers=12, hidden=256, tune_from=0, n_items
            "timing": "median of the per-step wall times (one device sync per step)", "step_ms": step_ms, "s_per_step_mean": round(sum(step_ms) / 1e3 / len(step_ms), 4), "loss": float(loss.detach()),
            "item_page_size": item_page_size, "effective_item_page": model._item_page(10 ** 9), "tune_from": a.tune_from, "layer_cache_s": round(t_cache, 3) if a.tune_from else None,
            "layer_cache_GB": round(model.item_op.hidden_weights.numel() * 4 / 1e9, 3) if a.tune_from else None,
+           "step_ms_max_over_min": round(max(step_ms) / max(1e-9, min(step_ms)), 3),
+           "live_rows_per_step": step_rows, "us_per_live_row": us_per_row,
+           "us_per_live_row_max_over_min": round(max(us_per_row) / max(1e-9, min(us_per_row)), 3),     # batches are ragged: a step's time follows its live rows
+           "workspace_arena": {"chunk_allocations_total": ar.allocations, "peak_GB": round(ar.peak / 2**30, 2), "reserved_GB": round(sum(c.numel() for c in ar.chunks) / 2**30, 2)},
+           "torch_allocator": {"allocated_GB": round(torch.cuda.memory_allocated() / 2**30, 2), "reserved_GB": round(torch.cuda.memory_reserved() / 2**30, 2),
+                               "num_device_alloc": torch.cuda.memory_stats().get("num_device_alloc", None)},
            "blocks_on": "the path's kernels over ragged rows (legommenders_amd/bert_native.py)" if kernels is not None
                         else "transformers modules on PyTorch-ROCm (LEGO_BERT_NATIVE=0 or an uncovered configuration)",
            "kernels": kernels})
