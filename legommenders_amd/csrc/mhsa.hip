@@ -202,27 +202,39 @@ __global__ __launch_bounds__(1024) void mhsa_long_segments_kernel(const int* __r
         }                                                                                                         \
     }
 
-// keep bits of a lane's 16 (query, key) pairs of key tile jt: two Philox calls, one 16-bit field per decision.  Forward and backward
-// call it with the same (row, head, tile, lane half), so the backward pass redraws the forward's mask
+// keep bits of a lane's NV (query, key) pairs of key tile jt, one 16-bit Philox field per decision.  The bit of (query row, head, key j) is
+// a function of those three alone: a 32-row tile's lane (i, lh) draws two Philox calls (index (2 jt + lh) 2 + call) for its 16 keys
+// j = 32 jt + (v & 3) + 8 (v >> 2) + 4 lh, field v & 7 of call v >> 3; a 16-row tile's lane (i, lh in 0..3) holds keys j = v + 4 lh < 16, which in that
+// numbering are lane half lh & 1, register v + 4 (lh >> 1) < 8: ONE call (index 2 (lh & 1)), fields v + 4 (lh >> 1).  Forward and backward call it
+// with the same (row, head, tile, lane part), so the backward pass redraws the forward's mask -- whatever tile size either took.
+template <int T>
 __device__ __forceinline__ uint32_t keep_bits(const Dropout& drop, uint32_t thr16, uint32_t ctr, int jt, int lh) {
     uint32_t keep = 0u;
+    if constexpr (T == 32) {
 #pragma unroll
-    for (int call = 0; call < 2; ++call) {
-        const Philox4 r = philox4x32_10(ctr, (uint32_t)((jt * 2 + lh) * 2 + call), drop.site, 0x6d687361u, drop.seed_lo, drop.seed_hi);
-        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+        for (int call = 0; call < 2; ++call) {
+            const Philox4 r = philox4x32_10(ctr, (uint32_t)((jt * 2 + lh) * 2 + call), drop.site, 0x6d687361u, drop.seed_lo, drop.seed_hi);
+            const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-        for (int f = 0; f < 8; ++f)
-            keep |= (((w[f >> 1] >> (16 * (f & 1))) & 0xFFFFu) >= thr16 ? 1u : 0u) << (call * 8 + f);
+            for (int f = 0; f < 8; ++f)
+                keep |= (((w[f >> 1] >> (16 * (f & 1))) & 0xFFFFu) >= thr16 ? 1u : 0u) << (call * 8 + f);
+        }
+    } else {
+        const Philox4 r = philox4x32_10(ctr, (uint32_t)((jt * 2 + (lh & 1)) * 2), drop.site, 0x6d687361u, drop.seed_lo, drop.seed_hi);
+        const uint32_t lo = (lh >> 1) ? r.z : r.x, hi = (lh >> 1) ? r.w : r.y;          // fields 4 (lh >> 1) .. 4 (lh >> 1) + 3
+        keep = ((lo & 0xFFFFu) >= thr16 ? 1u : 0u) | ((lo >> 16) >= thr16 ? 2u : 0u) | ((hi & 0xFFFFu) >= thr16 ? 4u : 0u) | ((hi >> 16) >= thr16 ? 8u : 0u);
     }
     return keep;
 }
 
-template <int HD, int JT>
-__device__ __forceinline__ void mhsa_fwd_pair(const float* __restrict__ qkv, int ldq, int D, int heads, float* __restrict__ out, int ldo,
+template <int HD, int JT, int T>
+__device__ __forceinline__ void mhsa_fwd_tile(const float* __restrict__ qkv, int ldq, int D, int heads, float* __restrict__ out, int ldo,
                                               float* __restrict__ lse, float* __restrict__ probs, int Lmax, const Dropout& drop, int h,
                                               int beg, int L, int t0, int t1) {
-    constexpr int CT = (HD + 31) / 32, HH = HD / 2;
-    const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    using TL = Tile<T>;
+    using acc_t = typename TL::acc_t;
+    constexpr int CT = (HD + T - 1) / T, HH = HD / TL::KL, NV = TL::NV;
+    const int lane = threadIdx.x & 63, li = lane & (T - 1), lh = lane >> TL::SH;
     const bool dropping = drop.p > 0.f;
     const float dinv = dropping ? 1.f / (1.f - drop.p) : 1.f;
     const uint32_t thr16 = (uint32_t)(drop.p * 65536.0f);
@@ -232,62 +244,76 @@ __device__ __forceinline__ void mhsa_fwd_pair(const float* __restrict__ qkv, int
         const View ov = make_view(out + (size_t)beg * ldo + h * HD, ldo, L, D - h * HD);
         const bool save_p = probs != nullptr;                    // the (segment, head) tile [key j][query i], L x L floats
         const View pv = make_view(save_p ? probs + ((size_t)beg * heads + (size_t)h * L) * Lmax : qkv, L, save_p ? L : 0, save_p ? L : 0);
-        float kr[JT][HH], vc[JT][CT][16];
+        float kr[JT][HH], vc[JT][CT][NV];
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
-            load_row<HD>(qv, D, jt * 32 + li, lh, kr[jt]);
-            load_cols<HD>(qv, 2 * D, jt, li, lh, vc[jt]);
+            load_row<HD, T>(qv, D, jt * T + li, lh, kr[jt]);
+            load_cols<HD, T>(qv, 2 * D, jt, li, lh, vc[jt]);
         }
 #pragma unroll 1
         for (int it = t0; it < t1; ++it) {
-            if (it * 32 >= L) break;
-            const int i = it * 32 + li;
+            if (it * T >= L) break;
+            const int i = it * T + li;
             float qr[HH];
-            load_row<HD>(qv, 0, i, lh, qr);
+            load_row<HD, T>(qv, 0, i, lh, qr);
             __builtin_amdgcn_sched_barrier(0);      // all operand loads in flight before the first MFMA
 #pragma unroll
             for (int s = 0; s < HH; ++s) qr[s] *= qscale;
-            f32x16 acc[JT];
-            zero<JT>(acc);
+            acc_t acc[JT];
+            zero<T, JT>(acc);
             float mx = -INFINITY;
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) {
-                rows_mfma<HD>(kr[jt], qr, acc[jt]);                        // S^T[j][i], j = jt*32 + acc_row(v, lh), i = it*32 + li
+                rows_mfma<HD, T>(kr[jt], qr, acc[jt]);                     // S^T[j][i], j = jt*T + acc_row(v, lh), i = it*T + li
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    if (jt * 32 + acc_row(v, lh) >= L) acc[jt][v] = -INFINITY;
+                for (int v = 0; v < NV; ++v) {
+                    if (jt * T + acc_row<T>(v, lh) >= L) acc[jt][v] = -INFINITY;
                     mx = fmaxf(mx, acc[jt][v]);
                 }
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = TL::max(mx);
             float se = 0.f;
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                for (int v = 0; v < 16; ++v) { acc[jt][v] = __expf(acc[jt][v] - mx); se += acc[jt][v]; }
-            se += __shfl_xor(se, 32, 64);
+                for (int v = 0; v < NV; ++v) { acc[jt][v] = __expf(acc[jt][v] - mx); se += acc[jt][v]; }
+            se = TL::sum(se);
             const float inv = 1.f / se;
             if (lse != nullptr && lh == 0 && i < L) lse[(size_t)(beg + i) * heads + h] = mx + __logf(se);   // all a recomputing backward needs
-            f32x16 o[CT];
-            zero<CT>(o);
+            acc_t o[CT];
+            zero<T, CT>(o);
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) {
                 uint32_t keep = 0xFFFFu;
-                if (dropping) keep = keep_bits(drop, thr16, (uint32_t)((beg + min(i, L - 1)) * heads + h), jt, lh);
+                if (dropping) keep = keep_bits<T>(drop, thr16, (uint32_t)((beg + min(i, L - 1)) * heads + h), jt, lh);
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
+                for (int v = 0; v < NV; ++v) {
                     const float p = acc[jt][v] * inv;
                     const bool kept = (keep >> v) & 1u;
                     if (save_p)                                  // sign bit = dropped; keys / queries past the segment are out of range
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, kept ? p : -p), view_rsrc(pv, (jt * 32 + acc_row0(v)) * L),
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, kept ? p : -p), view_rsrc(pv, (jt * T + TL::row0(v)) * L),
                                                               i < L ? (4 * lh * L + i) * 4 : 0x7FFFFFF0, 0, 0);
                     acc[jt][v] = kept ? p * dinv : 0.f;
                 }
-                regs_mfma<HD>(acc[jt], vc[jt], o);
+                regs_mfma<HD, T>(acc[jt], vc[jt], o);
             }
-            store_cols<HD>(o, 1.f, ov, 0, it, li, lh);
+            store_cols<HD, T>(o, 1.f, ov, 0, it, li, lh);
         }
     }
+}
+
+// one (segment, head) pair: segments of <= 16 rows take the 16 x 16 tile (head dims whose quarter rows are whole 16-byte pieces)
+template <int HD, int JT>
+__device__ __forceinline__ void mhsa_fwd_pair(const float* __restrict__ qkv, int ldq, int D, int heads, float* __restrict__ out, int ldo,
+                                              float* __restrict__ lse, float* __restrict__ probs, int Lmax, const Dropout& drop, int h,
+                                              int beg, int L, int t0, int t1) {
+    if constexpr (JT == 1 && HD >= 16) {
+        if (L <= 16) {                                           // wave-uniform
+            mhsa_fwd_tile<HD, 1, 16>(qkv, ldq, D, heads, out, ldo, lse, probs, Lmax, drop, h, beg, L, t0, t1);
+            return;
+        }
+    }
+    mhsa_fwd_tile<HD, JT, 32>(qkv, ldq, D, heads, out, ldo, lse, probs, Lmax, drop, h, beg, L, t0, t1);
 }
 
 template <int HD, int JT>
@@ -303,13 +329,15 @@ __global__ __launch_bounds__(64 * JT) __attribute__((amdgpu_waves_per_eu(JT == 1
 // RC (recompute): the probabilities come from S^T = K Q^T and the saved log-sum-exp rows, the keep bits from the forward's Philox
 // counters (no [rows, heads, L] tensor exists).  !RC: the forward pass saved the signed probabilities (`probs`), read here through a
 // descriptor of the (segment, head) tile.  Same-box measurement (tools/mhsa_bulk_probe.py): see DESIGN.md section 4.
-template <int HD, int JT, bool RC>
-__device__ __forceinline__ void mhsa_bwd_pair(const float* __restrict__ qkv, int ldq, int D, int heads, const float* __restrict__ gout, int ldgo,
+template <int HD, int JT, bool RC, int T>
+__device__ __forceinline__ void mhsa_bwd_tile(const float* __restrict__ qkv, int ldq, int D, int heads, const float* __restrict__ gout, int ldgo,
                                               const float* __restrict__ lse, const float* __restrict__ probs, int Lmax, const Dropout& drop,
                                               float keep_scale, float* __restrict__ gqkv, int ldgq,
                                               float* colsum, float* __restrict__ Pd, float* __restrict__ Ds, int h, int beg, int L, int t0, int t1) {
-    constexpr int CT = (HD + 31) / 32, HH = HD / 2, LT = 32 * JT, PLD = LT + 1;
-    const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    using TL = Tile<T>;
+    using acc_t = typename TL::acc_t;
+    constexpr int CT = (HD + T - 1) / T, HH = HD / TL::KL, NV = TL::NV, LT = T * JT, PLD = LT + 1;
+    const int lane = threadIdx.x & 63, li = lane & (T - 1), lh = lane >> TL::SH;
     const float scale = rsqrtf((float)HD);
     const bool dropping = drop.p > 0.f;
     const uint32_t thr16 = (uint32_t)(drop.p * 65536.0f);
@@ -319,22 +347,22 @@ __device__ __forceinline__ void mhsa_bwd_pair(const float* __restrict__ qkv, int
     __syncthreads();                                         // the previous pair's readers of Pd / Ds are done
     // ---- orientation 1, lane = query i: dP^T tiles -> row dots -> dS^T (kept for orientation 2 in LDS) -> dQ
     {
-        float kr[RC ? JT : 1][HH], vr[JT][HH], kc[JT][CT][16];
+        float kr[RC ? JT : 1][HH], vr[JT][HH], kc[JT][CT][NV];
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
-            if constexpr (RC) load_row<HD>(qv, D, jt * 32 + li, lh, kr[jt]);
-            load_row<HD>(qv, 2 * D, jt * 32 + li, lh, vr[jt]);
-            load_cols<HD>(qv, D, jt, li, lh, kc[jt]);
+            if constexpr (RC) load_row<HD, T>(qv, D, jt * T + li, lh, kr[jt]);
+            load_row<HD, T>(qv, 2 * D, jt * T + li, lh, vr[jt]);
+            load_cols<HD, T>(qv, D, jt, li, lh, kc[jt]);
         }
 #pragma unroll 1
         for (int it = t0; it < t1; ++it) {
-            if (it * 32 >= L) break;
-            const int i = it * 32 + li;
+            if (it * T >= L) break;
+            const int i = it * T + li;
             float qr[RC ? HH : 1], gr[HH];
-            f32x16 dp[JT], ps[JT];
+            acc_t dp[JT], ps[JT];
             float lse_i = 0.f;
             if constexpr (RC) {
-                load_row<HD>(qv, 0, i, lh, qr);
+                load_row<HD, T>(qv, 0, i, lh, qr);
                 lse_i = lse[(size_t)(beg + min(i, L - 1)) * heads + h];
             } else {
                 // the saved tile [key j][query i] (L x L floats) as a view of L rows of L columns: keys past the segment are out of
@@ -344,10 +372,10 @@ __device__ __forceinline__ void mhsa_bwd_pair(const float* __restrict__ qkv, int
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                    for (int v = 0; v < 16; ++v)
-                        ps[jt][v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(view_rsrc(pv, (jt * 32 + acc_row0(v)) * L), off, 0, 0));
+                    for (int v = 0; v < NV; ++v)
+                        ps[jt][v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(view_rsrc(pv, (jt * T + TL::row0(v)) * L), off, 0, 0));
             }
-            load_row<HD>(gv, 0, i, lh, gr);
+            load_row<HD, T>(gv, 0, i, lh, gr);
             __builtin_amdgcn_sched_barrier(0);      // every load of this phase is in flight before the first MFMA (see orientation 2)
             float dot = 0.f;
             if constexpr (RC) {
@@ -358,13 +386,13 @@ __device__ __forceinline__ void mhsa_bwd_pair(const float* __restrict__ qkv, int
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt) {
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) ps[jt][v] = 0.f;
-                    rows_mfma<HD>(kr[jt], qr, ps[jt]);
+                    for (int v = 0; v < NV; ++v) ps[jt][v] = 0.f;
+                    rows_mfma<HD, T>(kr[jt], qr, ps[jt]);
                     uint32_t keep = 0xFFFFu;
-                    if (dropping) keep = keep_bits(drop, thr16, (uint32_t)((beg + min(i, L - 1)) * heads + h), jt, lh);
+                    if (dropping) keep = keep_bits<T>(drop, thr16, (uint32_t)((beg + min(i, L - 1)) * heads + h), jt, lh);
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) {
-                        const int j = jt * 32 + acc_row(v, lh);
+                    for (int v = 0; v < NV; ++v) {
+                        const int j = jt * T + acc_row<T>(v, lh);
                         const float p = (i < L && j < L) ? __expf(ps[jt][v] - lse_i) : 0.f;
                         ps[jt][v] = ((keep >> v) & 1u) ? p : -p;
                     }
@@ -373,68 +401,82 @@ __device__ __forceinline__ void mhsa_bwd_pair(const float* __restrict__ qkv, int
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) {
 #pragma unroll
-                for (int v = 0; v < 16; ++v) dp[jt][v] = 0.f;
-                rows_mfma<HD>(vr[jt], gr, dp[jt]);                         // dP^T[j][i] = V_j . dOut_i
+                for (int v = 0; v < NV; ++v) dp[jt][v] = 0.f;
+                rows_mfma<HD, T>(vr[jt], gr, dp[jt]);                      // dP^T[j][i] = V_j . dOut_i
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
+                for (int v = 0; v < NV; ++v) {
                     dp[jt][v] = ps[jt][v] > 0.f ? dp[jt][v] * keep_scale : 0.f;            // gradient of the un-dropped probability
                     dot += dp[jt][v] * ps[jt][v];
                 }
             }
-            dot += __shfl_xor(dot, 32, 64);
-            f32x16 dq[CT];
-            zero<CT>(dq);
+            dot = TL::sum(dot);
+            acc_t dq[CT];
+            zero<T, CT>(dq);
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) {
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int j = jt * 32 + acc_row(v, lh);
+                for (int v = 0; v < NV; ++v) {
+                    const int j = jt * T + acc_row<T>(v, lh);
                     const float p = fabsf(ps[jt][v]);
                     dp[jt][v] = p * (dp[jt][v] - dot);                     // dS^T[j][i]
                     Ds[j * PLD + i] = dp[jt][v];
                     Pd[j * PLD + i] = ps[jt][v] > 0.f ? p * keep_scale : 0.f;              // dropped-and-rescaled probability
                 }
-                regs_mfma<HD>(dp[jt], kc[jt], dq);
+                regs_mfma<HD, T>(dp[jt], kc[jt], dq);
             }
-            store_cols<HD>(dq, scale, dv_, 0, it, li, lh);
-            if (colsum != nullptr) col_add<HD>(dq, scale, colsum + h * HD, li, lh);             // in_proj_bias gradient, Q third
+            store_cols<HD, T>(dq, scale, dv_, 0, it, li, lh);
+            if (colsum != nullptr) col_add<HD, T>(dq, scale, colsum + h * HD, li, lh);          // in_proj_bias gradient, Q third
         }
     }
     __syncthreads();
     // ---- orientation 2, lane = key j: dK = dS^T Q, dV = Pd^T dOut
 #pragma unroll 1
     for (int jt = t0; jt < t1; ++jt) {
-        if (jt * 32 >= L) break;
-        const int j = jt * 32 + li;
-        f32x16 dk[CT], dv[CT];
-        zero<CT>(dk);
-        zero<CT>(dv);
+        if (jt * T >= L) break;
+        const int j = jt * T + li;
+        acc_t dk[CT], dv[CT];
+        zero<T, CT>(dk);
+        zero<T, CT>(dv);
 #pragma unroll
         for (int it = 0; it < JT; ++it) {
-            if (it * 32 >= L) break;
-            float qc[CT][16], gc[CT][16];
-            load_cols<HD>(qv, 0, it, li, lh, qc);
-            load_cols<HD>(gv, 0, it, li, lh, gc);
+            if (it * T >= L) break;
+            float qc[CT][NV], gc[CT][NV];
+            load_cols<HD, T>(qv, 0, it, li, lh, qc);
+            load_cols<HD, T>(gv, 0, it, li, lh, gc);
             // without this fence the scheduler of the 2-tile instantiation pairs every load with the MFMA that consumes it -- 48
             // dependent round trips, 69 us per launch for 4 % of the pairs
             __builtin_amdgcn_sched_barrier(0);
-            f32x16 ds, pd;
+            acc_t ds, pd;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int i = it * 32 + acc_row(v, lh);
+            for (int v = 0; v < NV; ++v) {
+                const int i = it * T + acc_row<T>(v, lh);
                 ds[v] = Ds[j * PLD + i];
                 pd[v] = Pd[j * PLD + i];
             }
-            regs_mfma<HD>(ds, qc, dk);                                     // dK[j][c] += dS[i][j] Q[i][c]
-            regs_mfma<HD>(pd, gc, dv);                                     // dV[j][c] += Pd[i][j] dOut[i][c]
+            regs_mfma<HD, T>(ds, qc, dk);                                  // dK[j][c] += dS[i][j] Q[i][c]
+            regs_mfma<HD, T>(pd, gc, dv);                                  // dV[j][c] += Pd[i][j] dOut[i][c]
         }
-        store_cols<HD>(dk, scale, dv_, D, jt, li, lh);
-        store_cols<HD>(dv, 1.f, dv_, 2 * D, jt, li, lh);
+        store_cols<HD, T>(dk, scale, dv_, D, jt, li, lh);
+        store_cols<HD, T>(dv, 1.f, dv_, 2 * D, jt, li, lh);
         if (colsum != nullptr) {                                               // ... K and V thirds
-            col_add<HD>(dk, scale, colsum + D + h * HD, li, lh);
-            col_add<HD>(dv, 1.f, colsum + 2 * D + h * HD, li, lh);
+            col_add<HD, T>(dk, scale, colsum + D + h * HD, li, lh);
+            col_add<HD, T>(dv, 1.f, colsum + 2 * D + h * HD, li, lh);
         }
     }
+}
+
+template <int HD, int JT, bool RC>
+__device__ __forceinline__ void mhsa_bwd_pair(const float* __restrict__ qkv, int ldq, int D, int heads, const float* __restrict__ gout, int ldgo,
+                                              const float* __restrict__ lse, const float* __restrict__ probs, int Lmax, const Dropout& drop,
+                                              float keep_scale, float* __restrict__ gqkv, int ldgq,
+                                              float* colsum, float* __restrict__ Pd, float* __restrict__ Ds, int h, int beg, int L, int t0, int t1) {
+    if constexpr (JT == 1 && HD >= 16) {
+        if (L <= 16) {                                           // wave-uniform
+            mhsa_bwd_tile<HD, 1, RC, 16>(qkv, ldq, D, heads, gout, ldgo, lse, probs, Lmax, drop, keep_scale, gqkv, ldgq, colsum, Pd, Ds, h, beg, L, t0, t1);
+            return;
+        }
+    }
+    mhsa_bwd_tile<HD, JT, RC, 32>(qkv, ldq, D, heads, gout, ldgo, lse, probs, Lmax, drop, keep_scale, gqkv, ldgq, colsum, Pd, Ds, h, beg, L, t0, t1);
 }
 
 template <int HD, int JT, int OCC, bool RC>

@@ -1206,6 +1206,14 @@ def test_mhsa_core_ragged_segments_with_dropout(hd, heads, p, listed):
     torch.cuda.synchronize()
     probs = probs_fwd
     assert torch.equal(out, out2) and torch.equal(lse, lse2)
+    if p > 0 and part == 0:
+        # the keep bit of (query row, head, key) does not depend on the tile a segment takes (round 6: 16 x 16 tiles for <= 16 rows, 32 x 32,
+        # two-wave 2 x 2 tiles): the same launch with EVERY segment through the two-wave instantiation draws the same mask
+        probs_all = torch.zeros(R, heads, Lmax, device=dev)
+        call("lego_mhsa_core_fwd", _ptr(qkv), 3 * D, _ptr(seg), n, None, D, heads, _ptr(torch.empty_like(out)), D, _ptr(torch.empty_like(lse)),
+             _ptr(probs_all), Lmax, _drop(drop), R, 3, None, None, _stream())
+        torch.cuda.synchronize()
+        assert torch.equal(torch.signbit(probs_all), torch.signbit(probs_fwd)) and float((probs_all - probs_fwd).abs().max()) < 1e-6
     # lse = log sum_j exp(q_i . k_j / sqrt(hd)) per (row, head)
     q3 = qkv.cpu().double().view(R, 3, heads, hd)
     for s_, L_ in enumerate(lens):
