@@ -349,6 +349,8 @@ class NamlEngine(_Base):
         self.mask_proj = torch.zeros(((self.Rc + 3) // 4) * D + 1, dtype=torch.uint8, device=self.dev)
         self.mask_conv = torch.zeros(((self.Rc + 3) // 4) * D + 1, dtype=torch.uint8, device=self.dev)
         self._slot_mask_step, self._mask_step = {}, -1
+        self._slot_clean = {}
+        self._loss2 = [self.loss, torch.zeros_like(self.loss)]          # training steps alternate (pre_forward clears the next one)
         self.wino_u = self._f(4, D, D)
         self.wino_ut = self._f(4, D, D)                   # the same sets transposed (data gradient)
         self.wino_slabs = _lib.lib().lego_conv3_wino_du_slabs(D, D, max(self.Pc, 1)) if self.wino_dw else 1
@@ -365,7 +367,7 @@ class NamlEngine(_Base):
     # The GloVe table is frozen, so the gathered rows X of a batch depend on its plan only: with plan slots enabled
     # (TrainStep) the gather of step N+1 runs right after its plan on the prefetch stream, off the critical path.
     _PLAN_FIELDS = _Base._PLAN_FIELDS + ("X", "pair_info", "mask_proj", "mask_conv", "inst_cat")
-    _DEDUP_FIELDS = ("Xu", "uniq", "inv", "perm", "keys_sorted")
+    _DEDUP_FIELDS = ("Xu", "uniq", "inv", "perm", "keys_sorted", "dHu")
 
     def enable_plan_slots(self):
         if getattr(self, "_slots", None) is None and self.dedup:
@@ -386,6 +388,36 @@ class NamlEngine(_Base):
     def use_slot(self, s):
         super().use_slot(s)
         self._mask_step = self._slot_mask_step.get(s, -1)
+        # the slot's per-token sums dHu are zero rows between its plan (plan_on clears them on the prefetch stream) and the first backward
+        # pass that adds into them; a slot used again WITHOUT a new plan clears them in the forward pass (side stream), as an un-planned pass does
+        self._cur_slot = s
+        self._dhu_zeroed = bool(self.dedup_bwd and self._slot_clean.get(s, False))
+
+    _cur_slot = None
+    _pre_step = None        # (training step index, plan slot) whose parameter-dependent prologue ran at the end of the previous step (pre_forward)
+
+    def pre_forward(self, slot):
+        """TrainStep, right after Adam on the main stream: the part of the NEXT training step's forward pass that depends on the parameters
+        and the slot's plan only -- the Winograd weight sets, the category rows of Y (embedding + Linear, cnn_operator.py:58-60) and the clear
+        of the next loss accumulator.  Rounds 2-5 ran these on a side stream at the head of the forward pass; the main stream then waited for
+        them twice (in front of the conv, in front of the additive product) and every cross-stream wait costs it 6-17 us even when the event
+        has long been signalled (profiles/r05_timeline.txt: 12.6 + 17.4 us holes around the conv).  Here they cost the main stream their own
+        ~20 us and no wait at all; the forward pass of a step prepared this way touches no side stream."""
+        P, D = self.P, self.D
+        b = self._slots[slot]
+        m = current_stream()
+        if self.wino:
+            self.kk(m, None, "lego_conv3_wino_pack", _ptr(P["item_op.cnn.weight"]), _ptr(self.wino_u), _ptr(self.wino_ut), D, D)
+        else:
+            self.kk(m, None, "lego_conv3_pack", _ptr(P["item_op.cnn.weight"]), _ptr(self.wt), D, D)
+        nxt = self._loss2[(self.step + 0) % 2]       # forward() of training step `self.step` accumulates into buffer step % 2
+        nxt.zero_()
+        self.kk(m, None, "lego_gather_rows", _ptr(P["embedding_vocab_table.category.weight"]), D, D, _ptr(b["inst_cat"]),
+                self.NIc, _ptr(b["counters"], 1), _ptr(self.cat_emb), D, 0)
+        self.kk(m, None, "lego_linear_fwd", _ptr(self.cat_emb), D, _ptr(P["item_op.linear.weight"]), D,
+                _ptr(P["item_op.linear.bias"]), _ptr(self.Y), D, self.NIc, _ptr(b["counters"], 1), D, D, 0,
+                None, None, None, _ptr(b["counters"], 0))
+        self._pre_step = (self.step, slot)
 
     def drop(self, p, site, training):
         if not training or p <= 0.0:
@@ -448,6 +480,9 @@ class NamlEngine(_Base):
             if self.wino_dw:
                 self.plan_pairs(stream, self._slots[slot])
             self.gather_tokens(stream, self._slots[slot])
+            if self.dedup_bwd:                       # the slot's per-token gradient sums start from zero rows: cleared here, off the main stream
+                self.kk(stream, None, "lego_zero_rows", _ptr(b["dHu"]), self.D, self.D, self.Uc, _ptr(b["counters"], 6))
+                self._slot_clean[slot] = True
 
     # ------------------------------------------------------------------ streams
     # Independent branches of the step run on side HIP streams so the small category / user-side kernels
@@ -488,6 +523,9 @@ class NamlEngine(_Base):
         if not planned:
             self._plan(cand, hist, hist_len)
             fork_ev = None                           # the plan was enqueued after the caller's event
+            self._dhu_zeroed, self._cur_slot = False, None
+        if training:
+            self.loss = self._loss2[self.step % 2]
         self._forward_items(training, fork_ev, zero_loss=True, gathered=planned and getattr(self, "_slots", None) is not None,
                             neck_ev=neck_ev)
         self._fused = bool(training and with_loss and self.fused_grads is not None)
@@ -529,6 +567,29 @@ class NamlEngine(_Base):
         ev = self._evs
         if not gathered:                             # un-planned call: the token rows (and, de-duplicated, the distinct-token count in
             self.gather_tokens(need_perm=not getattr(self, "_eval_only", False))   # counters[6], read by the side chain's lego_zero_rows
+        prepared = training and gathered and self._pre_step == (self.step, self._cur_slot)
+        self._pre_step = None
+        if prepared:
+            # pre_forward() ran this step's parameter-dependent prologue at the end of the previous step, on this stream: no side chain, no waits
+            if self.dedup:
+                self.kk(m, "proj_fwd", "lego_linear_fwd", _ptr(self.Xu), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
+                        _ptr(P["embedding_vocab_table.glove.linear.bias"]), _ptr(self.Hu), D, self.Uc, self.cnt(6), D, E0, 0,
+                        None, None, None, None)
+                self.kk(m, "proj_expand", "lego_expand_rows", _ptr(self.Hu), D, _ptr(self.inv), self.Rc, self.cnt(0), D,
+                        self.drop(self.p_proj, SITE_PROJ, training), None, None, 0, None, None, 0, None, _ptr(self.H), D)
+            else:
+                self.kk(m, "proj_fwd", "lego_linear_fwd", _ptr(self.X), E0, _ptr(P["embedding_vocab_table.glove.linear.weight"]), E0,
+                        _ptr(P["embedding_vocab_table.glove.linear.bias"]), _ptr(self.H), D, self.Rc, self.cnt(0), D, E0, 0,
+                        None, self.drop(self.p_proj, SITE_PROJ, training), None, None)
+            if not self._dhu_zeroed and self.dedup_bwd:
+                self.kk(m, None, "lego_zero_rows", _ptr(self.dHu), D, D, self.Uc, self.cnt(6))
+                self._dhu_zeroed = True
+            self._conv_fwd(m, training)
+            if neck_ev is not None:
+                neck_ev.record(m)
+            self._additive_fwd(m, "item_op.", _ptr(self.Y), self.Ryc, self.cnt(2), self.Tt, A, self.seg_off, self.cnt(0),
+                               self.NIc, self.cnt(1), self.items, self.wrow)
+            return
         if fork_ev is not None and sb is not m:
             sb.wait_event(fork_ev)
         else:
@@ -545,9 +606,9 @@ class NamlEngine(_Base):
         if zero_loss:
             with torch.cuda.stream(sb):
                 self.loss.zero_()
-        if training and self.dedup_bwd:              # the per-token gradient sums start from zero rows: cleared here, on the side
-            self.kk(sb, None, "lego_zero_rows", _ptr(self.dHu), D, D, self.Uc, self.cnt(6))      # chain the conv waits for anyway
-            self._dhu_zeroed = True
+        if training and self.dedup_bwd and not self._dhu_zeroed:      # the per-token gradient sums start from zero rows: cleared here, on the
+            self.kk(sb, None, "lego_zero_rows", _ptr(self.dHu), D, D, self.Uc, self.cnt(6))      # side chain the conv waits for anyway
+            self._dhu_zeroed = True                                       # (a planned slot: cleared with its plan)
         self.kk(sb, None, "lego_gather_rows", _ptr(P["embedding_vocab_table.category.weight"]), D, D, _ptr(self.inst_cat),
                 self.NIc, self.cnt(1), _ptr(self.cat_emb), D, 0)
         self.kk(sb, None, "lego_linear_fwd", _ptr(self.cat_emb), D, _ptr(P["item_op.linear.weight"]), D,
@@ -571,14 +632,7 @@ class NamlEngine(_Base):
             # with the plan) and ends while the projection still runs: ONE wait here covers the conv's weights and the category
             # rows of Y -- every cross-stream wait costs the main stream 6-14 us of idle even when already signalled
             m.wait_event(ev[8])
-        # k3: conv + relu + mask + dropout (cnn_operator.py:54-57)
-        if self.wino:
-            self.kk(m, "conv3_fwd", "lego_conv3_wino_fwd", _ptr(self.H), D, _ptr(self.wino_u), _ptr(P["item_op.cnn.bias"]),
-                    _ptr(self.pair_info), self.Pc, self.cnt(5), _ptr(self.Y), D, D, D,
-                    self.drop(self.p_conv, SITE_CONV, training))
-        else:
-            self.kk(m, "conv3_fwd", "lego_conv3_fwd", _ptr(self.H), D, _ptr(self.wt), _ptr(P["item_op.cnn.bias"]), _ptr(self.rowinfo),
-                    _ptr(self.Y), D, self.Rc, self.cnt(0), D, D, self.drop(self.p_conv, SITE_CONV, training), 0)
+        self._conv_fwd(m, training)
         if neck_ev is not None:
             neck_ev.record(m)                        # the next batch's prefetch chain starts here (see forward)
         if sb is not m:
@@ -586,6 +640,17 @@ class NamlEngine(_Base):
         # k5: additive attention pool over [title tokens..., category] (attention.py:31-38)
         self._additive_fwd(m, "item_op.", _ptr(self.Y), self.Ryc, self.cnt(2), self.Tt, A, self.seg_off, self.cnt(0),
                            self.NIc, self.cnt(1), self.items, self.wrow)
+
+    def _conv_fwd(self, m, training):
+        """k3: conv + relu + mask + dropout (cnn_operator.py:54-57)"""
+        P, D = self.P, self.D
+        if self.wino:
+            self.kk(m, "conv3_fwd", "lego_conv3_wino_fwd", _ptr(self.H), D, _ptr(self.wino_u), _ptr(P["item_op.cnn.bias"]),
+                    _ptr(self.pair_info), self.Pc, self.cnt(5), _ptr(self.Y), D, D, D,
+                    self.drop(self.p_conv, SITE_CONV, training))
+        else:
+            self.kk(m, "conv3_fwd", "lego_conv3_fwd", _ptr(self.H), D, _ptr(self.wt), _ptr(P["item_op.cnn.bias"]), _ptr(self.rowinfo),
+                    _ptr(self.Y), D, self.Rc, self.cnt(0), D, D, self.drop(self.p_conv, SITE_CONV, training), 0)
 
     def _forward_users(self, training):
         """k7: AdaOperator = additive pool over the clicked items of each user (ada_operator.py:31-34)"""
@@ -602,8 +667,10 @@ class NamlEngine(_Base):
                 _ptr(seg_off), None, extra, n_cap, n_dyn, D, A, _ptr(out), D, _ptr(wrow))
 
     # ------------------------------------------------------------------ backward
-    def backward(self, G: Dict[str, torch.Tensor], gloss: float = 1.0, gloss_dev: Optional[torch.Tensor] = None):
+    def backward(self, G: Dict[str, torch.Tensor], gloss: float = 1.0, gloss_dev: Optional[torch.Tensor] = None, join_ev=None):
         """Accumulates d(loss)/d(param) into G (reference key names); call after forward(training...).
+        `join_ev`: an event of ANOTHER stream (TrainStep: the next batch's plan on the prefetch stream) that the side stream waits for in front
+        of the final join -- the main stream's one wait at the end of this pass then covers it too.
         `gloss_dev`: a one-element device tensor multiplied into the loss gradient ON THE DEVICE (autograd's upstream gradient:
         `Legommender`'s engine route passes it instead of reading it on the host, which would be a device sync per backward)."""
         P, B, C, S, D, A, E0 = self.P, self.nb, self.C, self.S, self.D, self.A, self.E0
@@ -681,11 +748,15 @@ class NamlEngine(_Base):
                     _ptr(self.keys_sorted), self.cnt(0), _ptr(self.dHu), D, self.Uc, self.cnt(6),
                     0 if getattr(self, "_dhu_zeroed", False) else 1, None, None)
             self._dhu_zeroed = False
+            if self._cur_slot is not None:
+                self._slot_clean[self._cur_slot] = False
             self.kk(pst, "proj_bwd_weight", "lego_linear_bwd_weight", _ptr(self.dHu), D, _ptr(self.Xu), E0,
                     _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Uc, self.cnt(6), D, E0, None, None)
         else:
             self.kk(pst, "proj_bwd_weight", "lego_linear_bwd_weight", _ptr(self.dH), D, _ptr(self.X), E0,
                     _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Rc, self.cnt(0), D, E0, None, None)
+        if join_ev is not None:
+            (sb if sb is not m else m).wait_event(join_ev)
         self._fork(ev[6], sb, m)
         self.step = step_save
 
@@ -1223,6 +1294,7 @@ class NrmsEngine(_Base):
             self._side_fold_grads(pre, ws, G, sp, True)
         self._deferred.append(side_rows)
         self._deferred.append(side_params)
+        self._param_side = side_params               # (LEGO_X_TND_FIRST experiment: backward() may move it behind the in-projection weight gradient)
 
     def _att_bwd_head(self, pre, ws, G, rows_dyn, seg_off, n_cap, n_dyn, gout, st, ev, m, sw, sp):
         """the additive attention and the two affine layers behind the attention core, fold levels 0 and 1"""
@@ -1520,6 +1592,9 @@ class NrmsEngine(_Base):
                 else:
                     call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.glove.weight"]), D, D, V, _ptr(self.idx_tok),
                          self.Rc, self.cnt(0), _ptr(self.dE), D, st)
+        if os.environ.get("LEGO_X_TND_FIRST") == "1" and getattr(self, "_param_side", None) in self._deferred:
+            self._deferred.remove(self._param_side)
+            self._deferred.append(self._param_side)
         for side in self._deferred:                  # the item operator's side-stream launches, behind its whole main chain
             side()
         self._deferred = ()

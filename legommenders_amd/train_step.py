@@ -263,6 +263,7 @@ class TrainStep:
             self._go = torch.cuda.Event()
             self._neck = torch.cuda.Event()
             self._planned_step = -1
+            self._ready_joined = -1
         self.lr, self.total_steps, self.warmup = lr, total_steps, warmup
         self.seed, self.step_idx = seed, 0
         self.schedule = BatchSchedule(data.n_rows, B, tail)
@@ -366,7 +367,26 @@ class TrainStep:
         if last_of_cycle:
             self.sync_gradients()
             self.apply_update()
+        self._prepare_next()
         return loss
+
+    def params_changed(self):
+        """call after writing into the parameter views (`fp.P`) from outside a step: a prologue prepared from the old values is dropped"""
+        if hasattr(self.engine, "_pre_step"):
+            self.engine._pre_step = None
+
+    def _prepare_next(self):
+        """the parameter-dependent prologue of the NEXT batch's forward pass, here, behind Adam on the main stream (NamlEngine.pre_forward):
+        the next step then starts without a side chain and without cross-stream waits.  The next batch's plan is complete by now (it was
+        started at this step's neck on the prefetch stream); the backward pass's final join has already waited for it (`join_ev`)."""
+        eng = self.engine
+        if not (self.prefetch and hasattr(eng, "pre_forward")) or self._planned_step != self.batch_idx or eng._serial:
+            return
+        slot = self.batch_idx % 2
+        if self._ready_joined != self.batch_idx:
+            current_stream().wait_event(self._ready[slot])
+            self._ready_joined = self.batch_idx
+        eng.pre_forward(slot)
 
     def compute_gradients(self):
         """one batch: sample -> forward -> backward into the flat gradient buffer; returns (loss, optimiser step due)"""
@@ -379,7 +399,9 @@ class TrainStep:
             self.data.ensure_epoch(self.schedule.at(self.batch_idx + 1)[0])   # on this stream, before the events below
             if self._planned_step != self.batch_idx:
                 self._prefetch(self.batch_idx)
-            current_stream().wait_event(self._ready[slot])
+            if self._ready_joined != self.batch_idx:   # (else: the previous step's final join covered this batch's plan)
+                current_stream().wait_event(self._ready[slot])
+                self._ready_joined = self.batch_idx
             self.engine.use_slot(slot)
         else:
             self.sample_batch()
@@ -389,14 +411,22 @@ class TrainStep:
         go = neck = None
         if self.prefetch:
             go, neck = self._go, self._neck
-            go.record(current_stream())         # everything before this step's forward
+            if getattr(self.engine, "_pre_step", None) != (self.engine.step, slot):
+                go.record(current_stream())     # everything before this step's forward (a prepared forward pass forks nothing: no event)
+            else:
+                go = None
         _, loss = self.engine.forward(self.cand, self.hist, self.hist_len, training=True, planned=self.prefetch,
                                       fork_ev=go, neck_ev=neck)
         if self.prefetch:
             # next batch: starts where this step's item tower ends (at the head of this step's forward pass instead: no faster)
             self._prefetch(self.batch_idx + 1, neck)
         self.engine.grad_hooks = self._exchange_hooks() if (last_of_cycle and self.overlap_exchange) else None
-        self.engine.backward(self.fp.G)
+        if self.prefetch and hasattr(self.engine, "pre_forward") and not self.engine._serial:
+            # the backward pass's final join of the side stream also covers the next batch's plan (ONE wait on the main stream for both)
+            self.engine.backward(self.fp.G, join_ev=self._ready[(self.batch_idx + 1) % 2])
+            self._ready_joined = self.batch_idx + 1
+        else:
+            self.engine.backward(self.fp.G)
         self.engine.grad_hooks = None
         self.batch_idx += 1
         if not self.prefetch:

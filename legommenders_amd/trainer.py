@@ -246,6 +246,7 @@ class Trainer:
                     self.ts.fp.P[k].copy_(v)
                 elif self.exp.load.strict:
                     raise KeyError(k)
+            self.ts.params_changed()
         model_only = bool(self.exp.load.model_only) if model_only is None else model_only
         if not model_only:
             if "optimizer" not in state or "scheduler" not in state:

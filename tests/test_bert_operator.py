@@ -552,7 +552,10 @@ def test_blocks_take_their_workspace_from_the_arena_and_adam_runs_on_flat_buffer
     layer0 = model.item_op.transformer.encoder.layer[0].attention.self
     assert bert_native._stacked((layer0.query.weight, layer0.key.weight, layer0.value.weight)) is not None
     assert bert_native._stacked((layer0.query.bias.grad, layer0.key.bias.grad, layer0.value.bias.grad)) is not None
+    import gc
+    gc.collect()
     ar = arena_of(dev)
+    ar.reset()                                       # (the arena is process-wide: forward passes of earlier tests whose graphs are still alive hold frames)
     for _ in range(6):
         ps.step()
     torch.cuda.synchronize()
