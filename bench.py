@@ -632,7 +632,10 @@ def main():
             torch.cuda.empty_cache()
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import gather_hbm
-            gh["alone_cold_cache"] = gather_hbm.measure(dev, table=glove)
+            # cold caches two ways (profiles/r06_gather.txt): behind a 640 MB READ (clean lines: the kernel's own traffic only) and behind a
+            # 640 MB WRITE (rounds 4-5's harness: 256 MB of dirty lines that the gather's stores must evict -- their write-back is timed with it)
+            gh["alone_cold_cache"] = gather_hbm.measure(dev, table=glove, flush_kind="read")
+            gh["alone_cold_dirty_cache"] = gather_hbm.measure(dev, table=glove)
             gh["traffic"] = traffic.get("gather_rows_hbm")
             sec["gather_rows_hbm_bound"] = gh
         except Exception as exc:                   # noqa: BLE001 -- recorded like the other secondaries' failures; the metric line stands

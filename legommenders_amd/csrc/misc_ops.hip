@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 // 1 152-B rows gathered into registers read at 5.5-5.8 TB/s in this shape): a row is w4 <= 128 pieces of 16 B, lane l moves
 // pieces l and l + 64; the row index is wave-uniform (scalar load), there is no per-element division, and every row's pieces
 // are contiguous in one instruction.  Rows are dealt to waves round-robin so that neighbouring waves write neighbouring rows.
-template <int U, bool NT>
+template <int U>
 __device__ __forceinline__ void gather_rows_wave_body(const float* __restrict__ table, int ld_table, int w4, const int* __restrict__ idx, int rows,
                                                       float* __restrict__ out, int ld_out, int accumulate) {
     const int lane = threadIdx.x & 63;
@@ -288,13 +288,8 @@ __device__ __forceinline__ void gather_rows_wave_body(const float* __restrict__ 
             a[u] = b[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (src[u] >= 0) {
                 const f32x4* row = reinterpret_cast<const f32x4*>(table + (size_t)src[u] * ld_table);
-                if constexpr (NT) {         // once-read rows: streaming loads leave the caches to data that is used again
-                    if (one) a[u] = __builtin_nontemporal_load(row + lane);
-                    if (two) b[u] = __builtin_nontemporal_load(row + lane + 64);
-                } else {
-                    if (one) a[u] = row[lane];
-                    if (two) b[u] = row[lane + 64];
-                }
+                if (one) a[u] = row[lane];
+                if (two) b[u] = row[lane + 64];
             }
         }
 #pragma unroll
@@ -304,9 +299,6 @@ __device__ __forceinline__ void gather_rows_wave_body(const float* __restrict__ 
             f32x4* dst = reinterpret_cast<f32x4*>(out + (size_t)r * ld_out);
             if (accumulate) {
                 if (src[u] >= 0) { if (one) dst[lane] += a[u]; if (two) dst[lane + 64] += b[u]; }
-            } else if constexpr (NT) {
-                if (one) __builtin_nontemporal_store(a[u], dst + lane);
-                if (two) __builtin_nontemporal_store(b[u], dst + lane + 64);
             } else {
                 if (one) dst[lane] = a[u];
                 if (two) dst[lane + 64] = b[u];
@@ -315,22 +307,18 @@ __device__ __forceinline__ void gather_rows_wave_body(const float* __restrict__ 
     }
 }
 
-// NT = the launch MAY stream (its capacity is HBM-sized); whether it does is decided on the LIVE row count, which only the device
-// knows: a de-duplicated batch moves ~5 MB through a launch sized for 127 MB, and its rows are read again by the projection
-// right behind it -- those stay ordinary loads / stores (stream_bytes = 0: always stream, the LEGO_GATHER_NT=1 tuning form)
-template <int U, bool NT>
+// Access policy (round 6): plain loads and stores.  Round 5 streamed (nt) launches of >= 64 MB because that measured best behind a 640 MB
+// WRITE -- 256 MB of dirty lines in the Infinity Cache, which plain stores must evict first (3.5 TB/s against 4.3 streamed).  Behind a 640 MB
+// READ (cold but clean caches) plain accesses move 5.1-5.3 TB/s against 4.3-4.4, and inside the dense training step -- the case that counts --
+// the launch runs at 4.9 TB/s plain against 4.1-4.3 streamed (tools/gather_sweep.py, profiles/r06_gather.txt): the 127 MB it writes are read
+// again by the projection right behind it and the Infinity Cache can hold them.
+template <int U>
 __global__ __launch_bounds__(256) void gather_rows_wave_kernel(const float* __restrict__ table, int ld_table, int w4,
                                                                const int* __restrict__ idx, int rows_cap,
                                                                const int* __restrict__ rows_dyn, float* __restrict__ out, int ld_out,
-                                                               int accumulate, long long stream_bytes) {
+                                                               int accumulate) {
     const int rows = rows_dyn != nullptr ? min(rows_cap, *rows_dyn) : rows_cap;
-    if constexpr (NT) {
-        if ((long long)rows * w4 * 16 >= stream_bytes) {         // block-uniform
-            gather_rows_wave_body<U, true>(table, ld_table, w4, idx, rows, out, ld_out, accumulate);
-            return;
-        }
-    }
-    gather_rows_wave_body<U, false>(table, ld_table, w4, idx, rows, out, ld_out, accumulate);
+    gather_rows_wave_body<U>(table, ld_table, w4, idx, rows, out, ld_out, accumulate);
 }
 
 
@@ -1727,24 +1715,11 @@ extern "C" int lego_gather_rows(const float* table, int ld_table, int width, con
                                 const int32_t* rows_dyn, float* out, int ld_out, int accumulate, void* stream) {
     LEGO_REQUIRE((width & 3) == 0 && (ld_table & 3) == 0 && (ld_out & 3) == 0, "lego_gather_rows: width/ld must be multiples of 4");
     if (rows_cap <= 0) return 0;
-    static int wave_form = -1;                       // LEGO_GATHER_WAVE=0: the flat float4 stream (A/B)
-    if (wave_form < 0) { const char* v = getenv("LEGO_GATHER_WAVE"); wave_form = (v != nullptr && v[0] == '0') ? 0 : 1; }
-    if (wave_form && width >= 64 * 4 && width <= 128 * 4) {          // rows of 1-2 KB: one wave per row, 16 waves per CU
-        static int gu = -1, gnt = -1, gb = -1;               // LEGO_GATHER_U / _NT / _BLOCKS: rows in flight per wave, streaming accesses, grid (A/B)
-        if (gu < 0) { const char* v = getenv("LEGO_GATHER_U"); gu = v != nullptr ? atoi(v) : 4; }
-        // streaming (nt) loads and stores when the launch moves more than the caches hold between two uses of a line: uniform random
-        // 1 200-byte rows of the 480 MB table, cold Infinity Cache, 105.6 k rows: 67.5 -> 54.4 us (0.47 -> 0.58 of 8 TB/s, read + write
-        // bytes; tools/gather_hbm.py); a Zipf index stream (rows repeat) is faster with the default policy, so small launches keep it
-        if (gnt < 0) { const char* v = getenv("LEGO_GATHER_NT"); gnt = v != nullptr ? atoi(v) : 2; }
-        if (gb < 0) { const char* v = getenv("LEGO_GATHER_BLOCKS"); gb = v != nullptr ? atoi(v) : 1024; }
-        const int want_blocks = (rows_cap + 4 * gu - 1) / (4 * gu);   // 4 waves per block x U rows in flight
-        const int blocks = want_blocks < gb ? (want_blocks > 0 ? want_blocks : 1) : gb;
-#define LEGO_GATHER_GO(U_, NT_) hipLaunchKernelGGL((gather_rows_wave_kernel<U_, NT_>), dim3(blocks), dim3(256), 0, ST, table, ld_table, width / 4, idx, rows_cap, rows_dyn, out, ld_out, accumulate, gnt == 1 ? 0ll : (64ll << 20))
-        const bool nt = gnt == 1 || (gnt == 2 && !accumulate && (long long)rows_cap * width * 4 >= (64ll << 20));
-        if (gu == 8) { if (nt) LEGO_GATHER_GO(8, true); else LEGO_GATHER_GO(8, false); }
-        else if (gu == 2) { if (nt) LEGO_GATHER_GO(2, true); else LEGO_GATHER_GO(2, false); }
-        else { if (nt) LEGO_GATHER_GO(4, true); else LEGO_GATHER_GO(4, false); }
-#undef LEGO_GATHER_GO
+    if (width >= 64 * 4 && width <= 128 * 4) {                       // rows of 1-2 KB: one wave per row, 2 rows in flight per wave, 16 waves per CU
+        constexpr int U = 2;                                         // (2 / 4 / 8 rows in flight: 48.3 / 49.9 / 52.5 us on 105.6 k rows, profiles/r06_gather.txt)
+        const int want_blocks = (rows_cap + 4 * U - 1) / (4 * U);    // 4 waves per block x U rows in flight
+        const int blocks = want_blocks < 1024 ? (want_blocks > 0 ? want_blocks : 1) : 1024;
+        hipLaunchKernelGGL((gather_rows_wave_kernel<U>), dim3(blocks), dim3(256), 0, ST, table, ld_table, width / 4, idx, rows_cap, rows_dyn, out, ld_out, accumulate);
         return check_launch("lego_gather_rows");
     }
     const long long total = (long long)rows_cap * (width / 4);

@@ -722,6 +722,8 @@ class NamlEngine(_Base):
         # before the main stream's accumulate strip (123 KB of LDS) could start and left a 44 us hole in the main chain; behind
         # the small category-branch kernels it arrives when the strip is already running (0.705 -> 0.6985 ms/step, same-box A/B;
         # on the main stream instead -- after the strip or after the conv data gradient -- 0.72 ms)
+        # (round 6, same box: this product on the MAIN stream behind the additive data gradient -- the conv kernels then run uncontended --
+        # 0.5515 -> 0.564 ms; on the LDS-free tnd_kernel instead of the 64 x 64 tile kernel: 0.559 ms; profiles/r06_naml_tn_ab.txt)
         self.kk(sb, "additive_bwd_weight_item", "lego_linear_bwd_weight", _ptr(self.Tt), A, _ptr(self.Y), D,
                 _ptr(G["item_op.additive_attention.encoder.0.weight"]), D, self.Ryc, self.cnt(2), A, D, None, None)
         # ---- main: conv data gradient -> projection weight gradient
@@ -1294,7 +1296,6 @@ class NrmsEngine(_Base):
             self._side_fold_grads(pre, ws, G, sp, True)
         self._deferred.append(side_rows)
         self._deferred.append(side_params)
-        self._param_side = side_params               # (LEGO_X_TND_FIRST experiment: backward() may move it behind the in-projection weight gradient)
 
     def _att_bwd_head(self, pre, ws, G, rows_dyn, seg_off, n_cap, n_dyn, gout, st, ev, m, sw, sp):
         """the additive attention and the two affine layers behind the attention core, fold levels 0 and 1"""
@@ -1592,9 +1593,6 @@ class NrmsEngine(_Base):
                 else:
                     call("lego_scatter_add_rows", _ptr(G["embedding_vocab_table.glove.weight"]), D, D, V, _ptr(self.idx_tok),
                          self.Rc, self.cnt(0), _ptr(self.dE), D, st)
-        if os.environ.get("LEGO_X_TND_FIRST") == "1" and getattr(self, "_param_side", None) in self._deferred:
-            self._deferred.remove(self._param_side)
-            self._deferred.append(self._param_side)
         for side in self._deferred:                  # the item operator's side-stream launches, behind its whole main chain
             side()
         self._deferred = ()

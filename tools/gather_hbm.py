@@ -14,7 +14,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 PEAK_HBM_GBS = 8000.0
 
 
-def measure(dev, table=None, rows=105600, launches=8, V=400000, E0=300, zipf=False, seed=5):
+def measure(dev, table=None, rows=105600, launches=8, V=400000, E0=300, zipf=False, seed=5, flush_kind="write"):
+    """`flush_kind`: how the caches are made cold before every launch -- "write": 640 MB written (the last 256 MB stay in the Infinity Cache as
+    DIRTY lines that the gather's own traffic has to evict: their write-back competes with it), "read": 640 MB read (cold, clean lines)"""
     from legommenders_amd._lib import call
 
     def P(t):
@@ -35,7 +37,10 @@ def measure(dev, table=None, rows=105600, launches=8, V=400000, E0=300, zipf=Fal
     f()
     ts = []
     for _ in range(launches):
-        flush.add_(1.0)
+        if flush_kind == "write":
+            flush.add_(1.0)
+        else:
+            flush.sum()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); f(); b.record()
         torch.cuda.synchronize()
@@ -48,7 +53,7 @@ def measure(dev, table=None, rows=105600, launches=8, V=400000, E0=300, zipf=Fal
             "index_law": "zipf(1.2)" if zipf else "uniform", "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": round(ms, 5),
             "launch_ms_all": [round(t, 5) for t in ts], "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
             "reads_only_GBs": round(rows * E0 * 4 / (ms * 1e-3) / 1e9, 1),
-            "timed": f"median of {launches} launches, each behind a 640 MB write (cold Infinity Cache), HIP events around the launch"}
+            "timed": f"median of {launches} launches, each behind a 640 MB {flush_kind} (cold Infinity Cache" + (", dirty lines" if flush_kind == "write" else ", clean lines") + "), HIP events around the launch"}
 
 
 if __name__ == "__main__":
@@ -56,7 +61,7 @@ if __name__ == "__main__":
     rows = int(pos[0]) if len(pos) > 0 else 105600
     n = int(pos[1]) if len(pos) > 1 else 8
     d = torch.device("cuda:0")
-    res = {"uniform": measure(d, rows=rows, launches=n)}
+    res = {"uniform": measure(d, rows=rows, launches=n), "uniform_clean_cache": measure(d, rows=rows, launches=n, flush_kind="read")}
     if "--uniform-only" not in sys.argv:            # (the PMC passes: every row-gather launch of the process is then an HBM-sized one)
         res["zipf"] = measure(d, rows=rows, launches=n, zipf=True)
     print(json.dumps(res))
