@@ -24,7 +24,7 @@ struct EpiArgs {
     size_t tap_stride;        // C offset per tap (TN conv weight gradient)
     const int* row_off_dyn;   // device row offset of C / rowinfo / relu_ref rows
     int M, N, row_off;
-    int rows_form;            // gemm_dma.hpp: 1 = row-major epilogue through LDS (LEGO_EPI_ROWS=0: fragment-shaped stores, A/B)
+    int rows_form;            // gemm_dma.hpp: 1 = row-major epilogue through LDS (0: fragment-shaped stores)
 };
 
 template <bool ROWINFO, bool ACCUM, bool RELUREF, bool ATOMIC>

@@ -20,7 +20,7 @@
 // strip) stay on the row-strip kernels: N = 768 158 against 133 us at two workgroups per CU.
 // Epilogue kinds: bias + activation (none / ReLU / tanh), or accumulate onto C [+ ReLU' mask from a reference] + column sums.
 // Needs K % 4 == 0 (a partial last k tile reads zeros), N % 4 == 0, 16-byte aligned rows, A of < 2 GiB, no dropout / live-bit epilogue; everything else stays on the
-// row-strip kernels (gemm_ops.hip: launch_rows).  LEGO_ROWS2=0 turns it off (A/B).
+// row-strip kernels (gemm_ops.hip: launch_rows).
 #pragma once
 #include "gemm_epi.hpp"
 

@@ -1,5 +1,5 @@
 // Winograd F(2,3) conv over row pairs, second form (round 5).  Same arithmetic, work split and accumulators as wino_kernel<false>
-// (gemm_wino.hpp: a strip of <= 112 pairs x 128 columns per workgroup, 8 waves side by side over the columns, three accumulator
+// (round 3: a strip of <= 112 pairs x 128 columns per workgroup, 8 waves side by side over the columns, three accumulator
 // sets, v_mfma_f32_16x16x4_f32), with the parts of its k loop that kept the matrix pipe at 0.56 busy rebuilt:
 //
 //   * the WEIGHT fragments never touch LDS.  A wave owns 16 output columns, so the B operand of its MFMAs is 16 rows x 32 k of the
@@ -17,7 +17,7 @@
 //     the column sums are applied on that side.  The fragment-shaped epilogue stored 4 x 64 B per instruction, one dword per lane.
 //
 // Needs the keep bits precomputed (drop.mask) when dropout is on, N % 4 == 0, 16-byte aligned rows and an input of < 2 GiB; the
-// launcher (gemm_ops.hip: launch_wino) keeps wino_kernel<false> for everything else.  LEGO_WINO2=0 selects the old kernel (A/B).
+// entry points refuse anything else with the reason (wino2_why_not): round 6 removed the round-3 kernel this one superseded.
 #pragma once
 #include "gemm_epi.hpp"
 #include "wino_common.hpp"
