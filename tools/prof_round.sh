@@ -2,6 +2,7 @@
 # kernel trace (overlapped + serial), PMC passes (FETCH_SIZE / WRITE_SIZE / issue counters) of the NAML bench and of the HBM-sized
 # row gather, timeline of one step, the plain bench line.   tools/prof_round.sh [outdir] [model]
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+export BENCH_SPIN_MS=0 BENCH_PREWARM_STEPS=0      # (profiling passes: no wake-up loop, no scratch instance -- the kernel statistics hold the measured steps only)
 O=${1:-gpurun_out/prof_r06}; M=${2:-naml}; rm -rf $O; mkdir -p $O
 B="python3 bench.py --model $M --steps 100 --warmup 10 --no-cpu-baseline --no-secondary --no-dist-check"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/bench_under_rocprof.json 2> $O/stats.err
