@@ -1,6 +1,6 @@
 // The small, latency-bound row products of the path (user-side additive attention, the category column: a few thousand rows,
 // K <= 1024): light_kernel below.  (Rounds 2-4 also had a "one-shot" 512-thread form with the whole A strip and B panel in LDS; on a
-// side stream it could not START while a row-strip / Winograd product held the CU's LDS -- removed in round 6, DESIGN.md section 12.)
+// side stream it could not START while a row-strip / Winograd product held the CU's LDS -- removed in round 6, DESIGN.md section 9.1.)
 // Loaders and epilogue kinds are those of gemm_core.hpp / gemm_ops.hip.
 #pragma once
 #include "gemm_core.hpp"

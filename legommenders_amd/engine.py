@@ -667,10 +667,10 @@ class NamlEngine(_Base):
                 _ptr(seg_off), None, extra, n_cap, n_dyn, D, A, _ptr(out), D, _ptr(wrow))
 
     # ------------------------------------------------------------------ backward
-    def backward(self, G: Dict[str, torch.Tensor], gloss: float = 1.0, gloss_dev: Optional[torch.Tensor] = None, join_ev=None):
+    def backward(self, G: Dict[str, torch.Tensor], gloss: float = 1.0, gloss_dev: Optional[torch.Tensor] = None, defer_join: bool = False):
         """Accumulates d(loss)/d(param) into G (reference key names); call after forward(training...).
-        `join_ev`: an event of ANOTHER stream (TrainStep: the next batch's plan on the prefetch stream) that the side stream waits for in front
-        of the final join -- the main stream's one wait at the end of this pass then covers it too.
+        `defer_join`: leave the final join of the side stream to `finish_backward()` (TrainStep enqueues the next batch's prefetch chain in
+        between: every launch of this pass's critical chain is then in its queue before the host turns to the ~23 small prefetch launches).
         `gloss_dev`: a one-element device tensor multiplied into the loss gradient ON THE DEVICE (autograd's upstream gradient:
         `Legommender`'s engine route passes it instead of reading it on the host, which would be a device sync per backward)."""
         P, B, C, S, D, A, E0 = self.P, self.nb, self.C, self.S, self.D, self.A, self.E0
@@ -757,10 +757,18 @@ class NamlEngine(_Base):
         else:
             self.kk(pst, "proj_bwd_weight", "lego_linear_bwd_weight", _ptr(self.dH), D, _ptr(self.X), E0,
                     _ptr(G["embedding_vocab_table.glove.linear.weight"]), E0, self.Rc, self.cnt(0), D, E0, None, None)
+        self.step = step_save
+        if not defer_join:
+            self.finish_backward()
+
+    def finish_backward(self, join_ev=None):
+        """the main stream's ONE wait at the end of a backward pass: for the side stream and -- `join_ev`, an event of ANOTHER stream (TrainStep:
+        the next batch's plan on the prefetch stream) that the side stream is made to wait for first -- for whatever else the caller needs
+        before the optimiser step and the next forward pass"""
+        m, sb, _ = self._lanes()
         if join_ev is not None:
             (sb if sb is not m else m).wait_event(join_ev)
-        self._fork(ev[6], sb, m)
-        self.step = step_save
+        self._fork(self._evs[6], sb, m)
 
     def _pool_bwd(self, st, prefix, G, x_ptr, dx_ptr, t, A, seg_off, extra, n_cap, n_dyn, gout, wrow):
         P, D = self.P, self.D

@@ -417,15 +417,19 @@ class TrainStep:
                 go = None
         _, loss = self.engine.forward(self.cand, self.hist, self.hist_len, training=True, planned=self.prefetch,
                                       fork_ev=go, neck_ev=neck)
-        if self.prefetch:
-            # next batch: starts where this step's item tower ends (at the head of this step's forward pass instead: no faster)
-            self._prefetch(self.batch_idx + 1, neck)
         self.engine.grad_hooks = self._exchange_hooks() if (last_of_cycle and self.overlap_exchange) else None
         if self.prefetch and hasattr(self.engine, "pre_forward") and not self.engine._serial:
-            # the backward pass's final join of the side stream also covers the next batch's plan (ONE wait on the main stream for both)
-            self.engine.backward(self.fp.G, join_ev=self._ready[(self.batch_idx + 1) % 2])
+            # host order (round 6): the backward pass's launches first, THEN the next batch's prefetch chain (its ~23 small launches start on the
+            # device where this step's item tower ended -- `neck` -- whenever the host gets to them), then the backward pass's final join of the
+            # side stream, which also covers the next batch's plan: ONE wait on the main stream for both
+            self.engine.backward(self.fp.G, defer_join=True)
+            self._prefetch(self.batch_idx + 1, neck)
+            self.engine.finish_backward(join_ev=self._ready[(self.batch_idx + 1) % 2])
             self._ready_joined = self.batch_idx + 1
         else:
+            if self.prefetch:
+                # next batch: starts where this step's item tower ends (at the head of this step's forward pass instead: no faster)
+                self._prefetch(self.batch_idx + 1, neck)
             self.engine.backward(self.fp.G)
         self.engine.grad_hooks = None
         self.batch_idx += 1
