@@ -384,8 +384,11 @@ extern "C" int lego_linear_gelu_fwd(const float* x, int ldx, const float* W, int
     e.bias = bias; e.act = 3; e.C2 = z; e.ldc2 = ldz;
     const int tm = (M + 127) / 128;
     if (product_mode() == 1 && M >= SPLIT_MIN_ROWS) {
-        if (N >= 512) return launch<C128x256s, false, false, EpiPlain, true>(d, a, b, e, tm, (N + 255) / 256, 1, (hipStream_t)stream, "lego_linear_gelu_fwd");
-        return launch<C128x128s, false, false, EpiPlain, true>(d, a, b, e, tm, (N + 127) / 128, 1, (hipStream_t)stream, "lego_linear_gelu_fwd");
+        // the opt-in split-bf16 tiles (128 x 256, 64 x 64 per wave) have no registers to spare for the erf in their epilogue (measured: 248 -> 206
+        // TFLOP/s-equivalent fused): that mode keeps the product and the GELU as two passes
+        LEGO_REQUIRE(ldz == N && ldg == N, "lego_linear_gelu_fwd: the split-bf16 mode needs contiguous outputs (ldz=%d ldg=%d N=%d)", ldz, ldg, N);
+        if (lego_linear_fwd(x, ldx, W, ldw, bias, z, ldz, M, nullptr, N, K, 0, nullptr, nullptr, nullptr, nullptr, stream) != 0) return 1;
+        return lego_gelu_fwd(z, g, (int64_t)M * N, stream);
     }
     return launch<C128x128, false, false, EpiPlain>(d, a, b, e, tm, (N + 127) / 128, 1, (hipStream_t)stream, "lego_linear_gelu_fwd");
 }
@@ -402,9 +405,10 @@ extern "C" int lego_linear_bwd_data_gelu(const float* dy, int ldy, const float* 
     Epi e = make_epi(dz, lddz);
     e.relu_ref = z; e.ld_ref = ldz; e.act = 4;
     const int tm = (M + 127) / 128;
-    if (product_mode() == 1 && M >= SPLIT_MIN_ROWS) {
-        if (K >= 512) return launch<C128x256s, false, true, EpiRef, true>(d, a, b, e, tm, (K + 255) / 256, 1, (hipStream_t)stream, "lego_linear_bwd_data_gelu");
-        return launch<C128x128s, false, true, EpiRef, true>(d, a, b, e, tm, (K + 127) / 128, 1, (hipStream_t)stream, "lego_linear_bwd_data_gelu");
+    if (product_mode() == 1 && M >= SPLIT_MIN_ROWS) {              // (see lego_linear_gelu_fwd: fused, the split tile spilled -- 238 -> 36 TFLOP/s-equivalent)
+        LEGO_REQUIRE(ldz == K && lddz == K, "lego_linear_bwd_data_gelu: the split-bf16 mode needs contiguous z / dz (ldz=%d lddz=%d K=%d)", ldz, lddz, K);
+        if (lego_linear_bwd_data(dy, ldy, W, ldw, dz, lddz, M, nullptr, N, K, 0, nullptr, 0, 1.f, nullptr, nullptr, nullptr, nullptr, nullptr, stream) != 0) return 1;
+        return lego_gelu_bwd(dz, z, dz, (int64_t)M * K, stream);
     }
     return launch<C128x128, false, true, EpiRef>(d, a, b, e, tm, (K + 127) / 128, 1, (hipStream_t)stream, "lego_linear_bwd_data_gelu");
 }
