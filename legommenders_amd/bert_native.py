@@ -147,11 +147,11 @@ def _lin_bwd_data(g, ldg, col, W, dx, accumulate, tag=None):
 
 
 def _lin_bwd_weight(g, ldg, col, x, gW, tag=None):
-    """gW += g[:, col : col + N]^T x"""
+    """gW += g[:, col : col + N]^T x   (outputs of more than 1 M elements: the library issues them as 768-wide chunks, csrc/gemm_ops.hip)"""
     M, Kd = x.shape
     N = gW.shape[0]
     with _timed(tag, 2.0 * M * N * Kd):
-        call("lego_linear_bwd_weight", _ptr(g, col), ldg, _ptr(x), Kd, _ptr(gW), Kd, M, None, N, Kd, None, None, _stream())
+        call("lego_linear_bwd_weight", _ptr(g, col), ldg, _ptr(x), Kd, _ptr(gW), gW.stride(0), M, None, N, Kd, None, None, _stream())
 
 
 FUSED_GELU = True       # the GELU inside the two feed-forward products' epilogues (False: lego_gelu_fwd / _bwd as passes of their own -- the cross-check)

@@ -421,6 +421,24 @@ extern "C" int lego_linear_bwd_weight(const float* g, int ldg, const float* x, i
     // dW[N,K] += sum_r g[r,:]^T x[r,:]: TN product, reduction over the rows
     if (product_mode() == 0 && tnd_ok(N, K, M_cap, ldg, ldx, lddw))        // round 5: operand fragments straight from global memory (gemm_tnd.hpp)
         return launch_tnd(g, ldg, x, ldx, dW, lddw, N, K, M_cap, M_dyn, g_row_off_dyn, x_row_off_dyn, (hipStream_t)stream, "lego_linear_bwd_weight");
+    // Round 6: outputs beyond that kernel's window (BERT: 3072 x 768, 2304 x 768) as 768-wide CHUNKS inside it.  One launch of the tile kernel
+    // has too few tiles to split the reduction (576 tiles, split 1: 114-117 TFLOP/s; 2304 x 768: 108); the chunks are disjoint blocks of the
+    // output over the same operands -- the same bytes from L2 -- at 135 TFLOP/s each (profiles/r06_bert_wgrad_chunks.txt).  Exact.
+    constexpr int CH = 768;
+    if (product_mode() == 0 && (long long)N * K > (1ll << 20)) {
+        if (N % CH == 0 && N > CH && tnd_ok(CH, K, M_cap, ldg, ldx, lddw)) {
+            for (int r0 = 0; r0 < N; r0 += CH)
+                if (launch_tnd(g + r0, ldg, x, ldx, dW + (size_t)r0 * lddw, lddw, CH, K, M_cap, M_dyn, g_row_off_dyn, x_row_off_dyn, (hipStream_t)stream,
+                               "lego_linear_bwd_weight") != 0) return 1;
+            return 0;
+        }
+        if (K % CH == 0 && K > CH && tnd_ok(N, CH, M_cap, ldg, ldx, lddw)) {
+            for (int c0 = 0; c0 < K; c0 += CH)
+                if (launch_tnd(g, ldg, x + c0, ldx, dW + c0, lddw, N, CH, M_cap, M_dyn, g_row_off_dyn, x_row_off_dyn, (hipStream_t)stream,
+                               "lego_linear_bwd_weight") != 0) return 1;
+            return 0;
+        }
+    }
     McRows a{g, ldg, N, M_cap, g_row_off_dyn};
     McRows b{x, ldx, K, M_cap, x_row_off_dyn};
     Epi e = make_epi(dW, lddw);

@@ -55,7 +55,8 @@ def test_linear_family_matches_torch():
     dev = _dev()
     g = torch.Generator().manual_seed(5)
     for (M, N, Kd) in [(1, 64, 300), (130, 256, 300), (257, 64, 64), (1000, 256, 256), (77, 300, 64),
-                       (8300, 768, 128), (8250, 300, 64), (9000, 200, 256)]:      # the last three: row-strip kernel, 3 / 2 / 1 column panels
+                       (8300, 768, 128), (8250, 300, 64), (9000, 200, 256),       # these three: row-strip kernel, 3 / 2 / 1 column panels
+                       (2100, 1536, 768), (2100, 768, 1536)]:                     # weight gradients of > 1 M outputs: 768-wide chunks (rows / columns)
         x = torch.randn(M, Kd, generator=g)
         W = torch.randn(N, Kd, generator=g) * 0.1
         b = torch.randn(N, generator=g)
