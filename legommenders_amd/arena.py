@@ -22,15 +22,28 @@ import torch
 ALIGN = 256
 
 
-class Frame:
-    __slots__ = ("arena", "chunk", "off", "alive", "used")
+class _Mark:
+    """the arena's own record of an open frame (the `Frame` handle the caller holds points at it; the arena never references the handle, so a
+    handle dropped with its autograd node is finalised)"""
+    __slots__ = ("chunk", "off", "used", "alive")
 
-    def __init__(self, arena, chunk, off, used):
-        self.arena, self.chunk, self.off, self.alive, self.used = arena, chunk, off, True, used
+    def __init__(self, chunk, off, used):
+        self.chunk, self.off, self.used, self.alive = chunk, off, used, True
+
+
+class Frame:
+    __slots__ = ("arena", "mark")
+
+    def __init__(self, arena, mark):
+        self.arena, self.mark = arena, mark
+
+    @property
+    def alive(self):
+        return self.mark.alive
 
     def release(self):
-        if self.alive:
-            self.alive = False
+        if self.mark.alive:
+            self.mark.alive = False
             self.arena._reclaim()
 
     def __del__(self):                               # the autograd node that owned the frame died without a backward pass (eval, a dropped graph)
@@ -47,14 +60,14 @@ class Arena:
         self.cur, self.off = 0, 0                    # bump pointer: chunk index, byte offset inside it
         self.used = 0                                # bytes handed out in the open frames (aligned), over all chunks
         self.peak = 0
-        self.frames: List[Frame] = []
+        self.frames: List[_Mark] = []
         self.allocations = 0                         # chunk allocations so far (growth events)
 
     # ------------------------------------------------------------------ frames
     def push(self) -> Frame:
-        f = Frame(self, self.cur, self.off, self.used)
-        self.frames.append(f)
-        return f
+        m = _Mark(self.cur, self.off, self.used)
+        self.frames.append(m)
+        return Frame(self, m)
 
     def _reclaim(self):
         low = None
