@@ -72,6 +72,13 @@ __device__ __forceinline__ View make_view(const float* p, int ld, int L, int col
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t view_rsrc(const View& v, int off_floats) {          // off_floats: wave-uniform
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(v.p + off_floats), 0, max(v.bytes - off_floats * 4, 0), 0x00020000);
 }
+// a per-lane byte offset the compiler may neither hoist nor re-derive: the row offsets of a "column per lane" tile are walked as ONE running
+// register (off += step) instead of NV registers that live from the top of the pair to its last store
+__device__ __forceinline__ int pin(int x) { asm volatile("" : "+v"(x)); return x; }
+// rows from the previous register's row to register v's, key / row tile jt (the walk starts at row 0 of tile 0)
+template <int T> __device__ __forceinline__ constexpr int row_step(int jt, int v) {
+    return v > 0 ? Tile<T>::row0(v) - Tile<T>::row0(v - 1) : (jt > 0 ? T - Tile<T>::row0(Tile<T>::NV - 1) : 0);
+}
 // "row per lane" operand: columns [col0 + lh * HD/KL, col0 + (lh + 1) * HD/KL) of row `row` (zeros past the segment)
 template <int HD, int T>
 __device__ __forceinline__ void load_row(const View& v, int col0, int row, int lh, float (&r)[HD / Tile<T>::KL]) {
@@ -89,13 +96,17 @@ __device__ __forceinline__ void load_row(const View& v, int col0, int row, int l
 // "column per lane" operand: column col0 + min(ct * T + li, HD - 1) of rows tile * T + acc_row(s, lh), s = 0..NV-1
 template <int HD, int T>
 __device__ __forceinline__ void load_cols(const View& v, int col0, int tile, int li, int lh, float (&r)[(HD + T - 1) / T][Tile<T>::NV]) {
+    const __amdgpu_buffer_rsrc_t rs = view_rsrc(v, col0);
+    const int ldb = v.ld * 4;
 #pragma unroll
     for (int ct = 0; ct < (HD + T - 1) / T; ++ct) {
         const int c = min(ct * T + li, HD - 1);                  // lanes past the head dim compute a duplicate column that is never stored
-        const int off = ((tile * T + 4 * lh) * v.ld + c) * 4;
+        int off = ((tile * T + 4 * lh) * v.ld + c) * 4;
 #pragma unroll
-        for (int s = 0; s < Tile<T>::NV; ++s)
-            r[ct][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(view_rsrc(v, col0 + Tile<T>::row0(s) * v.ld), off, 0, 0));
+        for (int s = 0; s < Tile<T>::NV; ++s) {
+            off = pin(off + row_step<T>(0, s) * ldb);
+            r[ct][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+        }
     }
 }
 // acc += A B^T over the head dim, both operands "row per lane"
@@ -124,13 +135,17 @@ __device__ __forceinline__ void zero(typename Tile<T>::acc_t (&t)[CT]) {
 // range check (their offset is out of range)
 template <int HD, int T>
 __device__ __forceinline__ void store_cols(const typename Tile<T>::acc_t (&t)[(HD + T - 1) / T], float scale, const View& o, int col0, int tile, int li, int lh) {
+    const __amdgpu_buffer_rsrc_t rs = view_rsrc(o, col0);
+    const int ldb = o.ld * 4;
 #pragma unroll
     for (int ct = 0; ct < (HD + T - 1) / T; ++ct) {
         const int c = ct * T + li;
-        const int off = c < HD ? ((tile * T + 4 * lh) * o.ld + c) * 4 : 0x7FFFFFF0;
+        int off = c < HD ? ((tile * T + 4 * lh) * o.ld + c) * 4 : 0x70000000;            // (+ 31 rows of < 2^20 bytes stays out of range and positive)
 #pragma unroll
-        for (int v = 0; v < Tile<T>::NV; ++v)
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t[ct][v] * scale), view_rsrc(o, col0 + Tile<T>::row0(v) * o.ld), off, 0, 0);
+        for (int v = 0; v < Tile<T>::NV; ++v) {
+            off = pin(off + row_step<T>(0, v) * ldb);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t[ct][v] * scale), rs, off, 0, 0);
+        }
     }
 }
 
@@ -244,6 +259,7 @@ __device__ __forceinline__ void mhsa_fwd_tile(const float* __restrict__ qkv, int
         const View ov = make_view(out + (size_t)beg * ldo + h * HD, ldo, L, D - h * HD);
         const bool save_p = probs != nullptr;                    // the (segment, head) tile [key j][query i], L x L floats
         const View pv = make_view(save_p ? probs + ((size_t)beg * heads + (size_t)h * L) * Lmax : qkv, L, save_p ? L : 0, save_p ? L : 0);
+        const __amdgpu_buffer_rsrc_t prs = view_rsrc(pv, 0);
         float kr[JT][HH], vc[JT][CT][NV];
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
@@ -254,6 +270,7 @@ __device__ __forceinline__ void mhsa_fwd_tile(const float* __restrict__ qkv, int
         for (int it = t0; it < t1; ++it) {
             if (it * T >= L) break;
             const int i = it * T + li;
+            int poff = i < L ? (4 * lh * L + i) * 4 : 0x70000000;
             float qr[HH];
             load_row<HD, T>(qv, 0, i, lh, qr);
             __builtin_amdgcn_sched_barrier(0);      // all operand loads in flight before the first MFMA
@@ -290,9 +307,10 @@ __device__ __forceinline__ void mhsa_fwd_tile(const float* __restrict__ qkv, int
                 for (int v = 0; v < NV; ++v) {
                     const float p = acc[jt][v] * inv;
                     const bool kept = (keep >> v) & 1u;
-                    if (save_p)                                  // sign bit = dropped; keys / queries past the segment are out of range
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, kept ? p : -p), view_rsrc(pv, (jt * T + TL::row0(v)) * L),
-                                                              i < L ? (4 * lh * L + i) * 4 : 0x7FFFFFF0, 0, 0);
+                    if (save_p) {                                // sign bit = dropped; keys / queries past the segment are out of range
+                        poff = pin(poff + row_step<T>(jt, v) * L * 4);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, kept ? p : -p), prs, poff, 0, 0);
+                    }
                     acc[jt][v] = kept ? p * dinv : 0.f;
                 }
                 regs_mfma<HD, T>(acc[jt], vc[jt], o);
@@ -368,12 +386,15 @@ __device__ __forceinline__ void mhsa_bwd_tile(const float* __restrict__ qkv, int
                 // the saved tile [key j][query i] (L x L floats) as a view of L rows of L columns: keys past the segment are out of
                 // range, and so is every lane whose query is (offset past the tile)
                 const View pv = make_view(probs + ((size_t)beg * heads + (size_t)h * L) * Lmax, L, L, L);
-                const int off = i < L ? (4 * lh * L + i) * 4 : 0x7FFFFFF0;
+                const __amdgpu_buffer_rsrc_t prs = view_rsrc(pv, 0);
+                int off = i < L ? (4 * lh * L + i) * 4 : 0x70000000;
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                    for (int v = 0; v < NV; ++v)
-                        ps[jt][v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(view_rsrc(pv, (jt * T + TL::row0(v)) * L), off, 0, 0));
+                    for (int v = 0; v < NV; ++v) {
+                        off = pin(off + row_step<T>(jt, v) * L * 4);
+                        ps[jt][v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, off, 0, 0));
+                    }
             }
             load_row<HD, T>(gv, 0, i, lh, gr);
             __builtin_amdgcn_sched_barrier(0);      // every load of this phase is in flight before the first MFMA (see orientation 2)
