@@ -304,15 +304,16 @@ __device__ __forceinline__ void mhsa_fwd_tile(const float* __restrict__ qkv, int
                 uint32_t keep = 0xFFFFu;
                 if (dropping) keep = keep_bits<T>(drop, thr16, (uint32_t)((beg + min(i, L - 1)) * heads + h), jt, lh);
 #pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    const float p = acc[jt][v] * inv;
-                    const bool kept = (keep >> v) & 1u;
-                    if (save_p) {                                // sign bit = dropped; keys / queries past the segment are out of range
+                for (int v = 0; v < NV; ++v) acc[jt][v] *= inv;                  // the probabilities
+                if (save_p) {                                    // ONE wave-uniform branch around the NV stores (the pinned offset is a volatile
+#pragma unroll                                                   // statement: inside the register loop it made the branch per register)
+                    for (int v = 0; v < NV; ++v) {               // sign bit = dropped; keys / queries past the segment are out of range
                         poff = pin(poff + row_step<T>(jt, v) * L * 4);
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, kept ? p : -p), prs, poff, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ((keep >> v) & 1u) ? acc[jt][v] : -acc[jt][v]), prs, poff, 0, 0);
                     }
-                    acc[jt][v] = kept ? p * dinv : 0.f;
                 }
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[jt][v] = ((keep >> v) & 1u) ? acc[jt][v] * dinv : 0.f;
                 regs_mfma<HD, T>(acc[jt], vc[jt], o);
             }
             store_cols<HD, T>(o, 1.f, ov, 0, it, li, lh);
