@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      Dropout dpost, float* __restrict__ dy, int lddy, float* __restrict__ dresid, int lddr,
                                                      float* dgamma, float* dbeta, float* dybias, int rows, int W) {
     __shared__ float red[4][3][LN_MAX_NJ * 256];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int waves = gridDim.x * (blockDim.x >> 6);
     const float inv_pre = dpre.p > 0.f ? 1.f / (1.f - dpre.p) : 1.f, inv_post = dpost.p > 0.f ? 1.f / (1.f - dpost.p) : 1.f;
     f32x4 gm[NJ], ag[NJ], ab[NJ], ay[NJ];

@@ -656,7 +656,7 @@ __global__ __launch_bounds__(256) void nrms_special_grads_kernel(const int* __re
     const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
     const int first = blockIdx.x * kSpecItems;
     if (first >= n) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform: row indices and addresses stay scalar)
     const int c = blockIdx.y * 256 + 4 * lane;
     for (int e = threadIdx.x; e < n_cat * 256; e += 256) (&tab[0][0])[e] = 0.f;
     __syncthreads();
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256) void scatter_add_small_kernel(float* grad_tabl
     const int first = blockIdx.x * iters * kSmallChunk;
     if (first >= rows) return;
     const int c0 = blockIdx.y * 256;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform: row indices and addresses stay scalar)
     for (int e = threadIdx.x; e < table_rows * 256; e += 256) (&tab[0][0])[e] = 0.f;
     if (threadIdx.x < kSmallTableRows) touched[threadIdx.x] = 0;
     __syncthreads();
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     const int M = M_dyn != nullptr ? min(M_cap, *M_dyn) : M_cap;
     const int off = off_dyn != nullptr ? *off_dyn : 0;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int ry = threadIdx.x >> 6;
+    const int ry = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r0 = blockIdx.y * 256;
     if (r0 >= M) return;
     float s = 0.f;
@@ -836,7 +836,7 @@ __global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ 
     __shared__ f32x4 part[4][64];
     const int M = M_dyn != nullptr ? min(M_cap, *M_dyn) : M_cap;
     const int off = off_dyn != nullptr ? *off_dyn : 0;
-    const int lane = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, ry = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int c = (blockIdx.x * 64 + lane) * 4;
     const int r0 = blockIdx.y * 256;
     if (r0 >= M) return;
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(256) void additive_pool_fwd_kernel(
     __shared__ float red_acc[4][kMaxChunks * 256];
     __shared__ float red_s[4];
     const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform: row indices and addresses stay scalar)
     const int i = blockIdx.x;
     if (i >= n) return;
     const int beg = seg_off[i], len = seg_off[i + 1] - beg;
@@ -956,7 +956,7 @@ __global__ __launch_bounds__(256) void additive_pool_fwd_fast_kernel(
     __shared__ float red_acc[4][256];
     __shared__ float red_s[4];
     const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform: row indices and addresses stay scalar)
     const int i = blockIdx.x;
     if (i >= n) return;
     const int beg = seg_off[i], len = seg_off[i + 1] - beg;
@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(256) void additive_pool_bwd_kernel(
     __shared__ float red[2][4][kMaxChunks * 256];
     __shared__ float red_s[2][4];
     const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform: row indices and addresses stay scalar)
     f32x4 aw2[kMaxChunks], ab1[kMaxChunks], w2v[kMaxChunks];
 #pragma unroll
     for (int j = 0; j < kMaxChunks; ++j) {
@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(256) void additive_pool_bwd_fast_kernel(
     __shared__ float red[2][4][256];
     __shared__ float red_s[2][4];
     const int n = n_dyn != nullptr ? min(n_cap, *n_dyn) : n_cap;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform: row indices and addresses stay scalar)
     const int c = 4 * lane;
     const bool inD = c < D, inA = c < A;
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1301,7 +1301,7 @@ __global__ __launch_bounds__(kUT_NW * 64) void user_tower_train_kernel(
     __shared__ float red[kMaxChunks * 256];             // partial sums of the 16 waves meet here through ds_add_f32
     __shared__ float uvec[kMaxChunks * 256], duvec[kMaxChunks * 256];
     __shared__ float wl[kMaxSegRows], dwl[kMaxSegRows], sc[kMaxCand], red_s[kUT_NW];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform: row indices and addresses stay scalar)
     const int b = blockIdx.x;
     const int BC = B * C;
     const int beg = hist_off[b], len = hist_off[b + 1] - beg;
@@ -1431,7 +1431,7 @@ __global__ __launch_bounds__(kUT_NW * 64) void user_tower_train_fast_kernel(
     __shared__ float red[256], red2[256];
     __shared__ float uvec[256], duvec[256];
     __shared__ float sc[kMaxCand], red_s[kUT_NW];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform: row indices and addresses stay scalar)
     const int b = blockIdx.x;
     const int BC = B * C;
     const int beg = hist_off[b], len = hist_off[b + 1] - beg;
