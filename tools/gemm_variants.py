@@ -24,7 +24,7 @@ names = {0: "128x128 4w(2x2)", 1: "128x128 8w(2x4)", 2: "256x128 8w(4x2)", 3: "1
          25: "SPLIT 64x128 1x4", 26: "SPLIT 128x128 4x2 stag"}
 SHAPES = [(26368, 256, 768), (24000, 256, 768), (28672, 256, 768), (32768, 256, 768), (65536, 256, 768), (26368, 256, 256), (26368, 256, 300), (26368, 200, 256), (1000, 256, 768), (26368+5, 240, 96), (3200, 200, 256), (3200, 256, 256), (3520, 256, 256), (6400, 256, 256), (26368, 768, 256), (30720, 768, 300), (105600, 256, 256), (26368, 256, 32), (26368, 256, 4), (26368, 256, 36)]
 if len(sys.argv) > 2 and sys.argv[2] == 'small':
-    SHAPES = [(4530, 256, 300), (4530, 256, 256), (8000, 256, 300)]
+    SHAPES = [(4530, 256, 300), (4530, 256, 256), (4530, 768, 256), (8000, 256, 300)]
 if len(sys.argv) > 2 and sys.argv[2] == 'bert':      # BERT-base block products at the rows of a B = 64 step (config 5)
     SHAPES = [(29600, 3072, 768), (29600, 768, 3072), (29600, 768, 768), (29600, 2304, 768)]
 if len(sys.argv) > 2 and sys.argv[2] == 'short':
