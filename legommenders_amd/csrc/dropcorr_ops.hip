@@ -17,6 +17,9 @@
 // (Round 5 also built the data gradient's per-key form -- per-key sums of d(qkv), a product over the keys and a correction kernel whose
 // atomics queued on the Zipf head's rows: 620 us against 130 for the row form; removed in round 6, DESIGN.md section 11.4 has the record.)
 #include <stdlib.h>
+#include <map>
+#include <mutex>
+#include <utility>
 #include "../../include/lego_hip.h"
 #include "common.hpp"
 
@@ -37,40 +40,100 @@ __device__ __forceinline__ void stage_wt(const float* __restrict__ wt, int ldw, 
     }
 }
 
-// keep bits of row r, coordinates 4 lane .. 4 lane + 3 (lane < D / 4), as bits 0 / 8 / 16 / 24 of the returned word; 0x01010101 = all kept
-__device__ __forceinline__ uint32_t keep_word(const uint8_t* __restrict__ mask, int r, int D, int lane) {
-    if (4 * lane >= D) return 0x01010101u;
-    return (*reinterpret_cast<const uint32_t*>(mask + (uint64_t)(r >> 2) * (uint64_t)D + (uint64_t)(4 * lane)) >> (r & 3)) & 0x01010101u;
+// no Dropout (evaluation, p = 0): out[r][cb + 2 lane ..] = Q_key(r) + b for the rows of a strip; lane = two consecutive output columns.  A wave
+// owns a contiguous run of rows, reads 64 keys with one vector load and fetches the q pieces of four rows at a time, one group ahead
+__global__ __launch_bounds__(DC_THREADS) void qkv_expand_plain_kernel(const float* __restrict__ qkvu, int ldq, const float* __restrict__ bias,
+                                                                      const int* __restrict__ inv, int rows_cap, const int* __restrict__ rows_dyn, int N,
+                                                                      float* __restrict__ out, int ldo, int strips) {
+    const int rows = rows_dyn != nullptr ? min(rows_cap, *rows_dyn) : rows_cap;
+    const int nblk = (N + DC_CB - 1) / DC_CB;
+    const int blk = blockIdx.x % nblk, strip = blockIdx.x / nblk;
+    const int cb = blk * DC_CB;
+    const int per = (rows + strips - 1) / strips;
+    const int r0 = strip * per, r1 = min(rows, r0 + per);
+    if (r0 >= r1) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int col = cb + 2 * lane;
+    const bool col_ok = col < N;
+    const int colc = min(col, N - 2);
+    const f32x2_t b2 = bias != nullptr ? *reinterpret_cast<const f32x2_t*>(bias + colc) : f32x2_t{0.f, 0.f};
+    const int cpw = (r1 - r0 + DC_WAVES - 1) / DC_WAVES;
+    const int ws = r0 + wave * cpw, we = min(r1, ws + cpw);
+    for (int gb = ws; gb < we; gb += 64) {
+        const int kv = inv[min(gb + lane, we - 1)];
+        const int gn = min(64, we - gb);
+        f32x2_t cur[4], nxt[4];
+        auto fetch = [&](f32x2_t (&q)[4], int b) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                q[u] = *reinterpret_cast<const f32x2_t*>(qkvu + (size_t)__builtin_amdgcn_readlane(kv, min(b + u, gn - 1)) * ldq + colc);
+        };
+        fetch(cur, 0);
+        for (int b = 0; b < gn; b += 4) {
+            fetch(nxt, b + 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (b + u < gn && col_ok) *reinterpret_cast<f32x2_t*>(out + (size_t)(gb + b + u) * ldo + col) = cur[u] + b2;
+                cur[u] = nxt[u];
+            }
+        }
+    }
 }
 
-// out[r][cb + 2 lane ..] for the rows of a strip; lane = two consecutive output columns.
-//
-// Arithmetic: per row the wave compacts its dropped coordinates into a list (LDS offset of the W^T row, h value) -- one entry per lane
-// when read back -- and walks it four entries at a time: the entries come out of the list registers as scalars (v_readlane with a
-// loop-counter index), so a turn is four independent ds_read_b64 of W^T rows and four packed multiply-adds with a scalar operand.
-// Memory: a row's inputs are two dependent trips (its key, then q / h / keep bits at that key) and the LDS slice leaves room for four
-// waves per SIMD, so the trips are taken in bulk: a wave owns a CONTIGUOUS run of rows, reads 64 keys / flags with one vector load,
-// and fetches the inputs of four rows at a time, one group of four ahead of the arithmetic, with no branch around the loads (indices
-// past the run are clamped) so the compiler's counted waits stay exact.  (Round 5's first forms: one coordinate per turn off the ballot
-// mask, every step waiting on the one before, 93 us at the bench batch; then the four-entry turns with the loads still row by row:
-// 96 us -- the waves were sitting on the two trips per row, not on the arithmetic.  With both: 88 us, of which 21 the plain
-// expansion, 18 keep words + list, 49 the correction's arithmetic = vector-ALU issue: 2 v_readlane + v_add + v_pk_fma per coordinate
-// and 128 columns.  Two forms that move work off the vector ALU, built and measured slower (tools/dropcorr_time.py): the address on
-// the scalar side with ds_read_addtid_b32 (LDS address = M0 + offset + 4 lane; one v_readlane + one v_pk_fma per coordinate): 140 us --
-// a write of M0 waits for the LDS reads in flight that used the old value, so the reads of a turn run one after the other; the
-// coordinates straight off four ballot masks with s_ff1 / s_and chains instead of the list: 121 us -- the dependent scalar chain and the
-// per-mask padding of the four-coordinate turns cost more than the list they save.)
-constexpr int DC_LIST = 256;               // list entries per wave (= the widest row: D <= 256)
-struct Rows4 {
-    f32x2_t q[4];
-    f32x4 h[4];
-    uint32_t kw[4];
-};
-template <bool DROP>
-__global__ __launch_bounds__(DC_THREADS) void qkv_expand_dropcorr_kernel(
-    const float* __restrict__ qkvu, int ldq, const float* __restrict__ eu, int lde, const float* __restrict__ wt, int ldw,
-    const float* __restrict__ bias, const int* __restrict__ inv, const int* __restrict__ rowinfo, const uint8_t* __restrict__ mask, float scale,
-    int rows_cap, const int* __restrict__ rows_dyn, int D, int N, float* __restrict__ out, int ldo, int strips) {
+// ---------------------------------------------------------------- the Dropout correction: dropped coordinates as (W^T row offset, h value) PAIRS
+// Round 5's kernel built a row's list of dropped coordinates inside the expansion -- once per 128-column slice, six times per row -- kept it in
+// registers and took offset and multiplier out of them with two v_readlane per coordinate: four vector instructions per coordinate and slice,
+// and the vector ALU bounded it (88 us at the bench batch: 21 the plain expansion, 18 keep words + list, 49 the correction).  Round 6:
+//   * dropcorr_pairs_kernel writes every row's list ONCE (one wave per row; the same (coordinate % 4, lane) order, so the sums keep their order), padded
+//     with (offset 0, multiplier 0) pairs to a multiple of DCP_CHUNK: a padded turn adds 0 x W^T[0];
+//   * qkv_expand_pairs_kernel reads it through the SCALAR unit -- s_load_dwordx16 = 8 pairs in 16 scalar registers -- so offset and multiplier
+//     are scalar operands of the address add and of the packed multiply-add: TWO vector instructions + one ds_read_b64 per coordinate.
+// 86 -> 76 us for both launches (tools/dropcorr_time.py), NRMS step 0.955 -> 0.950 ms.  Not the 2 x the instruction count promises: scalar loads and
+// LDS reads share one counter (lgkmcnt) and scalar loads return out of order, so the wait in front of the first multiply-add of a turn also waits
+// for the list -- every turn of 32 pairs pays an L2 round trip that only the other three waves of the SIMD cover.  (Round 6 also tried the lists read
+// by wave-uniform VECTOR loads: 85 us, the 1 KB a uniform 16-byte load returns through the 64 B/clk path costs what the v_readlane pairs did.)
+constexpr int DCP_CHUNK = 8;                 // pairs per scalar load
+constexpr int DCP_WAVES = 4;
+
+__global__ __launch_bounds__(DCP_WAVES * 64) void dropcorr_pairs_kernel(const float* __restrict__ eu, int lde, const int* __restrict__ inv,
+                                                                        const int* __restrict__ rowinfo, const uint8_t* __restrict__ mask, int rows_cap,
+                                                                        const int* __restrict__ rows_dyn, int D, f32x2_t* __restrict__ pairs, int stride,
+                                                                        int* __restrict__ cnt) {
+    const int rows = rows_dyn != nullptr ? min(rows_cap, *rows_dyn) : rows_cap;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const bool has = 4 * lane < D;
+    const int hoff = has ? 4 * lane : 0;
+    for (int r = blockIdx.x * DCP_WAVES + wave; r < rows; r += gridDim.x * DCP_WAVES) {
+        const int k = inv[r], ri = rowinfo[r];
+        if ((ri & RI_LIVE) == 0) {                               // wave-uniform: [SEP] / category positions carry no Dropout
+            if (lane == 0) cnt[r] = 0;
+            continue;
+        }
+        const f32x4 h = *reinterpret_cast<const f32x4*>(eu + (size_t)k * lde + hoff);
+        const uint32_t kw = has ? (*reinterpret_cast<const uint32_t*>(mask + (uint64_t)(r >> 2) * (uint64_t)D + (uint64_t)hoff) >> (r & 3)) : 0xFFFFFFFFu;
+        f32x2_t* const list = pairs + (size_t)r * stride;
+        int n = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                            // (j, lane) order: the order the in-kernel list had
+            const bool d = ((kw >> (8 * j)) & 1u) == 0u;
+            const unsigned long long m = __ballot(d);
+            if (d) list[n + __popcll(m & lt)] = f32x2_t{__int_as_float((4 * lane + j) * DC_CB * 4), h[j]};
+            n += __popcll(m);
+        }
+        n = __builtin_amdgcn_readfirstlane(n);
+        const int padded = (n + DCP_CHUNK - 1) / DCP_CHUNK * DCP_CHUNK;
+        if (n + lane < padded) list[n + lane] = f32x2_t{0.f, 0.f};
+        if (lane == 0) cnt[r] = n;
+    }
+}
+
+__global__ __launch_bounds__(DC_THREADS) void qkv_expand_pairs_kernel(
+    const float* __restrict__ qkvu, int ldq, const float* __restrict__ wt, int ldw, const float* __restrict__ bias, const int* __restrict__ inv,
+    const uint4* __restrict__ pairs, int stride16, const int* __restrict__ cnt, float scale, int rows_cap, const int* __restrict__ rows_dyn, int D, int N,
+    float* __restrict__ out, int ldo, int strips) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int rows = rows_dyn != nullptr ? min(rows_cap, *rows_dyn) : rows_cap;
     const int nblk = (N + DC_CB - 1) / DC_CB;
@@ -79,113 +142,74 @@ __global__ __launch_bounds__(DC_THREADS) void qkv_expand_dropcorr_kernel(
     const int per = (rows + strips - 1) / strips;
     const int r0 = strip * per, r1 = min(rows, r0 + per);
     if (r0 >= r1) return;
-    if (DROP) stage_wt(wt, ldw, D, cb, N, smem, DC_CB);
+    stage_wt(wt, ldw, D, cb, N, smem, DC_CB);
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    f32x2_t* const list = reinterpret_cast<f32x2_t*>(smem + D * DC_CB) + wave * DC_LIST;       // (LDS byte offset of W^T[c], h[c]) pairs
     const char* const wl = reinterpret_cast<const char*>(smem) + 8 * lane;                      // this lane's two columns of row 0
-    const unsigned long long lt = (1ull << lane) - 1ull;
     const int col = cb + 2 * lane;
     const bool col_ok = col < N;
     const int colc = min(col, N - 2);
     const f32x2_t b2 = bias != nullptr ? *reinterpret_cast<const f32x2_t*>(bias + colc) : f32x2_t{0.f, 0.f};
-    const bool has = 4 * lane < D;
-    const int hoff = has ? 4 * lane : 0;
     const int cpw = (r1 - r0 + DC_WAVES - 1) / DC_WAVES;
     const int ws = r0 + wave * cpw, we = min(r1, ws + cpw);
-    for (int gb = ws; gb < we; gb += 64) {
-        const int gi = min(gb + lane, we - 1);
-        const int kv = inv[gi], riv = rowinfo[gi];
-        const int gn = min(64, we - gb);                         // rows of this group
-        auto fetch = [&](Rows4& R, int b) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = min(b + u, gn - 1);
-                const int k = __builtin_amdgcn_readlane(kv, i);
-                R.q[u] = *reinterpret_cast<const f32x2_t*>(qkvu + (size_t)k * ldq + colc);
-                if (DROP) {
-                    const int r = gb + i;
-                    R.h[u] = *reinterpret_cast<const f32x4*>(eu + (size_t)k * lde + hoff);
-                    R.kw[u] = *reinterpret_cast<const uint32_t*>(mask + (uint64_t)(r >> 2) * (uint64_t)D + (uint64_t)hoff);
-                }
-            }
-        };
-        Rows4 cur, nxt;
-        fetch(cur, 0);
-        for (int b = 0; b < gn; b += 4) {
-            fetch(nxt, b + 4);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = b + u;
-                if (i < gn) {                                    // wave-uniform
-                    const int r = gb + i;
-                    const int ri = __builtin_amdgcn_readlane(riv, i);
-                    f32x2_t q = cur.q[u];
-                    if (DROP && (ri & RI_LIVE) != 0) {           // wave-uniform
-                        const float h0 = cur.h[u][0], h1 = cur.h[u][1], h2 = cur.h[u][2], h3 = cur.h[u][3];
-                        const uint32_t kw = has ? (cur.kw[u] >> (r & 3)) : 0xFFFFFFFFu;     // bits 0 / 8 / 16 / 24: keep coordinate 4 lane + j
-                        // the list: coordinate 4 lane + j of a lane that dropped it, in (j, lane) order
-                        int n = 0;
-                        {
-                            const bool d = (kw & 0x00000001u) == 0u;
-                            const unsigned long long m = __ballot(d);
-                            if (d) list[n + __popcll(m & lt)] = f32x2_t{__int_as_float((4 * lane + 0) * DC_CB * 4), h0};
-                            n += __popcll(m);
-                        }
-                        {
-                            const bool d = (kw & 0x00000100u) == 0u;
-                            const unsigned long long m = __ballot(d);
-                            if (d) list[n + __popcll(m & lt)] = f32x2_t{__int_as_float((4 * lane + 1) * DC_CB * 4), h1};
-                            n += __popcll(m);
-                        }
-                        {
-                            const bool d = (kw & 0x00010000u) == 0u;
-                            const unsigned long long m = __ballot(d);
-                            if (d) list[n + __popcll(m & lt)] = f32x2_t{__int_as_float((4 * lane + 2) * DC_CB * 4), h2};
-                            n += __popcll(m);
-                        }
-                        {
-                            const bool d = (kw & 0x01000000u) == 0u;
-                            const unsigned long long m = __ballot(d);
-                            if (d) list[n + __popcll(m & lt)] = f32x2_t{__int_as_float((4 * lane + 3) * DC_CB * 4), h3};
-                            n += __popcll(m);
-                        }
-                        n = __builtin_amdgcn_readfirstlane(n);
-                        // (the list is written and read by this wave only: LDS operations of one wave complete in order)
-                        f32x2_t a0 = f32x2_t{0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
-                        for (int base = 0; base < n; base += 64) {
-                            f32x2_t e = f32x2_t{0.f, 0.f};       // entry base + lane; past the end: row 0 of W^T times 0
-                            if (base + lane < n) e = list[base + lane];
-                            // (__builtin_bit_cast applied straight to an ELEMENT of an ext_vector reads element 0 whatever the index --
-                            // hipcc 7.2, seen in the IR -- so the elements go through scalars of their own first)
-                            const float e0 = e[0], e1 = e[1];
-                            const int ev = __float_as_int(e0), hv = __float_as_int(e1);
-                            const int cnt = min(64, n - base);
-                            for (int t = 0; t < cnt; t += 4) {
-                                const int o0 = __builtin_amdgcn_readlane(ev, t), o1 = __builtin_amdgcn_readlane(ev, t + 1);
-                                const int o2 = __builtin_amdgcn_readlane(ev, t + 2), o3 = __builtin_amdgcn_readlane(ev, t + 3);
-                                const float g0 = __int_as_float(__builtin_amdgcn_readlane(hv, t));
-                                const float g1 = __int_as_float(__builtin_amdgcn_readlane(hv, t + 1));
-                                const float g2 = __int_as_float(__builtin_amdgcn_readlane(hv, t + 2));
-                                const float g3 = __int_as_float(__builtin_amdgcn_readlane(hv, t + 3));
-                                const f32x2_t w0 = *reinterpret_cast<const f32x2_t*>(wl + o0), w1 = *reinterpret_cast<const f32x2_t*>(wl + o1);
-                                const f32x2_t w2 = *reinterpret_cast<const f32x2_t*>(wl + o2), w3 = *reinterpret_cast<const f32x2_t*>(wl + o3);
-                                a0 += g0 * w0;
-                                a1 += g1 * w1;
-                                a2 += g2 * w2;
-                                a3 += g3 * w3;
-                            }
-                        }
-                        q = scale * (q - ((a0 + a1) + (a2 + a3)));
-                    }
-                    q += b2;
-                    if (col_ok) *reinterpret_cast<f32x2_t*>(out + (size_t)r * ldo + col) = q;
-                }
-            }
-            cur = nxt;
+    if (ws >= we) return;
+    // a row's inputs one row ahead: its key (scalar), then q at that key (vector) and the list's length (scalar)
+    int k_nxt = inv[ws];
+    f32x2_t q_nxt = *reinterpret_cast<const f32x2_t*>(qkvu + (size_t)k_nxt * ldq + colc);
+    int n_nxt = cnt[ws];
+    for (int r = ws; r < we; ++r) {
+        f32x2_t q = q_nxt;
+        const int n = n_nxt;
+        if (r + 1 < we) {
+            k_nxt = inv[r + 1];
+            q_nxt = *reinterpret_cast<const f32x2_t*>(qkvu + (size_t)k_nxt * ldq + colc);
+            n_nxt = cnt[r + 1];
         }
+        if (n > 0) {                                             // wave-uniform
+            const uint4* pp = pairs + (size_t)r * stride16;
+            f32x2_t a0 = f32x2_t{0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+            for (int c0 = 0; c0 < n; c0 += DCP_CHUNK, pp += DCP_CHUNK / 2) {
+                const uint4 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];                  // 8 (offset, multiplier) pairs: s_load_dwordx16
+                const f32x2_t w0 = *reinterpret_cast<const f32x2_t*>(wl + p0.x), w1 = *reinterpret_cast<const f32x2_t*>(wl + p0.z);
+                const f32x2_t w2 = *reinterpret_cast<const f32x2_t*>(wl + p1.x), w3 = *reinterpret_cast<const f32x2_t*>(wl + p1.z);
+                const f32x2_t w4 = *reinterpret_cast<const f32x2_t*>(wl + p2.x), w5 = *reinterpret_cast<const f32x2_t*>(wl + p2.z);
+                const f32x2_t w6 = *reinterpret_cast<const f32x2_t*>(wl + p3.x), w7 = *reinterpret_cast<const f32x2_t*>(wl + p3.z);
+                a0 += __uint_as_float(p0.y) * w0;
+                a1 += __uint_as_float(p0.w) * w1;
+                a2 += __uint_as_float(p1.y) * w2;
+                a3 += __uint_as_float(p1.w) * w3;
+                a0 += __uint_as_float(p2.y) * w4;
+                a1 += __uint_as_float(p2.w) * w5;
+                a2 += __uint_as_float(p3.y) * w6;
+                a3 += __uint_as_float(p3.w) * w7;
+            }
+            q = scale * (q - ((a0 + a1) + (a2 + a3)));
+        }
+        q += b2;
+        if (col_ok) *reinterpret_cast<f32x2_t*>(out + (size_t)r * ldo + col) = q;
     }
+}
+
+// the pair lists of a launch: [rows_cap][D] pairs + [rows_cap] lengths, one buffer per device, grown on demand (a launch of another stream that
+// overlaps this one on the same device would share it: the engine's launches of this entry point are on one stream per device)
+static bool dc_pair_buffer(int rows_cap, int D, f32x2_t** pairs, int** cnt) {
+    static std::mutex mu;
+    static std::map<int, std::pair<void*, size_t>> bufs;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const size_t need = (size_t)rows_cap * D * sizeof(f32x2_t) + (size_t)rows_cap * sizeof(int) + 256;      // D = the list stride here (a multiple of DCP_CHUNK)
+    std::lock_guard<std::mutex> lock(mu);
+    auto& b = bufs[dev];
+    if (b.second < need) {
+        if (b.first != nullptr) { (void)hipDeviceSynchronize(); (void)hipFree(b.first); b.first = nullptr; b.second = 0; }
+        void* p = nullptr;
+        if (hipMalloc(&p, need) != hipSuccess) { (void)hipGetLastError(); return false; }
+        b.first = p; b.second = need;
+    }
+    *pairs = reinterpret_cast<f32x2_t*>(b.first);
+    *cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(b.first) + (size_t)rows_cap * D * sizeof(f32x2_t));
+    return true;
 }
 
 static int dc_cus() {
@@ -215,19 +239,26 @@ extern "C" int lego_qkv_expand_dropcorr(const float* qkvu, int ldq, const float*
     const int nblk = (N + DC_CB - 1) / DC_CB;
     int strips = dc_cus() / nblk;
     if (strips < 1) strips = 1;
-    const size_t lds = dropping ? (size_t)D * DC_CB * sizeof(float) + (size_t)DC_WAVES * DC_LIST * 8 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (!dropping) {
+        hipLaunchKernelGGL(qkv_expand_plain_kernel, dim3(nblk * strips), dim3(DC_THREADS), 0, st, qkvu, ldq, bias, inv, rows_cap, rows_dyn, N, out, ldo, strips);
+        return check_launch("lego_qkv_expand_dropcorr");
+    }
+    LEGO_REQUIRE(eu != nullptr && wt != nullptr, "lego_qkv_expand_dropcorr: a dropout site needs the per-key embeddings and W^T");
+    const int stride = (D + DCP_CHUNK - 1) / DCP_CHUNK * DCP_CHUNK;          // pairs per row of the list buffer
+    f32x2_t* pairs = nullptr;
+    int* cnt = nullptr;
+    if (!dc_pair_buffer(rows_cap, stride, &pairs, &cnt))
+        return set_error("lego_qkv_expand_dropcorr: no memory for the pair lists (%d rows x %d pairs)", rows_cap, stride);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qkv_expand_dropcorr_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  256 * DC_CB * 4 + DC_WAVES * DC_LIST * 8);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qkv_expand_pairs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * DC_CB * 4);
         attr_done = true;
     }
-    if (dropping)
-        hipLaunchKernelGGL(qkv_expand_dropcorr_kernel<true>, dim3(nblk * strips), dim3(DC_THREADS), lds, (hipStream_t)stream, qkvu, ldq, eu, lde, wt, ldw,
-                           bias, inv, rowinfo, drop->mask, 1.f / (1.f - drop->p), rows_cap, rows_dyn, D, N, out, ldo, strips);
-    else
-        hipLaunchKernelGGL(qkv_expand_dropcorr_kernel<false>, dim3(nblk * strips), dim3(DC_THREADS), 0, (hipStream_t)stream, qkvu, ldq, eu, lde, wt, ldw,
-                           bias, inv, rowinfo, (const uint8_t*)nullptr, 1.f, rows_cap, rows_dyn, D, N, out, ldo, strips);
+    const int pg = min((rows_cap + DCP_WAVES - 1) / DCP_WAVES, 8 * dc_cus());
+    hipLaunchKernelGGL(dropcorr_pairs_kernel, dim3(pg), dim3(DCP_WAVES * 64), 0, st, eu, lde, inv, rowinfo, drop->mask, rows_cap, rows_dyn, D, pairs, stride, cnt);
+    hipLaunchKernelGGL(qkv_expand_pairs_kernel, dim3(nblk * strips), dim3(DC_THREADS), (size_t)D * DC_CB * sizeof(float), st, qkvu, ldq, wt, ldw, bias, inv,
+                       reinterpret_cast<const uint4*>(pairs), stride / 2, cnt, 1.f / (1.f - drop->p), rows_cap, rows_dyn, D, N, out, ldo, strips);
     return check_launch("lego_qkv_expand_dropcorr");
 }
 
