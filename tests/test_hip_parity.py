@@ -1456,7 +1456,7 @@ def test_nrms_training_trajectory_per_key_in_projection(monkeypatch):
 
 
 @pytest.mark.parametrize("D,R,U,p", [(256, 3000, 500, 0.1), (64, 700, 90, 0.25), (128, 257, 40, 0.5), (256, 5, 3, 0.1), (128, 9001, 700, 0.1),
-                                     (256, 6000, 300, 0.9)])
+                                     (256, 6000, 300, 0.9), (68, 300, 40, 0.3)])      # (0.9: lists of ~230 pairs; 68: a width that is no multiple of the 8-pair load)
 def test_in_projection_per_key_with_dropout_correction(D, R, U, p):
     """csrc/dropcorr_ops.hip against the dense row-by-row form it replaces (embedding_hub.py:95-96 + attention_operator.py:49-55):
     q|k|v rows  E_r W^T + b  with  E_r = keep_r . Eu[k] / (1 - p)  for token rows and  Eu[k]  for the others, from the per-key product
