@@ -108,9 +108,8 @@ int lego_expand_rows(const float* src, int ld_src, const int32_t* inv, int rows_
  * eu[k,c] wt[c,:]) + bias,  s = 1 / (1 - p); for the other rows ([SEP] / category positions, no Dropout): out[r,:] = qkvu[k,:] + bias.
  * drop NULL or p == 0: plain expansion.  The keep bits must be precomputed (lego_dropout_mask over [rows, D]).  D <= 256.
  * With Dropout the call is two launches on `stream` (round 6): the rows' dropped coordinates as (offset, value) pairs into a buffer
- * the library keeps per device -- rows_cap x roundup(D, 8) x 8 bytes (216 MB at rows_cap = 105 600, D = 256), grown on demand, shared
- * by every caller on that device: launches of this entry point on ONE device must not overlap on different streams -- then the
- * expansion, which reads them through the scalar unit. */
+ * the library keeps per (device, stream) -- rows_cap x roundup(D, 8) x 8 bytes (216 MB at rows_cap = 105 600, D = 256), grown on
+ * demand -- then the expansion, which reads them through the scalar unit. */
 int lego_qkv_expand_dropcorr(const float* qkvu, int ldq, const float* eu, int lde, const float* wt, int ldw, const float* bias /*nullable*/,
                              const int32_t* inv, const int32_t* rowinfo, const lego_dropout* drop /*nullable*/, int rows_cap,
                              const int32_t* rows_dyn, int D, int N, float* out, int ldo, void* stream);

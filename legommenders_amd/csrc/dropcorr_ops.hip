@@ -191,24 +191,24 @@ __global__ __launch_bounds__(DC_THREADS) void qkv_expand_pairs_kernel(
     }
 }
 
-// the pair lists of a launch: [rows_cap][D] pairs + [rows_cap] lengths, one buffer per device, grown on demand (a launch of another stream that
-// overlaps this one on the same device would share it: the engine's launches of this entry point are on one stream per device)
-static bool dc_pair_buffer(int rows_cap, int D, f32x2_t** pairs, int** cnt) {
+// the pair lists of a launch: [rows_cap][stride] pairs + [rows_cap] lengths, one buffer per (device, stream) -- launches of one stream run one after
+// the other -- grown on demand
+static bool dc_pair_buffer(hipStream_t st, int rows_cap, int stride, f32x2_t** pairs, int** cnt) {
     static std::mutex mu;
-    static std::map<int, std::pair<void*, size_t>> bufs;
+    static std::map<std::pair<int, hipStream_t>, std::pair<void*, size_t>> bufs;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
-    const size_t need = (size_t)rows_cap * D * sizeof(f32x2_t) + (size_t)rows_cap * sizeof(int) + 256;      // D = the list stride here (a multiple of DCP_CHUNK)
+    const size_t need = (size_t)rows_cap * stride * sizeof(f32x2_t) + (size_t)rows_cap * sizeof(int) + 256;
     std::lock_guard<std::mutex> lock(mu);
-    auto& b = bufs[dev];
+    auto& b = bufs[{dev, st}];
     if (b.second < need) {
-        if (b.first != nullptr) { (void)hipDeviceSynchronize(); (void)hipFree(b.first); b.first = nullptr; b.second = 0; }
+        if (b.first != nullptr) { (void)hipStreamSynchronize(st); (void)hipFree(b.first); b.first = nullptr; b.second = 0; }
         void* p = nullptr;
         if (hipMalloc(&p, need) != hipSuccess) { (void)hipGetLastError(); return false; }
         b.first = p; b.second = need;
     }
     *pairs = reinterpret_cast<f32x2_t*>(b.first);
-    *cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(b.first) + (size_t)rows_cap * D * sizeof(f32x2_t));
+    *cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(b.first) + (size_t)rows_cap * stride * sizeof(f32x2_t));
     return true;
 }
 
@@ -248,7 +248,7 @@ extern "C" int lego_qkv_expand_dropcorr(const float* qkvu, int ldq, const float*
     const int stride = (D + DCP_CHUNK - 1) / DCP_CHUNK * DCP_CHUNK;          // pairs per row of the list buffer
     f32x2_t* pairs = nullptr;
     int* cnt = nullptr;
-    if (!dc_pair_buffer(rows_cap, stride, &pairs, &cnt))
+    if (!dc_pair_buffer(st, rows_cap, stride, &pairs, &cnt))
         return set_error("lego_qkv_expand_dropcorr: no memory for the pair lists (%d rows x %d pairs)", rows_cap, stride);
     static bool attr_done = false;
     if (!attr_done) {
